@@ -1,0 +1,181 @@
+/* sntc.h -- C ABI of the MI355X-native shallow-ntc hot path (libsntc_hip.so).
+ *
+ * The reference (mandt-lab/shallow-ntc) has no FFI: its arithmetic is TensorFlow /
+ * tensorflow-compression ops called from Python.  Each entry point below replaces ONE of those
+ * dependency ops at the place the reference calls it; the citations are reference file:line.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add to the reference.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types cross the boundary.
+ *   - every function returns an int status (SNTC_OK == 0); sntc_last_error() gives the
+ *     thread-local message of the last failure.  No exceptions cross the boundary.
+ *   - all tensor pointers are DEVICE pointers to dense NHWC float32 unless stated; the caller
+ *     owns every buffer.  The library owns only what a plan / prior object packs at creation.
+ *   - every launch takes a hipStream_t (passed as void*) and is asynchronous w.r.t. the host.
+ *   - one process per GPU; objects are bound to the device current at creation.
+ */
+#ifndef SNTC_H_
+#define SNTC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNTC_VERSION 100
+
+/* status codes (mirroring the failure classes of the reference: Python ValueError for shapes /
+ * configs, tf InvalidArgumentError from check_numerics at mshyper/models.py:308-309,356) */
+enum {
+  SNTC_OK = 0,
+  SNTC_ERR_BAD_SHAPE = 1,      /* inconsistent sizes / null pointer                           */
+  SNTC_ERR_UNSUPPORTED = 2,    /* configuration outside what the kernels implement            */
+  SNTC_ERR_HIP = 3,            /* HIP runtime error (message carries hipGetErrorString)       */
+  SNTC_ERR_NONFINITE = 4,      /* NaN/Inf where the reference's check_numerics would raise    */
+  SNTC_ERR_NO_DEVICE = 5       /* no gfx950 device visible                                    */
+};
+
+const char* sntc_last_error(void);
+int sntc_version(void);
+/* Number of visible HIP devices, 0 if none; never fails. */
+int sntc_device_count(void);
+/* Writes the gcnArchName of `device` ("gfx950:sramecc+:xnack-") into buf. */
+int sntc_device_arch(int device, char* buf, size_t buflen);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution plans
+ *   replaces tf.keras.layers.Conv2D / Conv2DTranspose (padding="SAME") and tfc.SignalConv2D
+ *   (padding="same_zeros") at common/transforms.py:81-90,101-134,152-155,172-175,186-231,
+ *   240-262,284-287,307-313,331-357,371-373 and common/elic.py:61-63,92-93,136-140,253-270;
+ *   and the 1x1 norm-pool contraction of GDN / GDN1 at common/transforms.py:8-63,150,170.
+ * ------------------------------------------------------------------------------------------ */
+enum {                       /* sntc_conv_desc.kind */
+  SNTC_CONV2D = 0,           /* Keras Conv2D SAME, kernel [kh,kw,Cin,Cout], cross-correlation */
+  SNTC_CONV2D_TRANSPOSE = 1, /* Keras Conv2DTranspose SAME, kernel [kh,kw,Cout,Cin]           */
+  SNTC_SIGNAL_DOWN = 2,      /* tfc.SignalConv2D corr=True, strides_down, same_zeros, [kh,kw,Cin,Cout] */
+  SNTC_SIGNAL_UP = 3         /* tfc.SignalConv2D corr=False, strides_up, same_zeros, [kh,kw,Cin,Cout]  */
+};
+enum {                       /* activation applied after bias (Keras `activation=`) */
+  SNTC_ACT_NONE = 0, SNTC_ACT_RELU = 1, SNTC_ACT_LEAKY_RELU = 2 /* alpha 0.2 */, SNTC_ACT_SIGMOID = 3
+};
+enum {                       /* input transform applied to x while it is staged (GDN norm pool) */
+  SNTC_PRO_NONE = 0, SNTC_PRO_ABS = 1, SNTC_PRO_SQUARE = 2
+};
+enum {                       /* epilogue, v = act(conv + bias) */
+  SNTC_EPI_STORE = 0,        /* y = v                                                          */
+  SNTC_EPI_ADD = 1,          /* y = v + res                (ResidualBlock skip, elic.py:66-68)  */
+  SNTC_EPI_GATE = 2,         /* y = res + aux * v          (SimpleAttention, elic.py:97-100)    */
+  SNTC_EPI_RES_DIV = 3,      /* y = res / v                (GDN1 forward, transforms.py:63)     */
+  SNTC_EPI_RES_MUL = 4,      /* y = res * v                (GDN1 inverse, transforms.py:61)     */
+  SNTC_EPI_RES_DIV_SQRT = 5, /* y = res / sqrt(v)          (classic tfc.GDN)                    */
+  SNTC_EPI_RES_MUL_SQRT = 6  /* y = res * sqrt(v)          (classic inverse tfc.GDN)            */
+};
+
+typedef struct sntc_conv_desc {
+  int32_t kind;        /* SNTC_CONV2D ...                                  */
+  int32_t kh, kw;      /* kernel size                                      */
+  int32_t stride;      /* strides (down for conv, up for transpose)        */
+  int32_t cin, cout;   /* channels                                         */
+  int32_t act;         /* SNTC_ACT_*                                       */
+  int32_t prologue;    /* SNTC_PRO_*                                       */
+  int32_t epilogue;    /* SNTC_EPI_*                                       */
+  int32_t reserved[7];
+} sntc_conv_desc;
+
+typedef struct sntc_conv_plan sntc_conv_plan;
+
+/* Packs `weight` (device pointer, layout per desc.kind) and `bias` (device [cout] or NULL) into
+ * the gather-GEMM layout on `stream`.  The plan keeps its own packed copy; weight/bias may be
+ * freed after the stream work completes. */
+int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* weight, const float* bias,
+                          void* stream, sntc_conv_plan** plan);
+void sntc_conv_plan_destroy(sntc_conv_plan* plan);
+/* Output spatial size for an input of h x w. */
+int sntc_conv_out_shape(const sntc_conv_plan* plan, int h, int w, int* ho, int* wo);
+/* Algorithmic 2*MAC FLOPs of one forward call (dense count, as tf.profiler counts them). */
+int64_t sntc_conv_flops(const sntc_conv_plan* plan, int n, int h, int w);
+/* y[n,ho,wo,cout] = epilogue(act(conv(prologue(x[n,h,w,cin])) + bias), res, aux).
+ * res / aux are NHWC tensors of the OUTPUT shape (NULL unless the epilogue uses them). */
+int sntc_conv_forward(const sntc_conv_plan* plan, const float* x, int n, int h, int w, float* y,
+                      const float* res, const float* aux, void* stream);
+/* Tile-selection override for experiments: 0 = heuristic. Returns previous value. */
+int sntc_conv_set_tile_override(int variant);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-channel GDN1 / IGDN1 (C <= 64): wave-shuffle contraction, no MFMA.
+ *   replaces GDN1.call, common/transforms.py:26-63.  gamma is [C(in), C(out)], effective values.
+ *   alpha in {1,2}; epsilon_is_half selects ^0.5.
+ * ------------------------------------------------------------------------------------------ */
+int sntc_gdn_small(const float* x, int64_t npix, int c, const float* beta, const float* gamma,
+                   int inverse, int alpha, int epsilon_is_half, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Two-layer synthesis tail: h = act(t[..., :Ch]) (+ t[..., Ch:2Ch] if has_res);
+ *   x_hat = Conv2DTranspose_{k2 x k2 / s2, SAME}(h) + bias2        (float, NHWC [n, s2*hh, s2*wh, 3])
+ *   replaces the IGDN1 + add + out_conv of TwoLayer[Res]Synthesis.call,
+ *   common/transforms.py:315-317,359-361 (out_conv kernel [k2,k2,3,Ch]).
+ *   act_kind: 0 none, 1 IGDN1, 2 GDN1, 3 relu, 4 leaky_relu.   Ch <= 48, k2 <= 5, s2 == 2.
+ * ------------------------------------------------------------------------------------------ */
+int sntc_two_layer_tail(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind,
+                        const float* beta, const float* gamma, const float* w2, const float* b2,
+                        int k2, int s2, int cout, float* x_hat, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pixel domain
+ *   pad_images / unpad_images       common/image_utils.py:41-71
+ *   floats_to_pixels + mse_psnr     common/data_lib.py:48-52, common/image_utils.py:22-38
+ * ------------------------------------------------------------------------------------------ */
+/* Reflect-pad bottom/right: y[n,hp,wp,c] from x[n,h,w,c]  (hp>=h, wp>=w, pads < size). */
+int sntc_pad_reflect(const float* x, int n, int h, int w, int c, int hp, int wp, float* y, void* stream);
+/* Crop top-left: y[n,h,w,c] from x[n,hp,wp,c]. */
+int sntc_crop(const float* x, int n, int hp, int wp, int c, int h, int w, float* y, void* stream);
+/* Quantise both images to uint8 the reference's way ((v+.5)*255, round-half-even, saturate) and
+ * accumulate the per-image integer sum of squared differences.  x_hat may be strided (crop fused):
+ * element (b,i,j,k) at x_hat[((b*hs + i)*ws + j)*c + k].  pixels_out (uint8 [n,h,w,c]) may be NULL.
+ * sse_out: uint64 [n], OVERWRITTEN (zeroed on stream first).  x == NULL: only quantise x_hat into
+ * pixels_out (the decoder's last step); sse_out is then ignored. */
+int sntc_pixels_sse(const float* x, const float* x_hat, int n, int h, int w, int c, int hs, int ws,
+                    uint8_t* pixels_out, unsigned long long* sse_out, void* stream);
+/* Training-mode distortion (SGA): sum over (255*(x - x_hat))^2 in float, per image, double out. */
+int sntc_float_sse(const float* x, const float* x_hat, int n, int h, int w, int c, int hs, int ws,
+                   double* sse_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Entropy models (compression=False paths: rate *estimates*, as the reference evaluates them)
+ * ------------------------------------------------------------------------------------------ */
+/* tfc.DeepFactorized parameters for C channels, `nlayers` = len(num_filters)+1 affine layers of
+ * widths 1 -> f1 -> ... -> 1 (widths[nlayers+1], each <= 4).  Raw TFC variables (softplus / tanh
+ * are applied inside): matrices[k] [C,f_{k+1},f_k], biases[k] [C,f_{k+1}], factors[k] [C,f_{k+1}],
+ * concatenated per kind in layer order as host float arrays. */
+typedef struct sntc_prior sntc_prior;
+int sntc_prior_create(int channels, int nlayers, const int* widths, const float* matrices,
+                      const float* biases, const float* factors, void* stream, sntc_prior** prior);
+void sntc_prior_destroy(sntc_prior* prior);
+
+/* tfc.ContinuousBatchedEntropyModel(NoisyDeepFactorized, coding_rank=3, compression=False)
+ *   __call__(z, training=False): mshyper/models.py:249-255, factorized/models.py:101-105.
+ * z[n, hw, C] -> z_hat = round(z) (float) and bits[n] (double, -sum log2 p).
+ * values_only != 0: skip rounding and evaluate bits at z as given (log_prob of an explicit sample,
+ *   mshyper/models.py:262-268). */
+int sntc_entropy_factorized(const sntc_prior* prior, const float* z, int n, int64_t hw, float* z_hat,
+                            double* bits, int values_only, void* stream);
+
+/* tfc.LocationScaleIndexedEntropyModel(NoisyNormal, 64, SCALE_FN, coding_rank=3,
+ *   compression=False)(y, indexes=exp(raw), loc=mu, training=False): mshyper/models.py:273-279.
+ * hyper[n, hw, 2C] holds mu = hyper[..., :C] and raw = hyper[..., C:]  (tf.split + tf.exp fused).
+ * Outputs: y_hat = round(y - mu) + mu (float), symbols = round(y - mu) as int32 (may be NULL),
+ * bits[n] (double).  values_only != 0: y is an explicit sample; bits evaluated at y - mu without
+ * rounding, y_hat/symbols untouched (mshyper/models.py:285-291). */
+int sntc_entropy_scale_normal(const float* y, const float* hyper, int n, int64_t hw, int c,
+                              float* y_hat, int32_t* symbols, double* bits, int values_only,
+                              void* stream);
+/* Decoder-side dequantisation: y_hat = symbols + mu  (mu = hyper[..., :C]). */
+int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n, int64_t hw, int c,
+                              float* y_hat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNTC_H_ */

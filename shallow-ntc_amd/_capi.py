@@ -1,0 +1,115 @@
+"""ctypes binding of libsntc_hip.so (include/sntc.h).
+
+There is no CPU fallback: importing this module without the built library raises, and every call
+that returns a non-zero status raises :class:`SntcError` carrying ``sntc_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("SNTC_LIB", _PKG / "lib" / "libsntc_hip.so"))
+
+OK, ERR_BAD_SHAPE, ERR_UNSUPPORTED, ERR_HIP, ERR_NONFINITE, ERR_NO_DEVICE = range(6)
+
+CONV2D, CONV2D_TRANSPOSE, SIGNAL_DOWN, SIGNAL_UP = range(4)
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID = range(4)
+PRO_NONE, PRO_ABS, PRO_SQUARE = range(3)
+EPI_STORE, EPI_ADD, EPI_GATE, EPI_RES_DIV, EPI_RES_MUL, EPI_RES_DIV_SQRT, EPI_RES_MUL_SQRT = range(7)
+
+
+class SntcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sntc error {code}: {msg}")
+        self.code = code
+
+
+class NonFiniteError(SntcError, ValueError):
+    """Mirrors tf.debugging.check_numerics' InvalidArgumentError (reference mshyper/models.py:308-309,356)."""
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("act", C.c_int32), ("prologue", C.c_int32),
+                ("epilogue", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+# name -> (restype, argtypes); every symbol include/sntc.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "sntc_last_error": (C.c_char_p, []),
+    "sntc_version": (C.c_int, []),
+    "sntc_device_count": (C.c_int, []),
+    "sntc_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "sntc_conv_plan_create": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(_P)]),
+    "sntc_conv_plan_destroy": (None, [_P]),
+    "sntc_conv_out_shape": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sntc_conv_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
+    "sntc_conv_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "sntc_conv_set_tile_override": (C.c_int, [C.c_int]),
+    "sntc_gdn_small": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sntc_two_layer_tail": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,
+                                      C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sntc_pad_reflect": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sntc_crop": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sntc_pixels_sse": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "sntc_float_sse": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sntc_prior_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float), _P, C.POINTER(_P)]),
+    "sntc_prior_destroy": (None, [_P]),
+    "sntc_entropy_factorized": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P]),
+    "sntc_entropy_scale_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "sntc_dequant_scale_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsntc_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C shallow-ntc_amd/csrc`.  There is no CPU fallback for the hot path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().sntc_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    if rc != OK:
+        msg = last_error()
+        raise (NonFiniteError if rc == ERR_NONFINITE else SntcError)(rc, msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def device_count() -> int:
+    return load().sntc_device_count()
+
+
+def require_gpu():
+    """Fail loudly when the hot path is asked to run without a gfx950 device."""
+    if device_count() < 1:
+        raise SntcError(ERR_NO_DEVICE, "no HIP device visible: the shallow-ntc hot path only runs on MI355X (gfx950)")
+
+
+def device_arch(device=0) -> str:
+    buf = C.create_string_buffer(256)
+    check(load().sntc_device_arch(device, buf, 256))
+    return buf.value.decode()

@@ -1,0 +1,161 @@
+"""Layer nodes the transforms are assembled from; each node owns its packed device plans.
+
+A node has
+    shapes(cin) -> (OrderedDict name -> shape, cout)      variable inventory in Keras / TFC layouts
+    build(w, cin) -> cout                                 create device plans from device weights w
+    __call__(x) -> y                                      launch
+Fusions: bias + activation in every conv epilogue; the ResidualBlock skip (elic.py:66-68) and the
+SimpleAttention gate (elic.py:97-100) ride on the last 1x1 conv's epilogue; GDN's norm pool is a
+1x1 gather-GEMM with |x| (or x^2) applied while staging and x / norm in the epilogue.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+from .. import _capi as capi
+from .. import ops
+
+
+class Conv:
+    """kind: conv (Keras Conv2D SAME) | convT (Keras Conv2DTranspose SAME) | sigdown / sigup (tfc.SignalConv2D)."""
+
+    def __init__(self, name, kind, cout, k, s, act=None, bias=True, epilogue=capi.EPI_STORE):
+        self.name, self.kind, self.cout, self.k, self.s, self.act, self.bias = name, kind, cout, k, s, act, bias
+        self.epilogue = epilogue
+        self.plan = None
+
+    def shapes(self, cin):
+        d = OrderedDict()
+        d[f"{self.name}/kernel"] = (self.k, self.k, self.cout, cin) if self.kind == "convT" else (self.k, self.k, cin, self.cout)
+        if self.bias:
+            d[f"{self.name}/bias"] = (self.cout,)
+        return d, self.cout
+
+    def build(self, w, cin):
+        self.plan = ops.ConvPlan(self.kind, w[f"{self.name}/kernel"], w.get(f"{self.name}/bias") if self.bias else None,
+                                 self.s, self.act, capi.PRO_NONE, self.epilogue)
+        return self.cout
+
+    def __call__(self, x, res=None, aux=None):
+        return self.plan(x, res, aux)
+
+    def flops(self, n, h, w):
+        return self.plan.flops(n, h, w), self.plan.out_hw(h, w)
+
+
+class GDN:
+    """GDN1 (transforms.py:8-63) or tfc.GDN with fixed alpha in {1,2}, epsilon in {1, .5}."""
+
+    def __init__(self, name, inverse=False, alpha=1, epsilon=1.0):
+        if alpha not in (1, 2) or epsilon not in (1, 1.0, 0.5):
+            raise NotImplementedError(f"GDN alpha={alpha} epsilon={epsilon}")
+        self.name, self.inverse, self.alpha, self.epsilon = name, inverse, alpha, float(epsilon)
+        self.plan = None
+        self.beta = self.gamma = None
+
+    def shapes(self, cin):
+        return OrderedDict([(f"{self.name}/beta", (cin,)), (f"{self.name}/gamma", (cin, cin))]), cin
+
+    def build(self, w, cin):
+        self.beta, self.gamma = w[f"{self.name}/beta"], w[f"{self.name}/gamma"]
+        self.c = cin
+        if cin not in ops.GDN_SMALL_CHANNELS:
+            pro = capi.PRO_ABS if self.alpha == 1 else capi.PRO_SQUARE
+            if self.epsilon == 0.5:
+                epi = capi.EPI_RES_MUL_SQRT if self.inverse else capi.EPI_RES_DIV_SQRT
+            else:
+                epi = capi.EPI_RES_MUL if self.inverse else capi.EPI_RES_DIV
+            # gamma[in, out] is exactly a 1x1 HWIO kernel; beta is its bias
+            self.plan = ops.ConvPlan("conv", self.gamma.reshape(1, 1, cin, cin), self.beta, 1, None, pro, epi)
+        return cin
+
+    def __call__(self, x):
+        if self.plan is not None:
+            return self.plan(x, res=x)
+        return ops.gdn_small(x, self.beta, self.gamma, self.inverse, self.alpha, self.epsilon)
+
+
+class Seq:
+    def __init__(self, layers):
+        self.layers = list(layers)
+
+    def shapes(self, cin):
+        d = OrderedDict()
+        for l in self.layers:
+            s, cin = l.shapes(cin)
+            for k, v in s.items():
+                if k in d and d[k] != v:
+                    raise ValueError(f"shared variable {k} used with shapes {d[k]} and {v}")
+                d[k] = v
+        return d, cin
+
+    def build(self, w, cin):
+        for l in self.layers:
+            cin = l.build(w, cin)
+        return cin
+
+    def __call__(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+class ResidualBlock:
+    """elic.py:41-68."""
+
+    def __init__(self, name):
+        self.name = name
+        self._convs = None
+
+    def _mk(self, c):
+        n = self.name
+        return [Conv(f"{n}/conv0", "conv", c // 2, 1, 1, "relu"), Conv(f"{n}/conv1", "conv", c // 2, 3, 1, "relu"),
+                Conv(f"{n}/conv2", "conv", c, 1, 1, None, epilogue=capi.EPI_ADD)]
+
+    def shapes(self, cin):
+        return Seq(self._mk(cin)).shapes(cin)
+
+    def build(self, w, cin):
+        self._convs = self._mk(cin)
+        c = cin
+        for l in self._convs:
+            c = l.build(w, c)
+        return cin
+
+    def __call__(self, x):
+        a, b, c = self._convs
+        return c(b(a(x)), res=x)
+
+
+class SimpleAttention:
+    """elic.py:71-100: x + trunk(x) * sigmoid(conv1x1(branch(x)))."""
+
+    def __init__(self, name):
+        self.name = name
+        self._trunk = self._branch = self._gate = None
+
+    def _mk(self, c):
+        n = self.name
+        trunk = [ResidualBlock(f"{n}/trunk/rb{i}") for i in range(3)]
+        branch = [ResidualBlock(f"{n}/branch/rb{i}") for i in range(3)]
+        gate = Conv(f"{n}/branch/conv", "conv", c, 1, 1, "sigmoid", epilogue=capi.EPI_GATE)
+        return trunk, branch, gate
+
+    def shapes(self, cin):
+        t, b, g = self._mk(cin)
+        return Seq(t + b + [g]).shapes(cin)
+
+    def build(self, w, cin):
+        self._trunk, self._branch, self._gate = self._mk(cin)
+        for l in self._trunk + self._branch + [self._gate]:
+            l.build(w, cin)
+        return cin
+
+    def __call__(self, x):
+        t = x
+        for l in self._trunk:
+            t = l(t)
+        b = x
+        for l in self._branch:
+            b = l(b)
+        return self._gate(b, res=x, aux=t)

@@ -1,0 +1,417 @@
+"""Analysis / synthesis / hyper transforms: the reference's registry, MI355X arithmetic.
+
+Same class names, keyword arguments and call convention as reference common/transforms.py
+(registry :380-393) and common/elic.py; ``class_builder.build(cls_name, **kwargs)`` is the plugin
+point mshyper/models.py:112-131 uses.  A transform is ``t(x, training=False)`` on NHWC float32
+CUDA tensors.  Like a Keras layer it is *built* on first use (input channels are inferred from the
+input) with framework-default initial values -- glorot-uniform kernels, zero biases, GDN beta = 1,
+gamma = 0.1 I -- and ``set_weights`` loads trained values given as ``{name: ndarray}`` in the
+Keras / TFC variable layouts (Conv2D [kh,kw,Cin,Cout]; Conv2DTranspose [kh,kw,Cout,Cin];
+SignalConv2D [kh,kw,Cin,Cout]; GDN beta [C], gamma [Cin,Cout], effective values).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import ops
+from ._graph import GDN, Conv, ResidualBlock, Seq, SimpleAttention
+from .utils import ClassBuilder
+
+
+def get_activation_op(activation, name="act"):
+    """reference transforms.py:66-78 -> (conv epilogue activation, separate GDN node or None)."""
+    if activation is None:
+        return None, None
+    if activation == "prelu":
+        raise NotImplementedError("prelu is not used by any reference config")
+    a = activation.lower()
+    if a in ("gdn", "gdn1"):
+        return None, GDN(name, inverse=False)
+    if a in ("igdn", "igdn1"):
+        return None, GDN(name, inverse=True)
+    if a == "lrelu":
+        a = "leaky_relu"
+    if a not in ("relu", "leaky_relu", "sigmoid"):
+        raise NotImplementedError(f"activation {activation!r}")
+    return a, None
+
+
+def _glorot(rng, shape):
+    rec = shape[0] * shape[1]
+    limit = np.sqrt(6.0 / (shape[2] * rec + shape[3] * rec))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+def default_init(shapes, seed):
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, shp in shapes.items():
+        leaf = name.rsplit("/", 1)[-1]
+        if leaf == "kernel":
+            out[name] = _glorot(rng, shp)
+        elif leaf == "bias":
+            out[name] = np.zeros(shp, np.float32)
+        elif leaf == "beta":
+            out[name] = np.ones(shp, np.float32)
+        elif leaf == "gamma":
+            out[name] = (0.1 * np.eye(shp[0])).astype(np.float32)
+        else:
+            raise KeyError(name)
+    return out
+
+
+class Transform:
+    """Base: holds the node graph, host weights, and (once built) the packed device plans."""
+
+    def __init__(self, graph, input_channels=None, seed=4321):
+        self._graph = graph
+        self._cin = input_channels
+        self._seed = seed
+        self._weights = None          # host, OrderedDict name -> float32 ndarray
+        self._built_on = None
+        self.output_channels = None
+
+    # -- variables ---------------------------------------------------------------------------
+    def param_shapes(self, input_channels=None):
+        cin = input_channels or self._cin
+        if cin is None:
+            raise ValueError("input channels unknown: pass input_channels or call the transform once")
+        return self._graph.shapes(cin)[0]
+
+    def num_params(self, input_channels=None):
+        return int(sum(int(np.prod(s)) for s in self.param_shapes(input_channels).values()))
+
+    def get_weights(self):
+        if self._weights is None:
+            self._weights = default_init(self.param_shapes(), self._seed)
+        return self._weights
+
+    def set_weights(self, weights, input_channels=None):
+        if input_channels is not None:
+            self._cin = input_channels
+        shapes = self.param_shapes()
+        missing = [k for k in shapes if k not in weights]
+        if missing:
+            raise KeyError(f"missing variables: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        w = OrderedDict()
+        for k, shp in shapes.items():
+            a = np.asarray(weights[k], dtype=np.float32)
+            if tuple(a.shape) != tuple(shp):
+                raise ValueError(f"{k}: expected shape {tuple(shp)}, got {tuple(a.shape)}")
+            w[k] = a
+        self._weights = w
+        self._built_on = None
+
+    def build(self, input_channels=None, device=None):
+        if input_channels is not None:
+            if self._cin is not None and self._cin != input_channels and self._built_on is not None:
+                raise ValueError(f"transform built for {self._cin} input channels, got {input_channels}")
+            self._cin = input_channels
+        device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self._built_on == device:
+            return self
+        host = self._prepare_weights(self.get_weights())
+        dev = {k: ops.to_device(v, device) for k, v in host.items()}
+        with torch.cuda.device(device):
+            self.output_channels = self._graph.build(dev, self._graph_cin())
+        self._dev = dev
+        self._built_on = device
+        return self
+
+    def _graph_cin(self):
+        return self._cin
+
+    def _prepare_weights(self, w):
+        return w
+
+    # -- call -----------------------------------------------------------------------------------
+    def __call__(self, x, training=False):
+        if self._built_on != x.device:
+            self.build(x.shape[-1], x.device)
+        return self._forward(x)
+
+    def _forward(self, x):
+        return self._graph(x)
+
+    def out_channels(self, input_channels=None):
+        return self._graph.shapes(input_channels or self._cin)[1]
+
+
+class BLS2017Analysis(Transform):
+    """reference transforms.py:93-112."""
+
+    def __init__(self, num_filters):
+        f = num_filters
+        super().__init__(Seq([Conv("layer_0", "sigdown", f, 9, 4), GDN("gdn_0"),
+                              Conv("layer_1", "sigdown", f, 5, 2), GDN("gdn_1"),
+                              Conv("layer_2", "sigdown", f, 5, 2, bias=False)]), 3)
+
+
+class BLS2017Synthesis(Transform):
+    """reference transforms.py:115-134."""
+
+    def __init__(self, num_filters):
+        f = num_filters
+        super().__init__(Seq([Conv("layer_0", "sigup", f, 5, 2), GDN("igdn_0", inverse=True),
+                              Conv("layer_1", "sigup", f, 5, 2), GDN("igdn_1", inverse=True),
+                              Conv("layer_2", "sigup", 3, 9, 4)]))
+
+
+class MBT2018Analysis(Transform):
+    """reference transforms.py:137-155.  ``tfc.GDN(name=...)`` is constructed with TFC's defaults;
+    gdn_alpha / gdn_epsilon choose the form (1, 1 = TFC 2.x default; 2, 0.5 = classic GDN)."""
+
+    def __init__(self, channels_base, n_layers=4, output_channels=None, gdn_alpha=1, gdn_epsilon=1.0):
+        layers = []
+        for i in range(n_layers):
+            last = i + 1 == n_layers
+            ch = (output_channels if output_channels is not None else channels_base) if last else channels_base
+            layers.append(Conv(f"layer_{i}", "sigdown", ch, 5, 2))
+            if not last:
+                layers.append(GDN(f"gdn_{i}", False, gdn_alpha, gdn_epsilon))
+        super().__init__(Seq(layers), 3)
+
+
+class MBT2018Synthesis(Transform):
+    """reference transforms.py:158-175."""
+
+    def __init__(self, channels_base, n_layers=4, output_channels=3, gdn_alpha=1, gdn_epsilon=1.0):
+        layers = []
+        for i in range(n_layers):
+            last = i + 1 == n_layers
+            ch = (output_channels if output_channels is not None else channels_base) if last else channels_base
+            layers.append(Conv(f"layer_{i}", "sigup", ch, 5, 2))
+            if not last:
+                layers.append(GDN(f"igdn_{i}", True, gdn_alpha, gdn_epsilon))
+        super().__init__(Seq(layers))
+
+
+def _four_layer(kind, channels_base, last_channels, activation_type):
+    act, extra = get_activation_op(activation_type)     # ONE activation object shared by the layers (:183,199)
+    layers = []
+    for i in range(4):
+        last = i == 3
+        layers.append(Conv(f"layer_{i}", kind, last_channels if last else channels_base, 5, 2, None if last else act))
+        if extra is not None and not last:
+            layers.append(extra)
+    return Seq(layers)
+
+
+class CNNAnalysis(Transform):
+    """reference transforms.py:179-192."""
+
+    def __init__(self, channels_base, output_channels=None, activation_type="leaky_relu"):
+        oc = channels_base if output_channels is None else output_channels
+        super().__init__(_four_layer("conv", channels_base, oc, activation_type), 3)
+
+
+class CNNSynthesis(Transform):
+    """reference transforms.py:195-206."""
+
+    def __init__(self, channels_base, output_channels=3, activation_type="leaky_relu"):
+        super().__init__(_four_layer("convT", channels_base, output_channels, activation_type))
+
+
+class HyperAnalysis(Transform):
+    """reference transforms.py:209-219."""
+
+    def __init__(self, bottleneck_size, activation_type="relu"):
+        act, _ = get_activation_op(activation_type)
+        b = bottleneck_size
+        super().__init__(Seq([Conv("layer_0", "conv", b, 3, 1, act), Conv("layer_1", "conv", b, 5, 2, act),
+                              Conv("layer_2", "conv", b, 5, 2, None)]))
+
+
+class HyperSynthesis(Transform):
+    """reference transforms.py:222-232."""
+
+    def __init__(self, bottleneck_size, activation_type="relu"):
+        act, _ = get_activation_op(activation_type)
+        b = bottleneck_size
+        super().__init__(Seq([Conv("layer_0", "convT", b, 5, 2, act), Conv("layer_1", "convT", int(b * 1.5), 5, 2, act),
+                              Conv("layer_2", "convT", b * 2, 3, 1, None)]))
+
+
+class HyperAnalysisSmall(Transform):
+    """reference transforms.py:235-247."""
+
+    def __init__(self, bottleneck_size):
+        b = bottleneck_size
+        super().__init__(Seq([Conv("layer_0", "sigdown", b, 3, 1, "relu"),
+                              Conv("layer_1", "sigdown", b, 5, 2, None, bias=False)]))
+
+
+class HyperSynthesisSmall(Transform):
+    """reference transforms.py:250-262."""
+
+    def __init__(self, bottleneck_size):
+        b = bottleneck_size
+        super().__init__(Seq([Conv("layer_0", "sigup", int(b * 1.5), 5, 2, "relu"),
+                              Conv("layer_1", "sigup", int(b * 2), 3, 1, None)]))
+
+
+class JPEGLikeSynthesis(Transform):
+    """reference transforms.py:265-295: one Conv2DTranspose(k, s) mapping each latent vector to an
+    overlapping k x k x 3 patch."""
+
+    def __init__(self, output_channels=3, kernel_size=16, strides=16, padding="SAME", use_bias=True, use_offset=False):
+        if padding != "SAME":
+            raise NotImplementedError("only padding='SAME' is used by the reference configs")
+        if use_offset:
+            raise NotImplementedError("use_offset=True (a constant extra input channel) is not used by any reference config")
+        super().__init__(Seq([Conv("conv", "convT", output_channels, kernel_size, strides, None, use_bias)]))
+
+
+class JPEGLikeHyperSynthesis(Transform):
+    """reference transforms.py:364-377."""
+
+    def __init__(self, bottleneck_size, kernel_size=6):
+        super().__init__(Seq([Conv("conv", "convT", bottleneck_size * 2, kernel_size, 4, None)]))
+
+
+class _TwoLayerBase(Transform):
+    """Shared driver of the two-layer syntheses: ONE stride-8 transposed conv producing [base | res]
+    (the two 13x13 kernels are concatenated along Cout, since they read the same input), then the
+    fused tail kernel (activation + residual add + 5x5/2 output layer)."""
+
+    def __init__(self, channels, strides, kernel_sizes, activation_type, has_res):
+        self._ch, self._out_ch = int(channels[0]), int(channels[1])
+        self._s, self._k = tuple(strides), tuple(kernel_sizes)
+        self._has_res = has_res
+        a = None if activation_type is None else activation_type.lower()
+        if a not in ops.TAIL_ACTS:
+            raise NotImplementedError(f"activation {activation_type!r} in the two-layer synthesis")
+        self._act_kind = ops.TAIL_ACTS[a]
+        if self._ch not in ops.TAIL_CHANNELS or self._k[1] != 5 or self._s[1] != 2 or self._out_ch != 3:
+            raise NotImplementedError("two-layer synthesis tail is fused for hidden channels 12/24/48, "
+                                      "5x5 stride-2 output layer, 3 output channels (the reference configs)")
+        super().__init__(None)
+        self._names = ("base_conv", "res", "out_conv") if has_res else ("conv1", None, "conv2")
+
+    def param_shapes(self, input_channels=None):
+        cin = input_channels or self._cin
+        if cin is None:
+            raise ValueError("input channels unknown")
+        n1, nr, n2 = self._names
+        d = OrderedDict()
+        d[f"{n1}/kernel"] = (self._k[0], self._k[0], self._ch, cin)
+        d[f"{n1}/bias"] = (self._ch,)
+        if self._act_kind in (1, 2):
+            d["act/beta"] = (self._ch,)
+            d["act/gamma"] = (self._ch, self._ch)
+        if nr:
+            d[f"{nr}/kernel"] = (self._k[0], self._k[0], self._ch, cin)
+            d[f"{nr}/bias"] = (self._ch,)
+        d[f"{n2}/kernel"] = (self._k[1], self._k[1], self._out_ch, self._ch)
+        d[f"{n2}/bias"] = (self._out_ch,)
+        return d
+
+    def out_channels(self, input_channels=None):
+        return self._out_ch
+
+    def build(self, input_channels=None, device=None):
+        if input_channels is not None:
+            self._cin = input_channels
+        device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self._built_on == device:
+            return self
+        w = self.get_weights()
+        n1, nr, n2 = self._names
+        k1, b1 = w[f"{n1}/kernel"], w[f"{n1}/bias"]
+        if nr:
+            k1 = np.concatenate([k1, w[f"{nr}/kernel"]], axis=2)
+            b1 = np.concatenate([b1, w[f"{nr}/bias"]])
+        with torch.cuda.device(device):
+            self._up = ops.ConvPlan("convT", ops.to_device(k1, device), ops.to_device(b1, device), self._s[0])
+        self._beta = ops.to_device(w["act/beta"], device) if "act/beta" in w else None
+        self._gamma = ops.to_device(w["act/gamma"], device) if "act/gamma" in w else None
+        self._w2 = ops.to_device(w[f"{n2}/kernel"], device)
+        self._b2 = ops.to_device(w[f"{n2}/bias"], device)
+        self.output_channels = self._out_ch
+        self._built_on = device
+        return self
+
+    def _forward(self, x):
+        t = self._up(x)
+        return ops.two_layer_tail(t, self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
+                                  self._w2, self._b2, self._k[1], self._s[1])
+
+
+class TwoLayerSynthesis(_TwoLayerBase):
+    """reference transforms.py:298-317."""
+
+    def __init__(self, channels=(24, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn"):
+        super().__init__(channels, strides, kernel_sizes, activation_type, has_res=False)
+
+
+class TwoLayerResSynthesis(_TwoLayerBase):
+    """reference transforms.py:320-361 (res_type='conv')."""
+
+    def __init__(self, channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn", res_type="conv"):
+        if res_type != "conv":
+            raise NotImplementedError("res_type='d2s' is not used by any reference config")
+        super().__init__(channels, strides, kernel_sizes, activation_type, has_res=True)
+
+
+class ElicAnalysis(Transform):
+    """reference elic.py:103-177."""
+
+    def __init__(self, num_residual_blocks=3, channels=(128, 160, 192, 192), kernel_sizes=(5, 5, 5, 5),
+                 strides=(2, 2, 2, 2), output_channels=None, name="ElicAnalysis"):
+        if len(channels) not in (3, 4):
+            raise ValueError(f"ELIC uses 3 or 4 conv layers (not {channels}).")
+        assert len(channels) == len(strides) == len(kernel_sizes)
+        if output_channels is not None and output_channels != channels[-1]:
+            raise ValueError(f"output_channels specified but does not match channels: {output_channels} vs. {channels}")
+        self._downsample_factor = 2 ** len(channels)
+        convs = [Conv(f"conv{i}", "conv", c, k, s) for i, (c, k, s) in enumerate(zip(channels, kernel_sizes, strides))]
+        count = [0]
+
+        def rbs():
+            out = [ResidualBlock(f"rb{count[0] + j}") for j in range(num_residual_blocks)]
+            count[0] += num_residual_blocks
+            return out
+
+        blocks = [convs[0], *rbs()] if len(channels) == 4 else []
+        blocks += [convs[-3], *rbs(), SimpleAttention("attn0"), convs[-2], *rbs(), convs[-1], SimpleAttention("attn1")]
+        super().__init__(Seq(blocks), 3)
+
+    @property
+    def output_depth(self):
+        return self.out_channels()
+
+
+class ElicSynthesis(Transform):
+    """reference elic.py:180-250 (registered at transforms.py:389 but used by no shipped config)."""
+
+    def __init__(self, num_residual_blocks=3, channels=(192, 160, 128, 3), kernel_sizes=(5, 5, 5, 5),
+                 strides=(2, 2, 2, 2), output_channels=None, name="ElicSynthesis"):
+        if len(channels) not in (3, 4):
+            raise ValueError(f"ELIC uses 3 or 4 conv layers (not {channels}).")
+        assert len(channels) == len(strides) == len(kernel_sizes)
+        if output_channels is not None and output_channels != channels[-1]:
+            raise ValueError(f"output_channels specified but does not match channels: {output_channels} vs. {channels}")
+        convs = [Conv(f"conv{i}", "convT", c, k, s) for i, (c, k, s) in enumerate(zip(channels, kernel_sizes, strides))]
+        count = [0]
+
+        def rbs():
+            out = [ResidualBlock(f"rb{count[0] + j}") for j in range(num_residual_blocks)]
+            count[0] += num_residual_blocks
+            return out
+
+        blocks = [SimpleAttention("attn0"), convs[0], *rbs(), convs[1], SimpleAttention("attn1"), *rbs(), convs[2]]
+        if len(channels) == 4:
+            blocks += [*rbs(), convs[3]]
+        super().__init__(Seq(blocks))
+
+
+classes = [
+    BLS2017Analysis, BLS2017Synthesis, CNNAnalysis, CNNSynthesis, HyperAnalysis, HyperSynthesis,
+    MBT2018Analysis, MBT2018Synthesis, HyperAnalysisSmall, HyperSynthesisSmall, ElicAnalysis, ElicSynthesis,
+    JPEGLikeSynthesis, TwoLayerSynthesis, TwoLayerResSynthesis, JPEGLikeHyperSynthesis,
+]
+# reference transforms.py:383-393
+class_builder = ClassBuilder({cls.__name__: cls for cls in classes})

@@ -1,0 +1,301 @@
+// conv_plan.hip -- host side of the convolution entry points of sntc.h: turns a Keras / TFC layer
+// description into gather-GEMM groups, packs the weights on the device once, and launches.
+//
+// Phase-grouped transposed convolution: for Conv2DTranspose(k, s, SAME) with
+// pt = max(k-s,0)//2, output row oy gathers  oy + pt = qy*s + phi,  ky = phi + jy*s,  i = qy - jy.
+// ceil((k-phi)/s) takes at most two values over phi in [0,s), so the s*s output phases fall into
+// <= 4 groups that share a tap pattern; each group is one GEMM whose columns are
+// (phase, channel) pairs: N = phases*Cout, K = taps*Cin -- no zero stuffing, no col2im.
+#include <algorithm>
+#include <vector>
+#include "sntc_internal.h"
+
+namespace sntc {
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                    const int* __restrict__ taps, const unsigned* __restrict__ cols,
+                                    int T, int Cin, int Cout, int K, int Ncol, int kind, int kw, int s,
+                                    int pt, int pl, int phase_mode) {
+  const size_t total = (size_t)Ncol * K;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / K);
+    const int k = (int)(idx - (size_t)col * K);
+    float v = 0.0f;
+    if (k < T * Cin) {
+      const int t = k / Cin;
+      const int ci = k - t * Cin;
+      const int tap = taps[t];
+      const unsigned ce = cols[col];
+      const int ch = ce & 0xffff;
+      int ky = tap >> 16, kx = tap & 0xffff;
+      if (phase_mode) {
+        ky = ((int)((ce >> 24) & 0xff) - 128 + pt) + ky * s;
+        kx = ((int)((ce >> 16) & 0xff) - 128 + pl) + kx * s;
+      }
+      const size_t tapi = (size_t)ky * kw + kx;
+      v = (kind == SNTC_CONV2D_TRANSPOSE) ? w[(tapi * Cout + ch) * Cin + ci] : w[(tapi * Cin + ci) * Cout + ch];
+    }
+    wp[idx] = v;
+  }
+}
+
+}  // namespace sntc
+
+using namespace sntc;
+
+struct sntc_conv_plan {
+  sntc_conv_desc d;
+  int device = 0;
+  bool up = false;          // transposed family
+  bool phase_mode = false;  // up && stride > 1
+  int pt = 0, pl = 0;       // fixed pads (transposed / SignalConv2D); Keras Conv2D SAME is per call
+  int ngroups = 0;
+  bool vec = false;
+  struct Grp {
+    int T = 0, K = 0, Ncol = 0;
+    float* wp = nullptr;
+    int* taps = nullptr;
+    unsigned* cols = nullptr;
+  } g[kMaxGroups];
+  float* bias = nullptr;
+};
+
+static thread_local int g_tile_override = 0;
+
+extern "C" int sntc_conv_set_tile_override(int variant) {
+  int prev = g_tile_override;
+  g_tile_override = variant;
+  return prev;
+}
+
+extern "C" void sntc_conv_plan_destroy(sntc_conv_plan* p) {
+  if (!p) return;
+  for (int i = 0; i < kMaxGroups; ++i) {
+    if (p->g[i].wp) (void)hipFree(p->g[i].wp);
+    if (p->g[i].taps) (void)hipFree(p->g[i].taps);
+    if (p->g[i].cols) (void)hipFree(p->g[i].cols);
+  }
+  if (p->bias) (void)hipFree(p->bias);
+  delete p;
+}
+
+static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias, hipStream_t stream) {
+  const sntc_conv_desc& d = p->d;
+  const int k = d.kh, s = d.stride;
+  struct HostGrp { std::vector<int> taps; std::vector<unsigned> cols; };
+  std::vector<HostGrp> groups;
+  auto enc = [](int oyo, int oxo, int ch) { return ((unsigned)(oyo + 128) << 24) | ((unsigned)(oxo + 128) << 16) | (unsigned)ch; };
+
+  if (!p->phase_mode) {
+    HostGrp hg;
+    for (int ky = 0; ky < d.kh; ++ky)
+      for (int kx = 0; kx < d.kw; ++kx) hg.taps.push_back((ky << 16) | kx);
+    for (int ch = 0; ch < d.cout; ++ch) hg.cols.push_back(enc(0, 0, ch));
+    groups.push_back(std::move(hg));
+  } else {
+    // classes of phases per axis by tap count
+    auto classes = [&](int kk, std::vector<std::pair<int, std::vector<int>>>& out) {
+      for (int phi = 0; phi < s; ++phi) {
+        const int cnt = (kk - phi + s - 1) / s;
+        if (cnt <= 0) return false;
+        bool found = false;
+        for (auto& c : out)
+          if (c.first == cnt) { c.second.push_back(phi); found = true; }
+        if (!found) out.push_back({cnt, {phi}});
+      }
+      std::sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+      return true;
+    };
+    std::vector<std::pair<int, std::vector<int>>> cy, cx;
+    if (!classes(d.kh, cy) || !classes(d.kw, cx))
+      return fail(SNTC_ERR_UNSUPPORTED, "transposed convolution with kernel < stride is not supported");
+    for (auto& a : cy)
+      for (auto& b : cx) {
+        HostGrp hg;
+        for (int jy = 0; jy < a.first; ++jy)
+          for (int jx = 0; jx < b.first; ++jx) hg.taps.push_back((jy << 16) | jx);
+        for (int py : a.second)
+          for (int px : b.second)
+            for (int ch = 0; ch < d.cout; ++ch) hg.cols.push_back(enc(py - p->pt, px - p->pl, ch));
+        groups.push_back(std::move(hg));
+      }
+    std::stable_sort(groups.begin(), groups.end(),
+                     [](const HostGrp& a, const HostGrp& b) { return a.taps.size() > b.taps.size(); });
+  }
+  if ((int)groups.size() > kMaxGroups) return fail(SNTC_ERR_UNSUPPORTED, "too many phase groups");
+  p->ngroups = (int)groups.size();
+  for (int gi = 0; gi < p->ngroups; ++gi) {
+    auto& hg = groups[gi];
+    auto& G = p->g[gi];
+    G.T = (int)hg.taps.size();
+    G.Ncol = (int)hg.cols.size();
+    G.K = ((G.T * d.cin + 31) / 32) * 32;
+    SNTC_HIP(hipMalloc(&G.taps, sizeof(int) * std::max(1, G.T)));
+    SNTC_HIP(hipMalloc(&G.cols, sizeof(unsigned) * G.Ncol));
+    SNTC_HIP(hipMalloc(&G.wp, sizeof(float) * (size_t)G.Ncol * std::max(32, G.K)));
+    SNTC_HIP(hipMemcpyAsync(G.taps, hg.taps.data(), sizeof(int) * G.T, hipMemcpyHostToDevice, stream));
+    SNTC_HIP(hipMemcpyAsync(G.cols, hg.cols.data(), sizeof(unsigned) * G.Ncol, hipMemcpyHostToDevice, stream));
+    // the host vectors must outlive the async copies
+    SNTC_HIP(hipStreamSynchronize(stream));
+    const size_t total = (size_t)G.Ncol * G.K;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    if (total > 0)
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, weight, G.wp, G.taps, G.cols,
+                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0);
+    SNTC_HIP(hipGetLastError());
+  }
+  if (bias) {
+    SNTC_HIP(hipMalloc(&p->bias, sizeof(float) * d.cout));
+    SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, stream));
+  }
+  (void)k;
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* weight, const float* bias,
+                                     void* stream, sntc_conv_plan** plan) {
+  if (!desc || !weight || !plan) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_create: null argument");
+  const sntc_conv_desc& d = *desc;
+  if (d.kind < SNTC_CONV2D || d.kind > SNTC_SIGNAL_UP) return fail(SNTC_ERR_UNSUPPORTED, "unknown conv kind");
+  if (d.kh < 1 || d.kw < 1 || d.kh > 64 || d.kw > 64 || d.stride < 1 || d.stride > 64 || d.cin < 1 || d.cout < 1 ||
+      d.cout > 65535)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_create: bad kernel / stride / channel sizes");
+  if (d.act < SNTC_ACT_NONE || d.act > SNTC_ACT_SIGMOID || d.prologue < 0 || d.prologue > SNTC_PRO_SQUARE ||
+      d.epilogue < 0 || d.epilogue > SNTC_EPI_RES_MUL_SQRT)
+    return fail(SNTC_ERR_UNSUPPORTED, "unknown activation / prologue / epilogue");
+  int rc = gg_init();
+  if (rc) return rc;
+  auto* p = new sntc_conv_plan();
+  p->d = d;
+  SNTC_HIP(hipGetDevice(&p->device));
+  p->up = (d.kind == SNTC_CONV2D_TRANSPOSE || d.kind == SNTC_SIGNAL_UP);
+  p->phase_mode = p->up && d.stride > 1;
+  if (d.kind == SNTC_CONV2D_TRANSPOSE) {
+    p->pt = std::max(d.kh - d.stride, 0) / 2;
+    p->pl = std::max(d.kw - d.stride, 0) / 2;
+  } else if (d.kind == SNTC_SIGNAL_UP) {
+    p->pt = (d.kh - 1) / 2;
+    p->pl = (d.kw - 1) / 2;
+  } else if (d.kind == SNTC_SIGNAL_DOWN) {
+    p->pt = d.kh / 2;
+    p->pl = d.kw / 2;
+  }
+  p->vec = (d.cin % 32) == 0;
+  rc = build_plan(p, weight, bias, (hipStream_t)stream);
+  if (rc) {
+    sntc_conv_plan_destroy(p);
+    return rc;
+  }
+  *plan = p;
+  return SNTC_OK;
+}
+
+struct Geo {
+  int Ho, Wo, Qh, Qw, sA, tstep, offy, offx, sO;
+};
+
+static int geometry(const sntc_conv_plan* p, int h, int w, Geo* g) {
+  const sntc_conv_desc& d = p->d;
+  const int s = d.stride;
+  if (h < 1 || w < 1) return fail(SNTC_ERR_BAD_SHAPE, "empty image");
+  if (!p->up) {
+    g->Ho = (h + s - 1) / s;
+    g->Wo = (w + s - 1) / s;
+    int pt, pl;
+    if (d.kind == SNTC_CONV2D) {
+      pt = std::max((g->Ho - 1) * s + d.kh - h, 0) / 2;
+      pl = std::max((g->Wo - 1) * s + d.kw - w, 0) / 2;
+    } else {
+      pt = p->pt;
+      pl = p->pl;
+    }
+    *g = Geo{g->Ho, g->Wo, g->Ho, g->Wo, s, 1, -pt, -pl, 1};
+  } else if (!p->phase_mode) {   // stride-1 transpose == correlation with the flipped kernel
+    *g = Geo{h, w, h, w, 1, -1, p->pt, p->pl, 1};
+  } else {
+    const int ho = h * s, wo = w * s;
+    *g = Geo{ho, wo, (ho - 1 + p->pt) / s + 1, (wo - 1 + p->pl) / s + 1, 1, -1, 0, 0, s};
+  }
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_out_shape(const sntc_conv_plan* p, int h, int w, int* ho, int* wo) {
+  if (!p || !ho || !wo) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_out_shape: null argument");
+  Geo g;
+  int rc = geometry(p, h, w, &g);
+  if (rc) return rc;
+  *ho = g.Ho;
+  *wo = g.Wo;
+  return SNTC_OK;
+}
+
+extern "C" int64_t sntc_conv_flops(const sntc_conv_plan* p, int n, int h, int w) {
+  if (!p) return 0;
+  Geo g;
+  if (geometry(p, h, w, &g)) return 0;
+  const sntc_conv_desc& d = p->d;
+  const int64_t px = p->up ? (int64_t)h * w : (int64_t)g.Ho * g.Wo;
+  return 2 * (int64_t)n * px * d.kh * d.kw * d.cin * d.cout;
+}
+
+static int pick_variant(const sntc_conv_plan* p, int64_t M) {
+  if (g_tile_override >= 1 && g_tile_override <= kNumVariants) return g_tile_override;
+  double best = 1e300;
+  int bestv = 4;
+  for (int v = 1; v <= kNumVariants; ++v) {
+    const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
+    const int64_t ntm = (M + bm - 1) / bm;
+    double work = 0;   // padded multiply-adds
+    int64_t nb = 0;
+    for (int gi = 0; gi < p->ngroups; ++gi) {
+      const int64_t ntn = (p->g[gi].Ncol + bn - 1) / bn;
+      work += (double)p->g[gi].K * (double)(ntn * bn) * (double)(ntm * bm);
+      nb += ntn * ntm;
+    }
+    const double waves = (double)nb / 256.0;   // 256 CUs
+    const double tail = waves < 1.0 ? 1.0 / waves : std::ceil(waves) / waves;
+    double cost = work * tail;
+    if (v == 8) cost *= 1.15;   // 64x64: half the MFMAs per staged byte
+    if (v == 1) cost *= 1.10;
+    if (v == 7) cost *= 1.08;   // 92 KB of LDS: one block per CU
+    if (cost < best) { best = cost; bestv = v; }
+  }
+  return bestv;
+}
+
+extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n, int h, int w, float* y,
+                                 const float* res, const float* aux, void* stream) {
+  if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: null argument");
+  if (n < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: empty batch");
+  const sntc_conv_desc& d = p->d;
+  if (d.epilogue != SNTC_EPI_STORE && !res) return fail(SNTC_ERR_BAD_SHAPE, "epilogue needs `res`");
+  if (d.epilogue == SNTC_EPI_GATE && !aux) return fail(SNTC_ERR_BAD_SHAPE, "gate epilogue needs `aux`");
+  Geo g;
+  int rc = geometry(p, h, w, &g);
+  if (rc) return rc;
+  const int64_t M = (int64_t)n * g.Qh * g.Qw;
+  if (M > 0x7fffffffLL || (int64_t)n * h * w * d.cin > (1LL << 40))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: tensor too large");
+  const int v = pick_variant(p, M);
+  const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
+  GGArgs a{};
+  a.x = x; a.y = y; a.bias = p->bias; a.res = res; a.aux = aux;
+  a.N = n; a.H = h; a.W = w; a.Cin = d.cin;
+  a.Qh = g.Qh; a.Qw = g.Qw; a.M = (int)M;
+  a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = d.cout;
+  a.sA = g.sA; a.tstep = g.tstep; a.offy = g.offy; a.offx = g.offx; a.sO = g.sO;
+  a.act = d.act; a.epi = d.epilogue; a.pro = d.prologue;
+  a.ntm = (int)((M + bm - 1) / bm);
+  a.ngroups = p->ngroups;
+  int nb = 0;
+  for (int gi = 0; gi < p->ngroups; ++gi) {
+    GGGroup& G = a.g[gi];
+    G.wp = p->g[gi].wp; G.taps = p->g[gi].taps; G.cols = reinterpret_cast<const int*>(p->g[gi].cols);
+    G.T = p->g[gi].T; G.K = p->g[gi].K; G.Ncol = p->g[gi].Ncol;
+    G.ntn = (G.Ncol + bn - 1) / bn;
+    G.blk0 = nb;
+    nb += G.ntn * a.ntm;
+  }
+  return gg_launch(v, p->vec, a, nb, (hipStream_t)stream);
+}

@@ -1,0 +1,290 @@
+// entropy.hip -- rate estimates of the two entropy models (compression=False paths).
+//
+// Both kernels are pure HBM streams: read each latent once, write the rounded value once, and
+// reduce -log2 p per image.  One thread handles 4 consecutive channels (16-B loads); per-thread
+// partial sums are kept in double, reduced across the wave with shuffles, across the block through
+// LDS, then one double atomic per block and image (DESIGN.md "entropy scans").
+//
+// Numerics follow tfc's UniformNoiseAdapter:
+//   log p(v) = big + log1p(-exp(small - big)),  (big, small) = (log cdf(v+.5), log cdf(v-.5)) left of
+//   the median and (log sf(v-.5), log sf(v+.5)) right of it.  For the zero-mean normal and for the
+//   logistic-sigmoid cumulative "right of the median" is simply upper > 0, and sf(x) = cdf(-x).
+#include <cmath>
+#include <vector>
+#include "sntc_internal.h"
+
+namespace sntc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLogScaleMin = -2.2072749131897207f;    // ln 0.11        (mshyper/models.py:29)
+constexpr float kScaleFactor = 0.12305479932808384f;    // (ln 256 - ln 0.11)/63   (:31)
+constexpr float kInvLn2 = 1.4426950408889634f;
+
+// log Phi(x), float32: direct for x > -10, asymptotic series below (as TFP's float32 log_ndtr).
+__device__ __forceinline__ float log_ndtr_f(float x) {
+  const float t = x * 0.70710678118654752f;
+  if (x > 0.0f) return log1pf(-0.5f * erfcf(t));
+  if (x > -10.0f) return logf(0.5f * erfcf(-t));
+  const float x2 = x * x;
+  const float ix2 = 1.0f / x2;
+  const float series = 1.0f - ix2 * (1.0f - 3.0f * ix2 * (1.0f - 5.0f * ix2));
+  return -0.5f * x2 - logf(-x) - 0.91893853320467274f + logf(series);
+}
+
+__device__ __forceinline__ float log_diff_exp(float big, float small) {
+  return big + log1pf(-expf(small - big));
+}
+
+// -log2 P(v) for N(0, sigma) convolved with U(-.5, .5)
+__device__ __forceinline__ float normal_bits(float v, float sigma) {
+  const float hi = (v + 0.5f) / sigma;
+  const float lo = (v - 0.5f) / sigma;
+  const bool right = hi > 0.0f;
+  const float a = right ? -lo : hi;
+  const float b = right ? -hi : lo;
+  return -log_diff_exp(log_ndtr_f(a), log_ndtr_f(b)) * kInvLn2;
+}
+
+__device__ __forceinline__ double block_sum_to(double v, double* dst) {
+  __shared__ double part[8];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
+    atomicAdd(dst, s);
+  }
+  __syncthreads();
+  return v;
+}
+
+// grid (blocks_per_image, n).  4 channels per thread; c % 4 == 0.
+__global__ void __launch_bounds__(256) scale_normal_kernel(const float* __restrict__ y, const float* __restrict__ hyper,
+                                                           int64_t hw, int c, float* __restrict__ y_hat,
+                                                           int32_t* __restrict__ symbols, double* __restrict__ bits,
+                                                           int values_only) {
+  const int img = blockIdx.y;
+  const int64_t per = hw * c;
+  const int c4 = c >> 2;
+  const int64_t nvec = hw * c4;
+  const float* yb = y + img * per;
+  const float* hb = hyper + img * per * 2;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c4;
+    const int ch = (int)(i - p * c4) << 2;
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(yb + p * c + ch);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(hb + p * 2 * c + ch);
+    const f32x4 raw = *reinterpret_cast<const f32x4*>(hb + p * 2 * c + c + ch);
+    f32x4 out;
+    i32x4 sym;
+    float b = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // indexes = exp(raw) (mshyper/models.py:274-276), clamp to [0, 63], sigma = SCALE_FN(idx)
+      const float idx = fminf(fmaxf(expf(raw[e]), 0.0f), 63.0f);
+      const float sigma = expf(kLogScaleMin + kScaleFactor * idx);
+      const float d = yv[e] - mu[e];
+      const float v = values_only ? d : rintf(d);
+      out[e] = v + mu[e];
+      sym[e] = (int)v;
+      b += normal_bits(v, sigma);
+    }
+    acc += (double)b;
+    if (!values_only) {
+      *reinterpret_cast<f32x4*>(y_hat + img * per + p * c + ch) = out;
+      if (symbols) *reinterpret_cast<i32x4*>(symbols + img * per + p * c + ch) = sym;
+    }
+  }
+  block_sum_to(acc, bits + img);
+}
+
+__global__ void __launch_bounds__(256) dequant_kernel(const int32_t* __restrict__ symbols, const float* __restrict__ hyper,
+                                                      int64_t npix, int c, float* __restrict__ y_hat) {
+  const int c4 = c >> 2;
+  const int64_t nvec = npix * c4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c4;
+    const int ch = (int)(i - p * c4) << 2;
+    const i32x4 s = *reinterpret_cast<const i32x4*>(symbols + p * c + ch);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(hyper + p * 2 * c + ch);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)s[e] + mu[e];
+    *reinterpret_cast<f32x4*>(y_hat + p * c + ch) = o;
+  }
+}
+
+// ----------------------------- deep factorized -----------------------------
+constexpr int kMaxW = 4;   // max hidden width
+constexpr int kMaxL = 5;   // max affine layers
+
+struct DFDesc {
+  int nl;
+  int w[kMaxL + 1];
+  int off_m[kMaxL], off_b[kMaxL], off_f[kMaxL];
+  int stride;   // floats per channel record
+};
+
+// record holds softplus(matrix), bias, tanh(factor) for one channel
+__device__ __forceinline__ float df_logits(const float* __restrict__ rec, const DFDesc& d, float x) {
+  float hcur[kMaxW] = {x, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kMaxL; ++k) {
+    if (k < d.nl) {
+      const int fi = d.w[k], fo = d.w[k + 1];
+      float hn[kMaxW] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) {
+        if (o < fo) {
+          float s = rec[d.off_b[k] + o];
+#pragma unroll
+          for (int i = 0; i < kMaxW; ++i)
+            if (i < fi) s += rec[d.off_m[k] + o * fi + i] * hcur[i];
+          if (k < d.nl - 1) s += rec[d.off_f[k] + o] * tanhf(s);
+          hn[o] = s;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) hcur[o] = hn[o];
+    }
+  }
+  return hcur[0];
+}
+
+__device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+
+__global__ void __launch_bounds__(256) factorized_kernel(const float* __restrict__ rec_all, DFDesc d, const float* __restrict__ z,
+                                                         int64_t hw, int c, float* __restrict__ z_hat,
+                                                         double* __restrict__ bits, int values_only) {
+  const int img = blockIdx.y;
+  const int64_t per = hw * c;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const float zin = z[img * per + i];
+    const float v = values_only ? zin : rintf(zin);
+    const float* rec = rec_all + (size_t)ch * d.stride;
+    const float hi = df_logits(rec, d, v + 0.5f);
+    const float lo = df_logits(rec, d, v - 0.5f);
+    const bool right = hi > 0.0f;
+    const float big = log_sigmoid_f(right ? -lo : hi);
+    const float small = log_sigmoid_f(right ? -hi : lo);
+    acc += (double)(-log_diff_exp(big, small) * kInvLn2);
+    if (!values_only) z_hat[img * per + i] = v;
+  }
+  block_sum_to(acc, bits + img);
+}
+
+}  // namespace sntc
+
+using namespace sntc;
+
+struct sntc_prior {
+  int channels = 0;
+  DFDesc d{};
+  float* rec = nullptr;
+};
+
+extern "C" void sntc_prior_destroy(sntc_prior* p) {
+  if (!p) return;
+  if (p->rec) (void)hipFree(p->rec);
+  delete p;
+}
+
+extern "C" int sntc_prior_create(int channels, int nlayers, const int* widths, const float* matrices,
+                                 const float* biases, const float* factors, void* stream, sntc_prior** prior) {
+  if (!widths || !matrices || !biases || !prior || channels < 1)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_prior_create: null argument");
+  if (nlayers < 1 || nlayers > kMaxL) return fail(SNTC_ERR_UNSUPPORTED, "deep factorized: 1..5 affine layers supported");
+  if (widths[0] != 1 || widths[nlayers] != 1) return fail(SNTC_ERR_BAD_SHAPE, "deep factorized: widths must start and end with 1");
+  for (int k = 0; k <= nlayers; ++k)
+    if (widths[k] < 1 || widths[k] > kMaxW) return fail(SNTC_ERR_UNSUPPORTED, "deep factorized: widths up to 4 supported");
+  if (nlayers > 1 && !factors) return fail(SNTC_ERR_BAD_SHAPE, "sntc_prior_create: factors missing");
+  auto* p = new sntc_prior();
+  p->channels = channels;
+  DFDesc& d = p->d;
+  d.nl = nlayers;
+  for (int k = 0; k <= nlayers; ++k) d.w[k] = widths[k];
+  int off = 0;
+  for (int k = 0; k < nlayers; ++k) {
+    d.off_m[k] = off; off += widths[k + 1] * widths[k];
+    d.off_b[k] = off; off += widths[k + 1];
+    d.off_f[k] = off; off += widths[k + 1];
+  }
+  d.stride = off;
+  std::vector<float> rec((size_t)channels * off, 0.0f);
+  size_t pm = 0, pb = 0, pf = 0;
+  for (int k = 0; k < nlayers; ++k) {
+    const int fi = widths[k], fo = widths[k + 1];
+    for (int ch = 0; ch < channels; ++ch) {
+      float* r = rec.data() + (size_t)ch * off;
+      for (int e = 0; e < fo * fi; ++e) {
+        const double m = matrices[pm + (size_t)ch * fo * fi + e];
+        r[d.off_m[k] + e] = (float)(m > 30 ? m : std::log1p(std::exp(m)));   // softplus
+      }
+      for (int e = 0; e < fo; ++e) r[d.off_b[k] + e] = biases[pb + (size_t)ch * fo + e];
+      if (k < nlayers - 1)
+        for (int e = 0; e < fo; ++e) r[d.off_f[k] + e] = (float)std::tanh((double)factors[pf + (size_t)ch * fo + e]);
+    }
+    pm += (size_t)channels * fo * fi;
+    pb += (size_t)channels * fo;
+    if (k < nlayers - 1) pf += (size_t)channels * fo;
+  }
+  hipError_t e = hipMalloc(&p->rec, rec.size() * sizeof(float));
+  if (e != hipSuccess) { delete p; return hip_fail(e, "hipMalloc(prior)"); }
+  e = hipMemcpy(p->rec, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { sntc_prior_destroy(p); return hip_fail(e, "hipMemcpy(prior)"); }
+  (void)stream;
+  *prior = p;
+  return SNTC_OK;
+}
+
+static int grid_for(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+extern "C" int sntc_entropy_factorized(const sntc_prior* prior, const float* z, int n, int64_t hw, float* z_hat,
+                                       double* bits, int values_only, void* stream) {
+  if (!prior || !z || !bits || (!values_only && !z_hat)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_factorized: null argument");
+  if (n < 1 || hw < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_factorized: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  const int64_t per = hw * prior->channels;
+  hipLaunchKernelGGL(factorized_kernel, dim3(grid_for(per), n), dim3(256), 0, s, prior->rec, prior->d, z, hw,
+                     prior->channels, z_hat, bits, values_only);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_entropy_scale_normal(const float* y, const float* hyper, int n, int64_t hw, int c, float* y_hat,
+                                         int32_t* symbols, double* bits, int values_only, void* stream) {
+  if (!y || !hyper || !bits || (!values_only && !y_hat)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_scale_normal: null argument");
+  if (n < 1 || hw < 1 || c < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_scale_normal: empty input");
+  if (c % 4) return fail(SNTC_ERR_UNSUPPORTED, "sntc_entropy_scale_normal: channels must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  hipLaunchKernelGGL(scale_normal_kernel, dim3(grid_for(hw * c / 4), n), dim3(256), 0, s, y, hyper, hw, c, y_hat,
+                     symbols, bits, values_only);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n, int64_t hw, int c,
+                                         float* y_hat, void* stream) {
+  if (!symbols || !hyper || !y_hat) return fail(SNTC_ERR_BAD_SHAPE, "sntc_dequant_scale_normal: null argument");
+  if (n < 1 || hw < 1 || c < 1 || (c % 4)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_dequant_scale_normal: bad sizes");
+  const int64_t npix = (int64_t)n * hw;
+  hipLaunchKernelGGL(dequant_kernel, dim3(grid_for(npix * c / 4)), dim3(256), 0, (hipStream_t)stream, symbols, hyper,
+                     npix, c, y_hat);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}

@@ -1,0 +1,316 @@
+// gather_gemm.hip -- the one contraction kernel of the codec: an im2col-free, NHWC gather GEMM on
+// the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 64 FLOP/clk/SIMD).
+//
+// Every Conv2D / Conv2DTranspose / SignalConv2D / GDN norm-pool on the hot path is
+//     out[m, col] = sum_t sum_c x[src(m, t), c] * Wp[col][t*Cin + c]          (sntc_internal.h)
+// with pixels on the MFMA row (A) side and output columns on the column (B) side.
+//
+// Block: 256 threads = 4 waves arranged WM x WN; each wave owns TM x TN tiles of 32x32; BK = 32.
+//   global -> registers (16 B per lane, each tile row is one full 128-B line of the NHWC input /
+//   K-contiguous packed weight) -> LDS (128-B rows, 16-B chunks XOR-swizzled by (row>>1)&7 so the
+//   ds_read_b128 fragment reads are bank-conflict free) -> MFMA.  Two LDS buffers, one barrier
+//   per K step; the next step's global loads are issued before the MFMAs of the current one.
+//   Per lane a ds_read_b128 fetches k = 8g+4h..8g+4h+3 (h = lane>>5): MFMA j of k-group g sums
+//   k in {8g+j, 8g+4+j}; A and B use the same permutation, so the products pair up.
+//   C/D layout: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+#include "sntc_internal.h"
+
+namespace sntc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case SNTC_ACT_RELU: return fmaxf(v, 0.0f);
+    case SNTC_ACT_LEAKY_RELU: return v >= 0.0f ? v : 0.2f * v;
+    case SNTC_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+template <int TM, int TN, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_CH = BM / 32;   // 16-B chunks per thread per K step (A)
+  constexpr int B_CH = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);          // [2][BM][32]
+  float* Bs = As + 2 * BM * 32;                        // [2][BN][32]
+  int4* rinfo = reinterpret_cast<int4*>(Bs + 2 * BN * 32);   // [BM] (n, qy, qx, valid)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroups; ++i)
+    if (i < a.ngroups && (int)blockIdx.x >= a.g[i].blk0) gi = i;
+  const GGGroup G = a.g[gi];
+  const int lb = blockIdx.x - G.blk0;
+  const int mt = lb % a.ntm;
+  const int nt = lb / a.ntm;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int4 ri = make_int4(0, 0, 0, 0);
+    if (m < a.M) {
+      const int per = a.Qh * a.Qw;
+      const int n = m / per;
+      const int rem = m - n * per;
+      const int qy = rem / a.Qw;
+      ri = make_int4(n, qy, rem - qy * a.Qw, 1);
+    }
+    rinfo[r] = ri;
+  }
+  __syncthreads();
+
+  // ---------------- loader state ----------------
+  const int c = tid & 7;     // 16-B chunk inside the 128-B K slab
+  const int r0 = tid >> 3;   // row 0..31 (+32 i)
+  int a_iy0[A_CH], a_ix0[A_CH];
+  const float* a_base[A_CH];
+  bool a_ok[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int4 ri = rinfo[r0 + 32 * i];
+    a_ok[i] = ri.w != 0;
+    a_iy0[i] = ri.y * a.sA + a.offy;
+    a_ix0[i] = ri.z * a.sA + a.offx;
+    a_base[i] = a.x + (size_t)ri.x * a.H * a.W * a.Cin;
+  }
+  const float* b_ptr[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {   // rows past Ncol re-read the last column (finite, discarded)
+    const int brow = min(n0 + r0 + 32 * i, G.Ncol - 1);
+    b_ptr[i] = G.wp + (size_t)brow * G.K + c * 4;
+  }
+
+  const int nsteps = G.K >> 5;
+  const int ncc = VEC ? (a.Cin >> 5) : 1;
+  const int ktrue = G.T * a.Cin;
+  int ld_t = 0, ld_cc = 0, ld_step = 0;
+  const float* a_ptr[A_CH];
+
+  auto set_tap = [&](int t) {
+    const int tap = G.taps[t];
+    const int ty = tap >> 16, tx = tap & 0xffff;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int iy = a_iy0[i] + ty * a.tstep;
+      const int ix = a_ix0[i] + tx * a.tstep;
+      const bool ok = a_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      a_ptr[i] = ok ? a_base[i] + ((size_t)iy * a.W + ix) * a.Cin + c * 4 : nullptr;
+    }
+  };
+  if (VEC && G.T > 0) set_tap(0);
+
+  f32x4 ra[A_CH], rb[B_CH];
+  auto load_regs = [&]() {
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a_ptr[i]) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ld_cc * 32);
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = ld_step * 32 + c * 4 + e;
+          if (k < ktrue && a_ok[i]) {
+            const int t = k / a.Cin;
+            const int ch = k - t * a.Cin;
+            const int tap = G.taps[t];
+            const int iy = a_iy0[i] + (tap >> 16) * a.tstep;
+            const int ix = a_ix0[i] + (tap & 0xffff) * a.tstep;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+              v[e] = a_base[i][((size_t)iy * a.W + ix) * a.Cin + ch];
+          }
+        }
+        ra[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + ld_step * 32);
+    ++ld_step;
+    if (VEC) {
+      if (++ld_cc == ncc) {
+        ld_cc = 0;
+        if (++ld_t < G.T) set_tap(ld_t);
+      }
+    }
+  };
+  auto write_lds = [&](int buf) {
+    float* Ab = As + buf * BM * 32;
+    float* Bb = Bs + buf * BN * 32;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int r = r0 + 32 * i;
+      f32x4 v = ra[i];
+      if (a.pro == SNTC_PRO_ABS) {
+        v[0] = fabsf(v[0]); v[1] = fabsf(v[1]); v[2] = fabsf(v[2]); v[3] = fabsf(v[3]);
+      } else if (a.pro == SNTC_PRO_SQUARE) {
+        v = v * v;
+      }
+      *reinterpret_cast<f32x4*>(Ab + r * 32 + ((c ^ ((r >> 1) & 7)) << 2)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int r = r0 + 32 * i;
+      *reinterpret_cast<f32x4*>(Bb + r * 32 + ((c ^ ((r >> 1) & 7)) << 2)) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+
+  if (nsteps > 0) {
+    load_regs();
+    write_lds(0);
+  }
+  __syncthreads();
+
+  for (int ks = 0; ks < nsteps; ++ks) {
+    const bool more = ks + 1 < nsteps;
+    if (more) load_regs();
+    const float* Ab = As + (ks & 1) * BM * 32 + (wm * TM * 32 + l31) * 32;
+    const float* Bb = Bs + (ks & 1) * BN * 32 + (wn * TN * 32 + l31) * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int off = ((2 * g + h) ^ swz) << 2;
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * 32 + off);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * 32 + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) write_lds((ks + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + l31;
+    if (col >= G.Ncol) continue;
+    const unsigned ce = G.cols[col];
+    const int ch = ce & 0xffff;
+    const int oyo = (int)((ce >> 24) & 0xff) - 128;
+    const int oxo = (int)((ce >> 16) & 0xff) - 128;
+    const float bv = a.bias ? a.bias[ch] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int4 ri = rinfo[row];
+        if (!ri.w) continue;
+        const int oy = ri.y * a.sO + oyo;
+        const int ox = ri.z * a.sO + oxo;
+        if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
+        const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
+        float v = apply_act(acc[i][j][r] + bv, a.act);
+        switch (a.epi) {
+          case SNTC_EPI_ADD: v = v + a.res[idx]; break;
+          case SNTC_EPI_GATE: v = a.res[idx] + a.aux[idx] * v; break;
+          case SNTC_EPI_RES_DIV: v = a.res[idx] / v; break;
+          case SNTC_EPI_RES_MUL: v = a.res[idx] * v; break;
+          case SNTC_EPI_RES_DIV_SQRT: v = a.res[idx] / sqrtf(v); break;
+          case SNTC_EPI_RES_MUL_SQRT: v = a.res[idx] * sqrtf(v); break;
+          default: break;
+        }
+        a.y[idx] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// variants + launch
+// ---------------------------------------------------------------------------------------------
+int gg_variant_bm(int v) { return v == 8 ? 64 : 128; }
+int gg_variant_bn(int v) { return v == 8 ? 64 : 32 * v; }
+
+static size_t lds_bytes(int v) {
+  return (size_t)2 * (gg_variant_bm(v) + gg_variant_bn(v)) * 32 * sizeof(float) + gg_variant_bm(v) * sizeof(int4);
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_t(bool vec, const GGArgs& args, int nblocks, size_t lds, hipStream_t stream) {
+  if (vec)
+    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, true>), dim3(nblocks), dim3(256), lds, stream, args);
+  else
+    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, false>), dim3(nblocks), dim3(256), lds, stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
+  return SNTC_OK;
+}
+
+template <int TM, int TN, int WM, int WN>
+static hipError_t set_attr(size_t lds) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+int gg_init() {
+  static thread_local int done_device = -1;
+  int dev = 0;
+  SNTC_HIP(hipGetDevice(&dev));
+  if (done_device == dev) return SNTC_OK;
+  SNTC_HIP((set_attr<1, 1, 4, 1>(lds_bytes(1))));
+  SNTC_HIP((set_attr<1, 2, 4, 1>(lds_bytes(2))));
+  SNTC_HIP((set_attr<1, 3, 4, 1>(lds_bytes(3))));
+  SNTC_HIP((set_attr<1, 4, 4, 1>(lds_bytes(4))));
+  SNTC_HIP((set_attr<1, 5, 4, 1>(lds_bytes(5))));
+  SNTC_HIP((set_attr<1, 6, 4, 1>(lds_bytes(6))));
+  SNTC_HIP((set_attr<1, 7, 4, 1>(lds_bytes(7))));
+  SNTC_HIP((set_attr<1, 1, 2, 2>(lds_bytes(8))));
+  done_device = dev;
+  return SNTC_OK;
+}
+
+int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {
+  const size_t lds = lds_bytes(variant);
+  switch (variant) {
+    case 1: return launch_t<1, 1, 4, 1>(vec, args, nblocks, lds, stream);
+    case 2: return launch_t<1, 2, 4, 1>(vec, args, nblocks, lds, stream);
+    case 3: return launch_t<1, 3, 4, 1>(vec, args, nblocks, lds, stream);
+    case 4: return launch_t<1, 4, 4, 1>(vec, args, nblocks, lds, stream);
+    case 5: return launch_t<1, 5, 4, 1>(vec, args, nblocks, lds, stream);
+    case 6: return launch_t<1, 6, 4, 1>(vec, args, nblocks, lds, stream);
+    case 7: return launch_t<1, 7, 4, 1>(vec, args, nblocks, lds, stream);
+    case 8: return launch_t<1, 1, 2, 2>(vec, args, nblocks, lds, stream);
+    default: return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
+  }
+}
+
+}  // namespace sntc

@@ -1,0 +1,64 @@
+// Internal declarations shared by the HIP translation units of libsntc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/sntc.h"
+
+namespace sntc {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define SNTC_HIP(expr)                                         \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) return ::sntc::hip_fail(_e, #expr);  \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Gather-GEMM: out[m, col] = sum_{t < T} sum_{c < Cin} x[src(m, t), c] * Wp[col][t*Cin + c]
+//   m    = (n, qy, qx) on the macro-pixel grid [Qh, Qw]
+//   src  = (n, qy*sA + offy + ty*tstep, qx*sA + offx + tx*tstep), zero outside the image
+//   col  -> (oy, ox, ch) = (qy*sO + oyoff[col], qx*sO + oxoff[col], ch[col]); skipped outside
+// A forward conv is one group with T = kh*kw; a stride-s transposed conv is up to four groups of
+// output phases that share a tap pattern (DESIGN.md "phase-grouped transposed convolution").
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxGroups = 4;
+
+struct GGGroup {
+  const float* wp;    // [NcolPad][K], K contiguous (K padded to a multiple of 32 with zeros)
+  const int* taps;    // [T]   (ty << 16) | tx
+  const int* cols;    // [NcolPad] ((oyoff+128) << 24) | ((oxoff+128) << 16) | ch ; -1 = padding
+  int T;              // taps
+  int K;              // padded K
+  int Ncol;           // real columns
+  int ntn;            // N tiles for the launched variant
+  int blk0;           // first block of this group
+};
+
+struct GGArgs {
+  const float* x;
+  float* y;
+  const float* bias;   // [Cout] or nullptr
+  const float* res;    // epilogue operand (output shape) or nullptr
+  const float* aux;    // second epilogue operand or nullptr
+  int N, H, W, Cin;
+  int Qh, Qw, M;
+  int Ho, Wo, Cout;
+  int sA, tstep, offy, offx, sO;
+  int act, epi, pro;
+  int ntm;
+  int ngroups;
+  GGGroup g[kMaxGroups];
+};
+
+// variant ids (BM x BN):  1..7 -> 128 x 32*v ;  8 -> 64 x 64
+constexpr int kNumVariants = 8;
+int gg_variant_bm(int v);
+int gg_variant_bn(int v);
+int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream);
+int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent)
+
+}  // namespace sntc

@@ -1,0 +1,331 @@
+"""Mean-scale hyperprior model: the reference's ``Model`` API on the MI355X kernels.
+
+Mirrors reference mshyper/models.py: constructor arguments (:46-51), ``infer_latent_rvs`` (:212-232),
+``frame_loss_given_latent_rvs`` (:234-359), ``end_to_end_frame_loss`` (:361-373), ``validation_step``
+(:385-387), ``evaluate`` (:415-433), ``downsample_factor`` (:137-140) and the ``Metrics.scalars`` keys
+(:342-354: rd_loss, bpp, mse, psnr, scheduled_lr, sched_rd_lambda).  MS-SSIM / LPIPS (:321-340) and the
+training step (:375-383) are out of scope.
+
+Additionally exposes the codec regions SURVEY.md 8(d) measures: ``encode`` (x -> z_hat, symbols, bits)
+and ``decode`` ((z_hat, symbols) -> uint8 pixels).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import _capi as capi
+from .. import ops
+from ..common import image_utils
+from ..common.latent_rvs_lib import LatentRVCollection, UQLatentRV
+from ..common.latent_rvs_utils import sga_schedule_at_step
+from ..common.train_lib import Metrics
+from ..common.transforms import class_builder as transform_builder
+
+EMPTY_DICT = {}
+
+# Fixed configs for the ScaleIndexedEntropyModel (reference :28-34); applied inside
+# csrc/entropy.hip (kLogScaleMin, kScaleFactor).
+NUM_SCALES = 64
+SCALE_MIN = 0.11
+SCALE_MAX = 256.0
+SCALE_FACTOR = (math.log(SCALE_MAX) - math.log(SCALE_MIN)) / (NUM_SCALES - 1.0)
+CODING_RANK = 3
+DUMMY_IMG_DIM = 64
+HIGHER_LAMBDA_UNTIL = 0.2
+HIGHER_LAMBDA_FACTOR = 10.0
+
+
+def deep_factorized_shapes(channels, num_filters=(3, 3)):
+    filters = (1,) + tuple(num_filters) + (1,)
+    d = OrderedDict()
+    for k in range(len(filters) - 1):
+        d[f"prior/matrix_{k}"] = (channels, filters[k + 1], filters[k])
+        d[f"prior/bias_{k}"] = (channels, filters[k + 1])
+        if k < len(filters) - 2:
+            d[f"prior/factor_{k}"] = (channels, filters[k + 1])
+    return d
+
+
+def deep_factorized_init(channels, num_filters=(3, 3), init_scale=10.0, seed=4321):
+    """tfc.DeepFactorized initial values: matrix = log(expm1(1/scale/f_{k+1})), bias ~ U(-.5,.5), factor = 0."""
+    rng = np.random.default_rng(seed)
+    filters = (1,) + tuple(num_filters) + (1,)
+    scale = init_scale ** (1.0 / (len(num_filters) + 1))
+    out = OrderedDict()
+    for name, shp in deep_factorized_shapes(channels, num_filters).items():
+        kind, k = name.split("/")[1].rsplit("_", 1)
+        if kind == "matrix":
+            v = np.full(shp, np.log(np.expm1(1.0 / scale / filters[int(k) + 1])))
+        elif kind == "bias":
+            v = rng.uniform(-0.5, 0.5, size=shp)
+        else:
+            v = np.zeros(shp)
+        out[name] = v.astype(np.float32)
+    return out
+
+
+class Model:
+    """Encapsulates the transforms + entropy models (reference :45-149)."""
+
+    factorized = False
+
+    def __init__(self, scheduled_num_steps=1500000, rd_lambda=0.01, offset_heuristic=True,
+                 transform_config=EMPTY_DICT, optimizer_config=EMPTY_DICT,
+                 latent_config=None, profile=False, device=None, prior_num_filters=(3, 3), seed=4321):
+        capi.require_gpu()
+        self._scheduled_num_steps = scheduled_num_steps
+        self._rd_lambda = rd_lambda
+        self._latent_config = dict(latent_config) if latent_config is not None else dict(uq=dict(method="unoise"))
+        uq_method = self._latent_config["uq"].get("method", "unoise")
+        if uq_method == "mixedq" and offset_heuristic:
+            offset_heuristic = False      # reference :70-76
+        self._offset_heuristic = offset_heuristic
+        self.itinf = False
+        self._optimizer_config = dict(optimizer_config)
+        self._transform_config = transform_config
+        self._profile = profile
+        self._prior_num_filters = tuple(prior_num_filters)
+        self._seed = seed
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._step = 0
+        self._prior = None
+        self._init_transforms(transform_config)
+
+    # -- construction (reference :111-149) ---------------------------------------------------------
+    def _build_named(self, cfg, cin, seed_offset):
+        cfg = dict(cfg)
+        t = transform_builder.build(cfg.pop("cls"), **cfg)
+        t._seed = self._seed + seed_offset
+        t._cin = t._cin or cin
+        return t
+
+    def _init_transforms(self, transform_config=EMPTY_DICT):
+        self._analysis = self._build_named(transform_config["analysis"], 3, 0)
+        self._bottleneck_size = b = self._analysis.out_channels(3)
+        self._synthesis = self._build_named(transform_config["synthesis"], b, 1)
+        ha = transform_config.get("hyper_analysis", dict(cls="HyperAnalysis", bottleneck_size=b))
+        hs = transform_config.get("hyper_synthesis", dict(cls="HyperSynthesis", bottleneck_size=b))
+        self._hyper_analysis = self._build_named(ha, b, 2)
+        self._hyper_bottleneck_size = hb = self._hyper_analysis.out_channels(b)
+        self._hyper_synthesis = self._build_named(hs, hb, 3)
+        if self._hyper_synthesis.out_channels(hb) != 2 * b:
+            raise ValueError("hyper-synthesis must emit 2 * bottleneck channels (mean and scale)")
+        self._prior_weights = deep_factorized_init(hb, self._prior_num_filters, seed=self._seed + 4)
+        # downsample_factor = 64 / spatial size of the hyper-latents of a 64 x 64 dummy image (:137-140)
+        self.downsample_factor = self._compute_downsample_factor()
+
+    def _transforms(self):
+        return OrderedDict(analysis=self._analysis, synthesis=self._synthesis,
+                           hyper_analysis=self._hyper_analysis, hyper_synthesis=self._hyper_synthesis)
+
+    def _compute_downsample_factor(self):
+        for t in self._transforms().values():
+            t.build(device=self.device)
+        with torch.cuda.device(self.device):
+            dummy = torch.zeros((1, DUMMY_IMG_DIM, DUMMY_IMG_DIM, 3), dtype=torch.float32, device=self.device)
+            z = self._hyper_analysis(self._analysis(dummy))
+        dim = z.shape[-2]
+        factor = int(DUMMY_IMG_DIM / dim)
+        assert dim * factor == DUMMY_IMG_DIM, "Downsample factor should divide evenly into the dummy image size."
+        return factor
+
+    # -- weights --------------------------------------------------------------------------------
+    def get_weights(self):
+        """Flat ``{prefix/name: ndarray}`` over all transforms + the hyper-prior ('prior/...')."""
+        out = OrderedDict()
+        for pre, t in self._transforms().items():
+            for k, v in t.get_weights().items():
+                out[f"{pre}/{k}"] = v
+        out.update(self._prior_weights)
+        return out
+
+    def set_weights(self, weights):
+        for pre, t in self._transforms().items():
+            sub = {k[len(pre) + 1:]: v for k, v in weights.items() if k.startswith(pre + "/")}
+            t.set_weights(sub)
+            t.build(device=self.device)
+        shapes = deep_factorized_shapes(self._prior_channels(), self._prior_num_filters)
+        pw = OrderedDict()
+        for k, shp in shapes.items():
+            a = np.asarray(weights[k], np.float32)
+            if tuple(a.shape) != tuple(shp):
+                raise ValueError(f"{k}: expected {shp}, got {a.shape}")
+            pw[k] = a
+        self._prior_weights = pw
+        self._prior = None
+
+    def _prior_channels(self):
+        return self._hyper_bottleneck_size
+
+    def _get_prior(self):
+        if self._prior is None:
+            nl = len(self._prior_num_filters) + 1
+            pw = self._prior_weights
+            with torch.cuda.device(self.device):
+                self._prior = ops.DeepFactorizedPrior([pw[f"prior/matrix_{k}"] for k in range(nl)],
+                                                      [pw[f"prior/bias_{k}"] for k in range(nl)],
+                                                      [pw[f"prior/factor_{k}"] for k in range(nl - 1)])
+        return self._prior
+
+    # -- schedules (reference :151-209) ----------------------------------------------------------
+    @property
+    def global_step(self):
+        return self._step
+
+    @property
+    def _scheduled_lr(self):
+        cfg = self._optimizer_config
+        lr = cfg.get("learning_rate", 1e-4)
+        after = cfg.get("reduce_lr_after", 0.8)
+        factor = cfg.get("reduce_lr_factor", 0.1)
+        warmup = cfg.get("warmup_steps", int(cfg.get("warmup_until", 0.02) * self._scheduled_num_steps))
+        step = self.global_step
+        if warmup > 0 and step < warmup:
+            return lr * step / warmup
+        return lr * (factor if step >= int(after * self._scheduled_num_steps) else 1.0)
+
+    @property
+    def _scheduled_rd_lambda(self):
+        if self._rd_lambda <= 0.01 and not self.itinf:
+            boundary = int(self._scheduled_num_steps * HIGHER_LAMBDA_UNTIL)
+            return self._rd_lambda * (HIGHER_LAMBDA_FACTOR if self.global_step < boundary else 1.0)
+        return self._rd_lambda
+
+    @property
+    def latent_config(self):
+        config = {k: dict(v) if isinstance(v, dict) else v for k, v in self._latent_config.items()}
+        cfg = config.get("uq")
+        if cfg and cfg.get("method") == "sga":
+            cfg["tau"] = sga_schedule_at_step(self.global_step, r=cfg["tau_r"], ub=cfg["tau_ub"],
+                                              lb=cfg.get("tau_lb", 1e-8), t0=cfg["tau_t0"])
+        return config
+
+    # -- inference path (reference :212-232) -----------------------------------------------------
+    def _as_device_images(self, x):
+        if isinstance(x, np.ndarray):
+            x = ops.to_device(x, self.device)
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        return x.contiguous()
+
+    def infer_latent_rvs(self, x):
+        x = self._as_device_images(x)
+        with torch.cuda.device(self.device):
+            xp = image_utils.pad_images(x, self.downsample_factor)
+            y = self._analysis(xp)
+            z = self._hyper_analysis(y)
+        return LatentRVCollection(uq=(UQLatentRV(z), UQLatentRV(y)))
+
+    # -- generative path + losses (reference :234-359, training=False branch) ------------------------
+    def _rate_and_reconstruction(self, latent_rvs, want_symbols=False):
+        z, y = latent_rvs.uq[0].loc, latent_rvs.uq[1].loc
+        z_hat, bits_z = self._get_prior()(z)                          # :254-259 (offset 0)
+        hyper = self._hyper_synthesis(z_hat)                          # :273; split + exp fused below
+        y_hat, bits_y, sym = ops.entropy_scale_normal(y, hyper, want_symbols)   # :274-279
+        recon = self._synthesis(y_hat)                                # :297
+        return dict(z_hat=z_hat, y_hat=y_hat, symbols=sym, hyper=hyper, bits_z=bits_z, bits_y=bits_y, recon=recon)
+
+    def frame_loss_given_latent_rvs(self, image_batch, latent_rvs, training):
+        if training:
+            raise NotImplementedError("training=True (noise / SGA sampling) runs through itinf_train_step")
+        x = self._as_device_images(image_batch)
+        with torch.cuda.device(self.device):
+            r = self._rate_and_reconstruction(latent_rvs)
+            sse, _ = ops.pixels_sse(x, r["recon"])                    # unpad + floats_to_pixels + mse fused
+            host = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)]).cpu().numpy()
+        rd_loss, metrics = self._finish_metrics(x.shape, host[0], host[1], host[2])
+        metrics.record_image("reconstruction", r["recon"])
+        return rd_loss, metrics
+
+    def _finish_metrics(self, x_shape, bits_z, bits_y, sse):
+        n, h, w, c = x_shape
+        num_pixels = np.float32(h * w)                                                  # :302
+        bits_z = None if bits_z is None else bits_z.astype(np.float32)
+        bits_y = bits_y.astype(np.float32)
+        hyper_bpp = np.float32(0.0) if bits_z is None else np.float32(bits_z.mean(dtype=np.float32) / num_pixels)
+        latent_bpp = np.float32(bits_y.mean(dtype=np.float32) / num_pixels)           # :306-307
+        for name, v in (("hyper_latent_bpp", hyper_bpp), ("latent_bpp", latent_bpp)):
+            if not np.isfinite(v):                                                      # check_numerics :308-309
+                raise capi.NonFiniteError(capi.ERR_NONFINITE, f"{name} : Tensor had NaN/Inf values")
+        bpp = np.float32(hyper_bpp + latent_bpp)
+        mses, psnrs = image_utils.mse_psnr_from_sse(sse, h * w * c)                     # :315
+        mse, psnr = np.float32(mses.mean(dtype=np.float32)), np.float32(psnrs.mean(dtype=np.float32))
+        lam = self._scheduled_rd_lambda
+        rd_loss = np.float32(bpp + np.float32(lam) * mse)                               # :343
+        if not np.isfinite(rd_loss):                                                    # :356
+            raise capi.NonFiniteError(capi.ERR_NONFINITE, "rd_loss : Tensor had NaN/Inf values")
+        metrics = Metrics.make()
+        metrics.record_scalar("sched_rd_lambda", lam)
+        if self.latent_config["uq"].get("method") == "sga":
+            metrics.record_scalar("tau", self.latent_config["uq"]["tau"])
+        metrics.record_scalars(dict(rd_loss=float(rd_loss), bpp=float(bpp), mse=float(mse), psnr=float(psnr),
+                                    scheduled_lr=self._scheduled_lr))
+        return float(rd_loss), metrics
+
+    def end_to_end_frame_loss(self, image_batch, training):
+        latent_rvs = self.infer_latent_rvs(image_batch)
+        return self.frame_loss_given_latent_rvs(image_batch, latent_rvs=latent_rvs, training=training)
+
+    def validation_step(self, image_batch, training=False) -> Metrics:
+        _, metrics = self.end_to_end_frame_loss(image_batch, training=training)
+        return metrics
+
+    def evaluate(self, images):
+        """Reference :415-433: a [B,H,W,3] tensor is evaluated one [1,H,W,3] image at a time, an
+        iterable is taken as is; yields one Metrics per image."""
+        if isinstance(images, (torch.Tensor, np.ndarray)):
+            images = [images[i:i + 1] for i in range(images.shape[0])]
+        for img in images:
+            _, metrics = self.end_to_end_frame_loss(img, training=False)
+            yield metrics
+
+    def evaluate_batched(self, images):
+        """Same numbers as ``evaluate`` for same-shaped images, but one launch sequence for the whole
+        batch (independent images fill the GPU): returns per-image dicts(bpp, mse, psnr, rd_loss)."""
+        x = self._as_device_images(images)
+        with torch.cuda.device(self.device):
+            r = self._rate_and_reconstruction(self.infer_latent_rvs(x))
+            sse, _ = ops.pixels_sse(x, r["recon"])
+            host = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)]).cpu().numpy()
+        out = []
+        for i in range(x.shape[0]):
+            _, m = self._finish_metrics((1,) + tuple(x.shape[1:]), host[0][i:i + 1], host[1][i:i + 1], host[2][i:i + 1])
+            out.append(m.scalars_float)
+        return out
+
+    # -- codec regions -------------------------------------------------------------
+    def encode(self, x):
+        """x -> (z_hat, symbols int32, bits_z[n], bits_y[n]); needs the hyper-synthesis for mu, sigma."""
+        x = self._as_device_images(x)
+        with torch.cuda.device(self.device):
+            lat = self.infer_latent_rvs(x)
+            z_hat, bits_z = self._get_prior()(lat.uq[0].loc)
+            hyper = self._hyper_synthesis(z_hat)
+            _, bits_y, sym = ops.entropy_scale_normal(lat.uq[1].loc, hyper, want_symbols=True)
+        return z_hat, sym, bits_z, bits_y
+
+    def decode(self, z_hat, symbols, image_hw, reference=None):
+        """(z_hat, symbols) -> hyper-synthesis -> y_hat = symbols + mu -> synthesis -> uint8 pixels
+        [n, H, W, 3] (and the per-image integer SSE against ``reference`` if given)."""
+        with torch.cuda.device(self.device):
+            hyper = self._hyper_synthesis(z_hat)
+            y_hat = ops.dequant_scale_normal(symbols, hyper)
+            recon = self._synthesis(y_hat)
+            if reference is None:
+                return ops.to_pixels(recon, image_hw[0], image_hw[1])
+            sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
+        return px, sse
+
+    # -- iterative inference (reference :389-413) -------------------------------------------------
+    def initialize_itinf(self, image_batch):
+        raise NotImplementedError("SGA iterative inference is the next scope row (DESIGN.md)")
+
+    def itinf_train_step(self, image_batch):
+        raise NotImplementedError("SGA iterative inference is the next scope row (DESIGN.md)")
+
+    def itinf_validation_step(self, image_batch, training=False):
+        raise NotImplementedError("SGA iterative inference is the next scope row (DESIGN.md)")

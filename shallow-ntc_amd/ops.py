@@ -1,0 +1,235 @@
+"""Operator layer: torch-ROCm tensors as buffers, libsntc_hip.so as the arithmetic.
+
+Every function takes / returns dense NHWC float32 CUDA tensors, passes raw device pointers and the
+current HIP stream through the C ABI (include/sntc.h), and allocates outputs with torch's caching
+allocator.  No torch compute op is used on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+
+ACTS = {None: capi.ACT_NONE, "none": capi.ACT_NONE, "relu": capi.ACT_RELU, "leaky_relu": capi.ACT_LEAKY_RELU,
+        "lrelu": capi.ACT_LEAKY_RELU, "sigmoid": capi.ACT_SIGMOID}
+KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SIGNAL_DOWN, "sigup": capi.SIGNAL_UP}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _check_nhwc(x, c=None):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous()):
+        raise ValueError("expected a contiguous float32 NHWC CUDA tensor, got "
+                         f"{type(x).__name__} {getattr(x, 'dtype', None)} {tuple(getattr(x, 'shape', ()))}")
+    if c is not None and x.shape[-1] != c:
+        raise ValueError(f"expected {c} channels, got {x.shape[-1]}")
+
+
+def to_device(a, device):
+    """Host array -> float32 device tensor (weights, images)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+class ConvPlan:
+    """One packed convolution (sntc_conv_plan): Conv2D / Conv2DTranspose / SignalConv2D (+GDN pool)."""
+
+    def __init__(self, kind, weight, bias, stride, act=None, prologue=capi.PRO_NONE, epilogue=capi.EPI_STORE):
+        capi.require_gpu()
+        w = weight
+        kh, kw = int(w.shape[0]), int(w.shape[1])
+        if kind == "convT":
+            cout, cin = int(w.shape[2]), int(w.shape[3])
+        else:
+            cin, cout = int(w.shape[2]), int(w.shape[3])
+        self.kind, self.cin, self.cout, self.stride, self.k = kind, cin, cout, int(stride), (kh, kw)
+        self.epilogue = epilogue
+        desc = capi.ConvDesc(kind=KINDS[kind], kh=kh, kw=kw, stride=int(stride), cin=cin, cout=cout,
+                             act=ACTS[act], prologue=prologue, epilogue=epilogue)
+        w = w.contiguous()
+        b = None if bias is None else bias.contiguous()
+        self._h = C.c_void_p()
+        capi.call("sntc_conv_plan_create", C.byref(desc), _ptr(w), _ptr(b), _stream(), C.byref(self._h))
+        torch.cuda.current_stream().synchronize()   # packing reads w/b; they may be freed after this
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_conv_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def out_hw(self, h, w):
+        ho, wo = C.c_int(), C.c_int()
+        capi.call("sntc_conv_out_shape", self._h, h, w, C.byref(ho), C.byref(wo))
+        return ho.value, wo.value
+
+    def flops(self, n, h, w):
+        return int(capi.load().sntc_conv_flops(self._h, n, h, w))
+
+    def __call__(self, x, res=None, aux=None, out=None):
+        _check_nhwc(x, self.cin)
+        n, h, w, _ = x.shape
+        ho, wo = self.out_hw(h, w)
+        y = out if out is not None else torch.empty((n, ho, wo, self.cout), dtype=torch.float32, device=x.device)
+        for t in (res, aux):
+            if t is not None and tuple(t.shape) != tuple(y.shape):
+                raise ValueError(f"epilogue operand shape {tuple(t.shape)} != output shape {tuple(y.shape)}")
+        capi.call("sntc_conv_forward", self._h, _ptr(x), n, h, w, _ptr(y), _ptr(res), _ptr(aux), _stream())
+        return y
+
+
+def gdn_small(x, beta, gamma, inverse=False, alpha=1, epsilon=1.0):
+    _check_nhwc(x)
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    capi.call("sntc_gdn_small", _ptr(x), x.numel() // c, c, _ptr(beta), _ptr(gamma), int(inverse), int(alpha),
+              int(epsilon == 0.5), _ptr(y), _stream())
+    return y
+
+
+GDN_SMALL_CHANNELS = (4, 8, 12, 16, 24, 32, 48)
+TAIL_CHANNELS = (12, 24, 48)
+TAIL_ACTS = {None: 0, "none": 0, "igdn": 1, "igdn1": 1, "gdn": 2, "gdn1": 2, "relu": 3, "leaky_relu": 4, "lrelu": 4}
+
+
+def two_layer_tail(t, ch, has_res, act_kind, beta, gamma, w2, b2, k2=5, s2=2):
+    _check_nhwc(t, ch * (2 if has_res else 1))
+    n, hh, wh, _ = t.shape
+    cout = int(w2.shape[2])
+    y = torch.empty((n, hh * s2, wh * s2, cout), dtype=torch.float32, device=t.device)
+    capi.call("sntc_two_layer_tail", _ptr(t), n, hh, wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma),
+              _ptr(w2), _ptr(b2), k2, s2, cout, _ptr(y), _stream())
+    return y
+
+
+def pad_reflect(x, hp, wp):
+    _check_nhwc(x)
+    n, h, w, c = x.shape
+    if (hp, wp) == (h, w):
+        return x
+    y = torch.empty((n, hp, wp, c), dtype=torch.float32, device=x.device)
+    capi.call("sntc_pad_reflect", _ptr(x), n, h, w, c, hp, wp, _ptr(y), _stream())
+    return y
+
+
+def crop(x, h, w):
+    _check_nhwc(x)
+    n, hp, wp, c = x.shape
+    if (hp, wp) == (h, w):
+        return x
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    capi.call("sntc_crop", _ptr(x), n, hp, wp, c, h, w, _ptr(y), _stream())
+    return y
+
+
+def to_pixels(x_hat, h, w):
+    """Decoder's last step: crop to h x w, (v+.5)*255, round-half-even, saturate -> uint8 [n,h,w,c]."""
+    _check_nhwc(x_hat)
+    n, hs, ws, c = x_hat.shape
+    px = torch.empty((n, h, w, c), dtype=torch.uint8, device=x_hat.device)
+    capi.call("sntc_pixels_sse", _ptr(None), _ptr(x_hat), n, h, w, c, hs, ws, _ptr(px), _ptr(None), _stream())
+    return px
+
+
+def pixels_sse(x, x_hat, want_pixels=False):
+    """uint8 quantisation of both images + per-image integer SSE.  x_hat may be spatially larger
+    (the crop of unpad_images is fused)."""
+    _check_nhwc(x)
+    _check_nhwc(x_hat, x.shape[-1])
+    n, h, w, c = x.shape
+    hs, ws = x_hat.shape[1], x_hat.shape[2]
+    sse = torch.empty((n,), dtype=torch.int64, device=x.device)
+    px = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device) if want_pixels else None
+    capi.call("sntc_pixels_sse", _ptr(x), _ptr(x_hat), n, h, w, c, hs, ws, _ptr(px), _ptr(sse), _stream())
+    return sse, px
+
+
+def float_sse(x, x_hat):
+    _check_nhwc(x)
+    _check_nhwc(x_hat, x.shape[-1])
+    n, h, w, c = x.shape
+    sse = torch.empty((n,), dtype=torch.float64, device=x.device)
+    capi.call("sntc_float_sse", _ptr(x), _ptr(x_hat), n, h, w, c, x_hat.shape[1], x_hat.shape[2], _ptr(sse), _stream())
+    return sse
+
+
+class DeepFactorizedPrior:
+    """Device copy of tfc.NoisyDeepFactorized parameters (sntc_prior)."""
+
+    def __init__(self, matrices, biases, factors):
+        capi.require_gpu()
+        self.channels = int(matrices[0].shape[0])
+        widths = [int(matrices[0].shape[2])] + [int(m.shape[1]) for m in matrices]
+        nl = len(matrices)
+
+        def flat(arrs):
+            if not arrs:
+                return None
+            a = np.concatenate([np.ascontiguousarray(v, dtype=np.float32).ravel() for v in arrs])
+            return a.ctypes.data_as(C.POINTER(C.c_float)), a
+
+        pm, _km = flat(matrices)
+        pb, _kb = flat(biases)
+        pf_keep = flat(factors)
+        warr = (C.c_int * (nl + 1))(*widths)
+        self._h = C.c_void_p()
+        capi.call("sntc_prior_create", self.channels, nl, warr, pm, pb, pf_keep[0] if pf_keep else None,
+                  _stream(), C.byref(self._h))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_prior_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def __call__(self, z, values_only=False):
+        """-> (z_hat, bits[n] float64).  values_only: evaluate bits at z itself (explicit sample)."""
+        _check_nhwc(z, self.channels)
+        n = z.shape[0]
+        hw = z.shape[1] * z.shape[2]
+        bits = torch.empty((n,), dtype=torch.float64, device=z.device)
+        z_hat = None if values_only else torch.empty_like(z)
+        capi.call("sntc_entropy_factorized", self._h, _ptr(z), n, hw, _ptr(z_hat), _ptr(bits), int(values_only), _stream())
+        return (z if values_only else z_hat), bits
+
+
+def entropy_scale_normal(y, hyper, want_symbols=False, values_only=False):
+    """-> (y_hat, bits[n] float64, symbols int32 or None)."""
+    _check_nhwc(y)
+    c = y.shape[-1]
+    _check_nhwc(hyper, 2 * c)
+    if tuple(hyper.shape[:3]) != tuple(y.shape[:3]):
+        raise ValueError(f"hyper-synthesis output {tuple(hyper.shape)} does not match latents {tuple(y.shape)}")
+    n = y.shape[0]
+    hw = y.shape[1] * y.shape[2]
+    bits = torch.empty((n,), dtype=torch.float64, device=y.device)
+    y_hat = None if values_only else torch.empty_like(y)
+    sym = torch.empty(y.shape, dtype=torch.int32, device=y.device) if (want_symbols and not values_only) else None
+    capi.call("sntc_entropy_scale_normal", _ptr(y), _ptr(hyper), n, hw, c, _ptr(y_hat), _ptr(sym), _ptr(bits),
+              int(values_only), _stream())
+    return (y if values_only else y_hat), bits, sym
+
+
+def dequant_scale_normal(symbols, hyper):
+    c = symbols.shape[-1]
+    _check_nhwc(hyper, 2 * c)
+    n = symbols.shape[0]
+    hw = symbols.shape[1] * symbols.shape[2]
+    y_hat = torch.empty(symbols.shape, dtype=torch.float32, device=symbols.device)
+    capi.call("sntc_dequant_scale_normal", _ptr(symbols), _ptr(hyper), n, hw, c, _ptr(y_hat), _stream())
+    return y_hat

@@ -1,0 +1,162 @@
+"""GPU parity of whole transforms and of the Model forward against the float64 oracle (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_np
+from oracle import transforms_np as T
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def randomize(weights, rng):
+    """Move biases / GDN parameters off their framework defaults so every term is exercised."""
+    out = {}
+    for k, v in weights.items():
+        leaf = k.rsplit("/", 1)[-1]
+        if leaf == "bias":
+            v = (0.1 * rng.standard_normal(v.shape)).astype(np.float32)
+        elif leaf == "beta":
+            v = (1.0 + 0.5 * rng.random(v.shape)).astype(np.float32)
+        elif leaf == "gamma":
+            v = (v + 0.01 * rng.random(v.shape)).astype(np.float32)
+        out[k] = v
+    return out
+
+
+TRANSFORMS = [  # cls, kwargs, input shape (n,h,w,c)
+    ("ElicAnalysis", dict(channels=(32, 32, 64, 64)), (1, 64, 96, 3)),
+    ("ElicAnalysis", dict(channels=(32, 64, 64), kernel_sizes=(5, 5, 5), strides=(2, 2, 2)), (1, 40, 24, 3)),
+    ("ElicSynthesis", dict(channels=(64, 32, 32, 3)), (1, 3, 4, 64)),
+    ("CNNAnalysis", dict(channels_base=32, output_channels=64), (2, 48, 32, 3)),
+    ("CNNAnalysis", dict(channels_base=32, output_channels=64, activation_type="gdn"), (1, 32, 32, 3)),
+    ("CNNSynthesis", dict(channels_base=32, output_channels=3), (1, 3, 2, 64)),
+    ("CNNSynthesis", dict(channels_base=32, output_channels=3, activation_type="igdn"), (1, 2, 2, 64)),
+    ("HyperAnalysis", dict(bottleneck_size=64), (2, 12, 8, 64)),
+    ("HyperSynthesis", dict(bottleneck_size=64), (2, 3, 2, 64)),
+    ("BLS2017Analysis", dict(num_filters=64), (1, 64, 48, 3)),
+    ("BLS2017Synthesis", dict(num_filters=64), (1, 4, 3, 64)),
+    ("MBT2018Analysis", dict(channels_base=32, output_channels=64), (1, 64, 64, 3)),
+    ("MBT2018Synthesis", dict(channels_base=32, output_channels=3), (1, 4, 4, 64)),
+    ("MBT2018Analysis", dict(channels_base=32, output_channels=64, gdn_alpha=2, gdn_epsilon=0.5), (1, 32, 32, 3)),
+    ("MBT2018Synthesis", dict(channels_base=32, output_channels=3, gdn_alpha=2, gdn_epsilon=0.5), (1, 2, 2, 64)),
+    ("HyperAnalysisSmall", dict(bottleneck_size=32), (1, 8, 8, 32)),
+    ("HyperSynthesisSmall", dict(bottleneck_size=32), (1, 4, 4, 32)),
+    ("JPEGLikeSynthesis", dict(kernel_size=18, strides=16), (2, 3, 4, 64)),
+    ("JPEGLikeSynthesis", dict(kernel_size=16, strides=16), (1, 2, 2, 64)),
+    ("JPEGLikeHyperSynthesis", dict(bottleneck_size=32, kernel_size=6), (1, 3, 3, 32)),
+    ("TwoLayerSynthesis", dict(channels=(24, 3)), (1, 3, 4, 64)),
+    ("TwoLayerSynthesis", dict(channels=(48, 3)), (1, 2, 3, 64)),
+    ("TwoLayerResSynthesis", dict(channels=(12, 3)), (2, 4, 3, 64)),
+]
+
+
+@pytest.mark.parametrize("cls,kwargs,shape", TRANSFORMS, ids=[f"{c}-{i}" for i, (c, _, _) in enumerate(TRANSFORMS)])
+def test_transform_parity(cls, kwargs, shape, dev):
+    from shallow_ntc_amd.common.transforms import class_builder
+    rng = np.random.default_rng(abs(hash(cls)) % 1000)
+    t = class_builder.build(cls, **kwargs)
+    cin = shape[-1]
+    okw = dict(kwargs)
+    if cin != 3 or cls.endswith("Synthesis"):
+        okw["cin"] = cin
+    ref_t = T.build(cls, **okw)
+    # the two independently written inventories agree on names and shapes
+    assert dict(t.param_shapes(cin)) == dict(ref_t.param_shapes())
+    t.build(cin, dev)
+    w = randomize(t.get_weights(), rng)
+    t.set_weights(w)
+    x = rng.standard_normal(shape).astype(np.float32)
+    got = t(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = ref_t(w, x)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 5e-5
+
+
+def _small_cfg(synth):
+    return dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 64)), synthesis=synth)
+
+
+@pytest.mark.parametrize("synth", [
+    dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn", res_type="conv"),
+    dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16),
+    dict(cls="TwoLayerSynthesis", channels=(24, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn"),
+], ids=["two_layer_res", "jpeg_like", "two_layer"])
+def test_mshyper_model_parity(synth, dev):
+    """bpp / PSNR of the HIP path vs the oracle on the same image + weights.  The latents are compared
+    first; rate and distortion are then checked with the oracle evaluated on the HIP latents so that a
+    float32-vs-float64 rounding flip of round(y - mu) (counted below) cannot hide an arithmetic error."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper.models import Model
+    rng = np.random.default_rng(0)
+    tc = _small_cfg(synth)
+    model = Model(rd_lambda=0.02, transform_config=tc, device=dev)
+    assert model.downsample_factor == 64
+    w = randomize(model.get_weights(), rng)
+    # realistic spread of scales: bias of the sigma half of the hyper-synthesis output
+    b = w["hyper_synthesis/layer_2/bias"].copy()
+    b[64:] = rng.uniform(-1.0, 3.0, size=64)
+    w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
+    model.set_weights(w)
+    x = data_lib.normalize_image(data_lib.synthetic_images(2, 100, 150, seed=3))      # pads to 128 x 192
+    ref_model = model_np.Model(tc, rd_lambda=0.02)
+    lat = model.infer_latent_rvs(x)
+    z, y = lat.uq[0].loc.cpu().numpy(), lat.uq[1].loc.cpu().numpy()
+    rz, ry = ref_model.infer_latents(w, x)
+    assert rel_err(y, ry) < 5e-5 and rel_err(z, rz) < 5e-5
+    # oracle on the HIP latents (float32 -> float64): isolates the generative path
+    ref = ref_model.frame_loss(w, x, (z, y))
+    r = model._rate_and_reconstruction(lat, want_symbols=True)
+    flips = int((r["symbols"].cpu().numpy() != ref["symbols_y"]).sum())
+    assert flips <= 2, flips
+    np.testing.assert_array_equal(r["z_hat"].cpu().numpy(), ref["z_hat"])
+    per_image = model.evaluate_batched(x)
+    _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
+    m = metrics.scalars_float
+    if flips == 0:
+        assert abs(m["bpp"] - ref["bpp"]) <= 1e-4                    # BASELINE tolerance
+        assert abs(m["psnr"] - ref["psnr"]) <= 1e-3
+    assert abs(m["bpp"] - ref["bpp"]) <= 1e-3 and abs(m["psnr"] - ref["psnr"]) <= 1e-2
+    assert abs(m["rd_loss"] - (m["bpp"] + 0.02 * m["mse"])) < 1e-5   # results/readme.md identity
+    assert abs(np.mean([d["psnr"] for d in per_image]) - m["psnr"]) < 1e-4
+    # end to end against the oracle's own latents: same numbers up to the counted flips
+    ref_e2e = ref_model.end_to_end(w, x)
+    assert abs(m["bpp"] - ref_e2e["bpp"]) <= 2e-3 and abs(m["psnr"] - ref_e2e["psnr"]) <= 2e-2
+    # evaluate() yields one Metrics per image with the reference's scalar keys
+    ms = list(model.evaluate(x))
+    assert len(ms) == 2 and {"rd_loss", "bpp", "mse", "psnr", "scheduled_lr", "sched_rd_lambda"} <= set(ms[0].scalars)
+    # codec regions: decode(encode(x)) reproduces the evaluated reconstruction bit for bit
+    z_hat, sym, bz, by = model.encode(x)
+    px, sse = model.decode(z_hat, sym, (100, 150), reference=torch.from_numpy(x).to(dev))
+    np.testing.assert_array_equal(px.cpu().numpy(), ref["recon_pixels"]) if flips == 0 else None
+    mse_dec = sse.cpu().numpy() / (100 * 150 * 3.0)
+    assert abs(mse_dec.mean() - m["mse"]) < 1e-3
+
+
+def test_factorized_model_parity(dev):
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.factorized.models import Model
+    rng = np.random.default_rng(1)
+    tc = dict(analysis=dict(cls="BLS2017Analysis", num_filters=64), synthesis=dict(cls="BLS2017Synthesis", num_filters=64))
+    model = Model(rd_lambda=0.01, transform_config=tc, device=dev)
+    assert model.downsample_factor == 16
+    w = randomize(model.get_weights(), rng)
+    model.set_weights(w)
+    x = data_lib.normalize_image(data_lib.synthetic_images(1, 70, 90, seed=5))        # pads to 80 x 96
+    ref_model = model_np.Model(tc, rd_lambda=0.01, factorized=True)
+    lat = model.infer_latent_rvs(x)
+    y = lat.uq[0].loc.cpu().numpy()
+    (ry,) = ref_model.infer_latents(w, x)
+    assert rel_err(y, ry) < 5e-5
+    ref = ref_model.frame_loss(w, x, (y,))
+    _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
+    m = metrics.scalars_float
+    assert abs(m["bpp"] - ref["bpp"]) <= 1e-4 and abs(m["psnr"] - ref["psnr"]) <= 1e-3
+    # lambda warm-up (mshyper/models.py:168-184): rd_lambda <= 0.01 is scaled x10 at step 0
+    assert abs(m["sched_rd_lambda"] - 0.1) < 1e-9

@@ -1,0 +1,251 @@
+"""GPU parity of every C-ABI op against the float64 oracle on seeded inputs (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def dev_t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+
+
+# float32 accumulation against float64: K up to ~8000 products per output
+TOL = 2e-5
+
+CONV_CASES = [  # kind, k, s, cin, cout, n, h, w, act
+    ("conv", 1, 1, 32, 64, 2, 9, 7, "relu"),
+    ("conv", 3, 1, 32, 32, 1, 16, 12, "relu"),
+    ("conv", 3, 1, 96, 96, 1, 20, 24, None),
+    ("conv", 5, 2, 64, 96, 2, 16, 20, None),
+    ("conv", 5, 2, 32, 160, 1, 17, 13, "leaky_relu"),     # odd sizes: SAME pad changes
+    ("conv", 5, 2, 3, 32, 2, 32, 24, None),               # first layer, Cin = 3 (scalar-gather path)
+    ("conv", 1, 1, 192, 96, 1, 12, 16, "sigmoid"),
+    ("conv", 5, 2, 320, 320, 1, 8, 12, "relu"),
+    ("sigdown", 5, 2, 32, 64, 1, 16, 16, None),
+    ("sigdown", 9, 4, 3, 32, 1, 32, 32, None),
+    ("sigdown", 3, 1, 32, 32, 1, 7, 9, "relu"),
+    ("convT", 5, 2, 32, 64, 2, 6, 5, "relu"),
+    ("convT", 5, 2, 320, 480, 1, 4, 6, "relu"),
+    ("convT", 3, 1, 96, 128, 1, 8, 12, None),
+    ("convT", 13, 8, 64, 24, 1, 4, 6, None),
+    ("convT", 18, 16, 64, 3, 2, 3, 4, None),
+    ("convT", 16, 16, 32, 3, 1, 2, 3, None),
+    ("convT", 6, 4, 32, 64, 1, 3, 3, None),
+    ("sigup", 5, 2, 32, 32, 1, 5, 6, None),
+    ("sigup", 9, 4, 32, 3, 1, 4, 4, None),
+    ("sigup", 3, 1, 32, 64, 1, 6, 5, "relu"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv_family(case, dev):
+    from shallow_ntc_amd import ops
+    kind, k, s, cin, cout, n, h, w, act = case
+    rng = np.random.default_rng(hash(case) % (2**32))
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wshape = (k, k, cout, cin) if kind == "convT" else (k, k, cin, cout)
+    wk = (rng.standard_normal(wshape) / np.sqrt(k * k * cin / 4)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    fn = {"conv": O.conv2d, "convT": O.conv2d_transpose, "sigdown": O.signal_conv_down, "sigup": O.signal_conv_up}[kind]
+    ref = O.ACTIVATIONS[act](fn(x, wk, b, s))
+    plan = ops.ConvPlan(kind, dev_t(wk, dev), dev_t(b, dev), s, act)
+    got = plan(dev_t(x, dev)).cpu().numpy()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < TOL
+    assert plan.flops(n, h, w) == 2 * n * k * k * cin * cout * (h * w if kind in ("convT", "sigup") else ref.shape[1] * ref.shape[2])
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_tile_variant(variant, dev):
+    """Each gather-GEMM instantiation gives the same answer (tile selection is a speed choice only)."""
+    from shallow_ntc_amd import _capi, ops
+    rng = np.random.default_rng(variant)
+    x = rng.standard_normal((2, 11, 13, 64)).astype(np.float32)
+    wk = (rng.standard_normal((5, 5, 200, 64)) * 0.05).astype(np.float32)     # convT 5/2: 4 phase groups
+    b = rng.standard_normal(200).astype(np.float32)
+    ref = O.conv2d_transpose(x, wk, b, 2)
+    plan = ops.ConvPlan("convT", dev_t(wk, dev), dev_t(b, dev), 2)
+    prev = _capi.load().sntc_conv_set_tile_override(variant)
+    try:
+        got = plan(dev_t(x, dev)).cpu().numpy()
+    finally:
+        _capi.load().sntc_conv_set_tile_override(prev)
+    assert rel_err(got, ref) < TOL
+
+
+def test_epilogues(dev):
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 6, 7, 32)).astype(np.float32)
+    wk = (rng.standard_normal((1, 1, 32, 64)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    res = rng.standard_normal((2, 6, 7, 64)).astype(np.float32)
+    aux = rng.standard_normal((2, 6, 7, 64)).astype(np.float32)
+    conv = O.conv2d(x, wk, b, 1)
+    add = ops.ConvPlan("conv", dev_t(wk, dev), dev_t(b, dev), 1, None, capi.PRO_NONE, capi.EPI_ADD)
+    assert rel_err(add(dev_t(x, dev), res=dev_t(res, dev)).cpu().numpy(), conv + res) < TOL
+    gate = ops.ConvPlan("conv", dev_t(wk, dev), dev_t(b, dev), 1, "sigmoid", capi.PRO_NONE, capi.EPI_GATE)
+    got = gate(dev_t(x, dev), res=dev_t(res, dev), aux=dev_t(aux, dev)).cpu().numpy()
+    assert rel_err(got, res + aux * O.sigmoid(conv)) < TOL
+    with pytest.raises(capi.SntcError):
+        add(dev_t(x, dev))          # epilogue operand missing -> loud failure, not a silent store
+
+
+@pytest.mark.parametrize("c,inverse,alpha,eps", [(12, True, 1, 1.0), (12, False, 1, 1.0), (24, True, 1, 1.0),
+                                                 (48, False, 2, 0.5), (64, False, 1, 1.0), (192, True, 1, 1.0),
+                                                 (96, False, 2, 0.5), (256, False, 1, 1.0)])
+def test_gdn(c, inverse, alpha, eps, dev):
+    from shallow_ntc_amd.common._graph import GDN
+    rng = np.random.default_rng(c)
+    x = rng.standard_normal((2, 9, 10, c)).astype(np.float32)
+    beta = (1.0 + rng.random(c)).astype(np.float32)
+    gamma = (0.1 * np.eye(c) + 0.02 * rng.random((c, c))).astype(np.float32)
+    node = GDN("g", inverse, alpha, eps)
+    node.build({"g/beta": dev_t(beta, dev), "g/gamma": dev_t(gamma, dev)}, c)
+    got = node(dev_t(x, dev)).cpu().numpy()
+    assert rel_err(got, O.gdn(x, beta, gamma, inverse, alpha, eps)) < TOL
+
+
+@pytest.mark.parametrize("ch,has_res,act", [(12, True, "igdn"), (24, False, "igdn"), (48, False, "igdn"),
+                                            (12, True, None), (24, True, "relu")])
+def test_two_layer_tail(ch, has_res, act, dev):
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(ch)
+    n, hh, wh = 2, 21, 19
+    t = rng.standard_normal((n, hh, wh, ch * (2 if has_res else 1))).astype(np.float32)
+    beta = (1.0 + rng.random(ch)).astype(np.float32)
+    gamma = (0.1 * np.eye(ch) + 0.02 * rng.random((ch, ch))).astype(np.float32)
+    w2 = (rng.standard_normal((5, 5, 3, ch)) * 0.1).astype(np.float32)
+    b2 = rng.standard_normal(3).astype(np.float32)
+    base = t[..., :ch].astype(np.float64)
+    if act == "igdn":
+        base = O.gdn(base, beta, gamma, inverse=True)
+    elif act == "relu":
+        base = O.relu(base)
+    hsum = base + (t[..., ch:] if has_res else 0.0)
+    ref = O.conv2d_transpose(hsum, w2, b2, 2)
+    got = ops.two_layer_tail(dev_t(t, dev), ch, has_res, ops.TAIL_ACTS[act], dev_t(beta, dev), dev_t(gamma, dev),
+                             dev_t(w2, dev), dev_t(b2, dev)).cpu().numpy()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < TOL
+
+
+def test_pad_crop_pixels(dev):
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(3)
+    x = (rng.integers(0, 256, size=(2, 37, 50, 3)).astype(np.float32) / np.float32(255) - np.float32(0.5))
+    xp = ops.pad_reflect(dev_t(x, dev), 64, 64)
+    np.testing.assert_array_equal(xp.cpu().numpy(), O.pad_images(x, 64).astype(np.float32))
+    np.testing.assert_array_equal(ops.crop(xp, 37, 50).cpu().numpy(), x)
+    xh = (x + rng.normal(0, 0.05, size=x.shape)).astype(np.float32)
+    xh[0, 0, 0, 0] = 2.0      # saturates to 255
+    xh[0, 0, 0, 1] = -3.0     # saturates to 0
+    xh[0, 0, 1, 0] = np.float32(100.5) / np.float32(255) - np.float32(0.5)   # lands near a .5 tie
+    xh_p = np.pad(xh, ((0, 0), (0, 27), (0, 14), (0, 0)))
+    sse, px = ops.pixels_sse(dev_t(x, dev), dev_t(xh_p, dev), want_pixels=True)
+    ref_px = O.floats_to_pixels(xh, training=False)
+    ref_x = O.floats_to_pixels(x, training=False)
+    np.testing.assert_array_equal(px.cpu().numpy(), ref_px)
+    ref_sse = ((ref_x.astype(np.int64) - ref_px.astype(np.int64)) ** 2).reshape(2, -1).sum(1)
+    np.testing.assert_array_equal(sse.cpu().numpy(), ref_sse)
+    np.testing.assert_array_equal(ops.to_pixels(dev_t(xh_p, dev), 37, 50).cpu().numpy(), ref_px)
+    fs = ops.float_sse(dev_t(x, dev), dev_t(xh_p, dev)).cpu().numpy()
+    ref_fs = (((x.astype(np.float64) - xh.astype(np.float64)) * 255.0) ** 2).reshape(2, -1).sum(1)
+    assert np.abs(fs - ref_fs).max() / ref_fs.max() < 1e-5
+
+
+def _synthetic_latents(rng, n, h, w, c):
+    """SURVEY.md 8d entropy set: y-mu ~ Laplace(0,2), mu ~ N(0,1), raw ~ U(-3, 4.3) (spans both clamps)."""
+    mu = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    raw = rng.uniform(-3.0, 4.3, size=(n, h, w, c)).astype(np.float32)
+    y = (mu + rng.laplace(0, 2.0, size=(n, h, w, c))).astype(np.float32)
+    return y, np.concatenate([mu, raw], axis=-1)
+
+
+def test_entropy_scale_normal(dev):
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(11)
+    y, hyper = _synthetic_latents(rng, 3, 8, 6, 64)
+    y[0, 0, 0, :4] = hyper[0, 0, 0, :4] + np.array([20.0, -35.0, 0.5, -1.5], np.float32)    # far tails + ties
+    hyper[0, 0, 0, 64:68] = np.array([-10.0, -10.0, 5.0, 0.0], np.float32)                   # sigma = 0.11 / 256 clamps
+    c = 64
+    mu, raw = hyper[..., :c], hyper[..., c:]
+    ref_yhat, ref_bits, ref_sym = O.scale_indexed_normal(y, mu, np.exp(raw.astype(np.float64)))
+    y_hat, bits, sym = ops.entropy_scale_normal(dev_t(y, dev), dev_t(hyper, dev), want_symbols=True)
+    # symbols: bit-exact in the integer domain given identical float32 (y, mu)
+    ref_sym32 = np.rint(y - mu).astype(np.int32)
+    np.testing.assert_array_equal(sym.cpu().numpy(), ref_sym32)
+    np.testing.assert_array_equal(y_hat.cpu().numpy(), ref_sym32.astype(np.float32) + mu)
+    got = bits.cpu().numpy()
+    assert np.abs(got - ref_bits).max() / np.abs(ref_bits).max() < 2e-5
+    # explicit-sample mode
+    _, bits2, _ = ops.entropy_scale_normal(y_hat, dev_t(hyper, dev), values_only=True)
+    assert np.abs(bits2.cpu().numpy() - ref_bits).max() / np.abs(ref_bits).max() < 2e-5
+    # decoder-side dequantisation reproduces y_hat exactly
+    np.testing.assert_array_equal(ops.dequant_scale_normal(sym, dev_t(hyper, dev)).cpu().numpy(), y_hat.cpu().numpy())
+
+
+def test_entropy_known_answers(dev):
+    """float64 SciPy values of -log2[Phi((v+.5)/s) - Phi((v-.5)/s)]."""
+    from shallow_ntc_amd import ops
+    kat = {0.0: [7.908418055e-06, 18.47694976, 378.4317401, 22677.58857],
+           10.0: [0.2937470448, 3.441034068, 35.88577211, 1941.606578],
+           31.5: [3.735669186, 3.761209505, 3.965532119, 13.95192272],
+           63.0: [9.325748982, 9.325759989, 9.325848044, 9.330151732]}
+    vs = [0.0, 1.0, -3.0, 20.0]
+    for idx, want in kat.items():
+        for v, w in zip(vs, want):
+            y = np.full((1, 1, 1, 4), v, np.float32)
+            raw = np.full((1, 1, 1, 4), np.log(idx) if idx > 0 else -50.0, np.float32)
+            hyper = np.concatenate([np.zeros_like(y), raw], -1)
+            _, bits, _ = ops.entropy_scale_normal(dev_t(y, dev), dev_t(hyper, dev))
+            got = bits.cpu().numpy()[0] / 4
+            assert abs(got - w) <= 2e-4 * max(w, 1e-3), (idx, v, got, w)
+
+
+@pytest.mark.parametrize("num_filters", [(3, 3), (3, 3, 3), (2,), (4, 4, 4, 4)])
+def test_entropy_factorized(num_filters, dev):
+    from oracle import model_np
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(len(num_filters))
+    c = 48
+    p = model_np.init_deep_factorized(c, rng, num_filters)
+    for k in p:                                   # move off the initial values so tanh factors matter
+        p[k] = (p[k] + 0.3 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    nl = len(num_filters) + 1
+    ms = [p[f"prior/matrix_{k}"] for k in range(nl)]
+    bs = [p[f"prior/bias_{k}"] for k in range(nl)]
+    fs = [p[f"prior/factor_{k}"] for k in range(nl - 1)]
+    z = (rng.standard_normal((2, 5, 7, c)) * 3).astype(np.float32)
+    z[0, 0, 0, :3] = [40.0, -55.0, 2.5]
+    ref_v, ref_bits = O.batched_deep_factorized(z, ms, bs, fs)
+    prior = ops.DeepFactorizedPrior(ms, bs, fs)
+    z_hat, bits = prior(dev_t(z, dev))
+    np.testing.assert_array_equal(z_hat.cpu().numpy(), np.rint(z))
+    assert np.abs(bits.cpu().numpy() - ref_bits).max() / np.abs(ref_bits).max() < 2e-5
+    _, bits2 = prior(z_hat, values_only=True)
+    assert np.abs(bits2.cpu().numpy() - ref_bits).max() / np.abs(ref_bits).max() < 2e-5
+
+
+def test_errors_are_loud(dev):
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    with pytest.raises(ValueError):
+        ops.pad_reflect(torch.zeros((1, 4, 4, 3)), 8, 8)                 # CPU tensor
+    with pytest.raises(capi.SntcError):
+        ops.pad_reflect(torch.zeros((1, 4, 4, 3), device=dev), 16, 16)   # reflect pad >= size
+    with pytest.raises(capi.SntcError):
+        ops.gdn_small(torch.zeros((1, 2, 2, 7), device=dev), torch.ones(7, device=dev), torch.zeros((7, 7), device=dev))
+    w = torch.zeros((3, 3, 8, 16), device=dev)                            # kernel smaller than the stride
+    with pytest.raises(capi.SntcError):
+        ops.ConvPlan("convT", w, None, 4)
