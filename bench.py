@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- decode Mpixel/s (+ bpp, PSNR) of the two_layer_syn codec on Kodak-shaped inputs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one decode pass of the hot path over the rank's batch: (z_hat, symbols) resident in HBM ->
+hyper-synthesis -> y_hat = symbols + mu -> two-layer synthesis -> uint8 pixels, for a Kodak-24-shaped
+synthetic set (18 x 512x768 + 6 x 768x512; mshyper/configs/two_layer_syn.py, random-init weights --
+there is no network for Kodak or checkpoints).  Weak scaling: every rank decodes its own set.
+The JSON line also carries the encode+decode rate, the (bpp, PSNR) of the set, the live-measured
+roofline of the dominant kernel and a CPU baseline (torch-CPU port of the same decode, rank 0, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import __graft_entry__ as graft  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+KODAK_SHAPES = [(512, 768)] * 18 + [(768, 512)] * 6
+
+
+def synthetic_batch(n, h, w, seed, device):
+    """Seeded smooth images (SURVEY.md 8d recipe) generated on the device: 16 low-frequency cosines per
+    channel + N(0, 4^2) noise, rounded to uint8 values, normalised to [-0.5, 0.5]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    yy = (torch.arange(h, device=device, dtype=torch.float32) / h).view(1, h, 1, 1, 1)
+    xx = (torch.arange(w, device=device, dtype=torch.float32) / w).view(1, 1, w, 1, 1)
+    f = torch.rand((n, 1, 1, 3, 16, 2), device=device, generator=g) * 6.0
+    ph = torch.rand((n, 1, 1, 3, 16), device=device, generator=g) * (2 * np.pi)
+    amp = torch.rand((n, 1, 1, 3, 16), device=device, generator=g) * 20.0 + 4.0
+    img = 128.0 + (amp * torch.cos(2 * np.pi * (f[..., 0] * yy + f[..., 1] * xx) + ph)).sum(-1)
+    img = img + 4.0 * torch.randn(img.shape, device=device, generator=g)
+    img = torch.clamp(torch.round(img), 0, 255)
+    return (img / 255.0 - 0.5).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images", type=int, default=24, help="images per rank (Kodak-24 shaped set)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=3)
+    args = ap.parse_args()
+
+    graft.load_package()
+    from shallow_ntc_amd import distributed as D
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+
+    rank, local_rank, world = D.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = configs.two_layer_syn(rd_lambda=0.005)
+    model = Model(device=dev, **cfg)
+    # spread the predicted scales like a trained model would (untrained nets give one degenerate sigma)
+    w = model.get_weights()
+    rng = np.random.default_rng(4321)
+    b = w["hyper_synthesis/layer_2/bias"].copy()
+    b[320:] = rng.uniform(-2.0, 2.5, size=320)
+    w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
+    model.set_weights(w)
+
+    shapes = KODAK_SHAPES[:args.images] if args.images <= 24 else [KODAK_SHAPES[i % 24] for i in range(args.images)]
+    groups = {}
+    for i, s in enumerate(shapes):
+        groups.setdefault(s, []).append(i)
+    batches = []   # (image ids, x)
+    for (h, wd), ids in groups.items():
+        batches.append((ids, synthetic_batch(len(ids), h, wd, 1234 + 97 * rank + h, dev), (h, wd)))
+    pixels_per_step = sum(h * wd for h, wd in shapes)
+
+    # ---- encode once (untimed): codes stay resident in HBM ---------------------------------------
+    codes, rows = [], []
+    for ids, x, hw in batches:
+        z_hat, sym, bits_z, bits_y = model.encode(x)
+        codes.append((z_hat, sym, hw, x))
+        for d, i in zip(model.evaluate_batched(x), ids):
+            rows.append((i, d["bpp"], d["psnr"], d["mse"]))
+    torch.cuda.synchronize()
+    rows.sort()
+    table = D.gather_rows([r[1:] for r in rows], [r[0] + rank * len(shapes) for r in rows], world * len(shapes), device=dev)
+
+    def decode_step():
+        out = []
+        for z_hat, sym, hw, _x in codes:
+            out.append(model.decode(z_hat, sym, hw))
+        return out
+
+    def e2e_step():
+        for ids, x, hw in batches:
+            z_hat, sym, _, _ = model.encode(x)
+            model.decode(z_hat, sym, hw, reference=x)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        D.barrier()
+        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+    t_dec = timed(decode_step, args.steps, args.warmup)
+    e2e_steps = max(2, args.steps // 4)
+    t_e2e = timed(e2e_step, e2e_steps, 1)
+    ms_per_step = 1e3 * t_dec / args.steps
+    value = world * pixels_per_step * args.steps / t_dec / 1e6
+    e2e_value = world * pixels_per_step * e2e_steps / t_e2e / 1e6
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, per launch ---------------
+    roofline = None
+    if rank == 0:
+        per_kernel = {}
+        for _rep in range(3):
+            ops.PROFILE = []
+            decode_step()
+            torch.cuda.synchronize()
+            for e in ops.PROFILE:
+                name = f"gg_kernel<1,{e['variant']},4,1,{'vec' if e['vec'] else 'scalar'}>" if e["variant"] != 8 \
+                    else f"gg_kernel<1,1,2,2,{'vec' if e['vec'] else 'scalar'}>"
+                k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
+                k["ms"] += e["e0"].elapsed_time(e["e1"])
+                k["flops"] += e["flops"]
+                k["launches"] += 1
+            ops.PROFILE = None
+        name, k = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
+        achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_ms=round(k["ms"] / k["launches"], 4), launches_per_step=k["launches"] // 3,
+                        precision="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                        all_kernels={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                             ms_per_step=round(v["ms"] / 3, 4)) for n, v in per_kernel.items()})
+
+    # ---- CPU baseline: the torch-CPU port of the same decode on this box's host cores ---------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import model_np, torch_ref
+        ref_model = model_np.Model(cfg["transform_config"], rd_lambda=cfg["rd_lambda"])
+        weights = model.get_weights()
+        host_codes = [(z.cpu().numpy(), s.cpu().numpy().astype(np.float32), hw) for z, s, hw, _ in codes]
+        n_img = sum(z.shape[0] for z, _, _ in host_codes)
+        times = []
+        for p in range(args.cpu_passes + 1):
+            t0 = time.perf_counter()
+            for z, s, hw in host_codes:
+                torch_ref.decode(ref_model, weights, z, s, hw)
+            if p > 0:
+                times.append(time.perf_counter() - t0)
+        t_cpu = float(np.median(times))
+        cpu_baseline = dict(value=round(pixels_per_step / t_cpu / 1e6, 3), unit="Mpixel/s", cores=torch.get_num_threads(),
+                            kind="port",
+                            sample=f"{n_img} Kodak-shaped images decoded by oracle/torch_ref.py (float32, oneDNN), "
+                                   f"median of {args.cpu_passes} passes after 1 warm-up; the reference's TF-CPU path "
+                                   f"cannot be installed here")
+
+    if rank == 0:
+        tbl = table[~np.isnan(table[:, 0])]
+        line = dict(
+            metric="decode Mpixels/s + (bpp, PSNR) on Kodak, two_layer_syn",
+            value=round(value, 2), unit="Mpixel/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+            dtype="f32", data="synthetic",
+            config=dict(workload=f"mshyper/configs/two_layer_syn.py (ElicAnalysis 192,192,192,320 + TwoLayerResSynthesis 12,3), "
+                                 f"Kodak-24-shaped synthetic set per GPU ({len(shapes)} images: 512x768 / 768x512), "
+                                 f"random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
+                        timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels"),
+            encode_decode_mpixels_per_s=round(e2e_value, 2),
+            rd=dict(bpp=round(float(tbl[:, 0].mean()), 5), psnr=round(float(tbl[:, 1].mean()), 4), images=int(tbl.shape[0]),
+                    note="untrained random-init weights: parity-checked numbers, not a trained R-D point"),
+            roofline=roofline, cpu_baseline=cpu_baseline,
+        )
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

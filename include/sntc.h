@@ -102,6 +102,9 @@ int sntc_conv_forward(const sntc_conv_plan* plan, const float* x, int n, int h, 
                       const float* res, const float* aux, void* stream);
 /* Tile-selection override for experiments: 0 = heuristic. Returns previous value. */
 int sntc_conv_set_tile_override(int variant);
+/* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64) the heuristic picks for this call shape,
+ * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
+int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);
 
 /* ------------------------------------------------------------------------------------------
  * Small-channel GDN1 / IGDN1 (C <= 64): wave-shuffle contraction, no MFMA.

@@ -228,6 +228,27 @@ class ElicAnalysis(Transform):
         super().__init__(Seq(blocks), cin)
 
 
+class ElicSynthesis(Transform):
+    """common/elic.py:180-250."""
+
+    def __init__(self, num_residual_blocks=3, channels=(192, 160, 128, 3), kernel_sizes=(5, 5, 5, 5),
+                 strides=(2, 2, 2, 2), output_channels=None, cin=None):
+        assert len(channels) in (3, 4) and len(channels) == len(strides) == len(kernel_sizes)
+        convs = [Conv(f"conv{i}", "convT", c, k, s, None)
+                 for i, (c, k, s) in enumerate(zip(channels, kernel_sizes, strides))]
+        cnt = [0]
+
+        def rbs():
+            out = [ResidualBlock(f"rb{cnt[0] + j}") for j in range(num_residual_blocks)]
+            cnt[0] += num_residual_blocks
+            return out
+
+        blocks = [SimpleAttention("attn0"), convs[0], *rbs(), convs[1], SimpleAttention("attn1"), *rbs(), convs[2]]
+        if len(channels) == 4:
+            blocks += [*rbs(), convs[3]]
+        super().__init__(Seq(blocks), cin)
+
+
 class CNNAnalysis(Transform):
     """common/transforms.py:179-192 (one shared activation object, :183)."""
 
@@ -419,7 +440,7 @@ class JPEGLikeHyperSynthesis(Transform):
 
 CLASSES = {c.__name__: c for c in [
     BLS2017Analysis, BLS2017Synthesis, CNNAnalysis, CNNSynthesis, HyperAnalysis, HyperSynthesis,
-    MBT2018Analysis, MBT2018Synthesis, HyperAnalysisSmall, HyperSynthesisSmall, ElicAnalysis,
+    MBT2018Analysis, MBT2018Synthesis, HyperAnalysisSmall, HyperSynthesisSmall, ElicAnalysis, ElicSynthesis,
     JPEGLikeSynthesis, TwoLayerSynthesis, TwoLayerResSynthesis, JPEGLikeHyperSynthesis]}
 
 

@@ -264,6 +264,21 @@ static int pick_variant(const sntc_conv_plan* p, int64_t M) {
   return bestv;
 }
 
+extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int w, int* variant, int* nblocks) {
+  if (!p || !variant || !nblocks) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_launch_info: null argument");
+  Geo g;
+  int rc = geometry(p, h, w, &g);
+  if (rc) return rc;
+  const int64_t M = (int64_t)n * g.Qh * g.Qw;
+  const int v = pick_variant(p, M);
+  const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
+  int64_t nb = 0;
+  for (int gi = 0; gi < p->ngroups; ++gi) nb += (int64_t)((p->g[gi].Ncol + bn - 1) / bn) * ((M + bm - 1) / bm);
+  *variant = v;
+  *nblocks = (int)nb;
+  return SNTC_OK;
+}
+
 extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n, int h, int w, float* y,
                                  const float* res, const float* aux, void* stream) {
   if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: null argument");

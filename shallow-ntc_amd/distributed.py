@@ -1,0 +1,75 @@
+"""Multi-GPU driver: independent images shard over ranks; the only exchange is one all-gather of
+per-image (bpp, psnr, mse, bits) rows at the end (RCCL over xGMI when the backend is "nccl").
+
+The reference has no distribution at all (one GPU per Slurm array task, slurm_template.py:8-11);
+images are independent (mshyper/models.py:425-433), so there is no data-path collective.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when not launched by it."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def init(backend=None):
+    """Initialise torch.distributed if WORLD_SIZE > 1 (nccl == RCCL on ROCm; gloo for CPU tests)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(num_items, rank, world):
+    """Image i goes to rank i mod world (round-robin keeps the Kodak orientations balanced)."""
+    return list(range(rank, num_items, world))
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local_rows, indices, num_items, device="cpu"):
+    """All-gather per-image metric rows.  local_rows: float array [len(indices), k] for the image
+    ids in ``indices``.  Returns the full [num_items, k] table on every rank, ordered by image id."""
+    local_rows = np.asarray(local_rows, np.float64).reshape(len(indices), -1)
+    k = local_rows.shape[1] if local_rows.size else 0
+    if not dist.is_initialized():
+        out = np.full((num_items, k), np.nan)
+        out[np.asarray(indices, int)] = local_rows
+        return out
+    world = dist.get_world_size()
+    per = -(-num_items // world)                                    # pad every rank to the same length
+    buf = torch.full((per, k + 1), float("nan"), dtype=torch.float64, device=device)
+    if len(indices):
+        buf[:len(indices), 0] = torch.as_tensor(indices, dtype=torch.float64)
+        buf[:len(indices), 1:] = torch.as_tensor(local_rows)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    out = np.full((num_items, k), np.nan)
+    for g in gathered:
+        g = g.cpu().numpy()
+        ok = ~np.isnan(g[:, 0])
+        out[g[ok, 0].astype(int)] = g[ok, 1:]
+    return out

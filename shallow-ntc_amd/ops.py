@@ -18,6 +18,9 @@ ACTS = {None: capi.ACT_NONE, "none": capi.ACT_NONE, "relu": capi.ACT_RELU, "leak
 KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SIGNAL_DOWN, "sigup": capi.SIGNAL_UP}
 
 
+PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -78,6 +81,11 @@ class ConvPlan:
     def flops(self, n, h, w):
         return int(capi.load().sntc_conv_flops(self._h, n, h, w))
 
+    def launch_info(self, n, h, w):
+        v, nb = C.c_int(), C.c_int()
+        capi.call("sntc_conv_launch_info", self._h, n, h, w, C.byref(v), C.byref(nb))
+        return v.value, nb.value
+
     def __call__(self, x, res=None, aux=None, out=None):
         _check_nhwc(x, self.cin)
         n, h, w, _ = x.shape
@@ -86,7 +94,16 @@ class ConvPlan:
         for t in (res, aux):
             if t is not None and tuple(t.shape) != tuple(y.shape):
                 raise ValueError(f"epilogue operand shape {tuple(t.shape)} != output shape {tuple(y.shape)}")
+        prof = PROFILE
+        if prof is not None:     # bench.py: HIP events on the launch stream around this kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         capi.call("sntc_conv_forward", self._h, _ptr(x), n, h, w, _ptr(y), _ptr(res), _ptr(aux), _stream())
+        if prof is not None:
+            e1.record()
+            v, nb = self.launch_info(n, h, w)
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 32 == 0,
+                             kind=self.kind, k=self.k[0], s=self.stride, cin=self.cin, cout=self.cout, n=n, h=h, w=w))
         return y
 
 
