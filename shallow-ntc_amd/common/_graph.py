@@ -39,6 +39,11 @@ class Conv:
     def __call__(self, x, res=None, aux=None):
         return self.plan(x, res, aux)
 
+    def out_hw(self, h, w):
+        if self.kind in ("convT", "sigup"):
+            return h * self.s, w * self.s
+        return -(-h // self.s), -(-w // self.s)
+
     def flops(self, n, h, w):
         return self.plan.flops(n, h, w), self.plan.out_hw(h, w)
 
@@ -74,6 +79,9 @@ class GDN:
             return self.plan(x, res=x)
         return ops.gdn_small(x, self.beta, self.gamma, self.inverse, self.alpha, self.epsilon)
 
+    def out_hw(self, h, w):
+        return h, w
+
 
 class Seq:
     def __init__(self, layers):
@@ -98,6 +106,11 @@ class Seq:
         for l in self.layers:
             x = l(x)
         return x
+
+    def out_hw(self, h, w):
+        for l in self.layers:
+            h, w = l.out_hw(h, w)
+        return h, w
 
 
 class ResidualBlock:
@@ -125,6 +138,9 @@ class ResidualBlock:
     def __call__(self, x):
         a, b, c = self._convs
         return c(b(a(x)), res=x)
+
+    def out_hw(self, h, w):
+        return h, w
 
 
 class SimpleAttention:
@@ -159,3 +175,6 @@ class SimpleAttention:
         for l in self._branch:
             b = l(b)
         return self._gate(b, res=x, aux=t)
+
+    def out_hw(self, h, w):
+        return h, w

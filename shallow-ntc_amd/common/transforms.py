@@ -139,6 +139,10 @@ class Transform:
     def out_channels(self, input_channels=None):
         return self._graph.shapes(input_channels or self._cin)[1]
 
+    def out_hw(self, h, w):
+        """Output spatial size for an h x w input (shape inference only, nothing is launched)."""
+        return self._graph.out_hw(h, w)
+
 
 class BLS2017Analysis(Transform):
     """reference transforms.py:93-112."""
@@ -311,6 +315,9 @@ class _TwoLayerBase(Transform):
 
     def out_channels(self, input_channels=None):
         return self._out_ch
+
+    def out_hw(self, h, w):
+        return h * self._s[0] * self._s[1], w * self._s[0] * self._s[1]
 
     def build(self, input_channels=None, device=None):
         if input_channels is not None:

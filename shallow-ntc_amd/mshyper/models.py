@@ -125,10 +125,9 @@ class Model:
     def _compute_downsample_factor(self):
         for t in self._transforms().values():
             t.build(device=self.device)
-        with torch.cuda.device(self.device):
-            dummy = torch.zeros((1, DUMMY_IMG_DIM, DUMMY_IMG_DIM, 3), dtype=torch.float32, device=self.device)
-            z = self._hyper_analysis(self._analysis(dummy))
-        dim = z.shape[-2]
+        # the reference pushes a zero 64 x 64 image through analysis + hyper-analysis; the spatial size of
+        # the result is all it uses, so shape inference suffices
+        _, dim = self._hyper_analysis.out_hw(*self._analysis.out_hw(DUMMY_IMG_DIM, DUMMY_IMG_DIM))
         factor = int(DUMMY_IMG_DIM / dim)
         assert dim * factor == DUMMY_IMG_DIM, "Downsample factor should divide evenly into the dummy image size."
         return factor

@@ -1,0 +1,130 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sntc.h declares, the
+host logic (registry, configs, metrics, schedules) mirrors the reference, and the product path
+refuses to run without a GPU instead of falling back."""
+import json
+import math
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from shallow_ntc_amd import _capi
+    header = (ROOT / "include" / "sntc.h").read_text()
+    declared = set(re.findall(r"\b(sntc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = _capi.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in sntc.h but not exported by libsntc_hip.so"
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    assert lib.sntc_version() == 100
+    assert isinstance(_capi.last_error(), str)
+
+
+def test_every_entry_point_cites_the_reference():
+    header = (ROOT / "include" / "sntc.h").read_text()
+    for cite in ["common/transforms.py", "common/elic.py", "mshyper/models.py", "common/image_utils.py", "common/data_lib.py",
+                 "factorized/models.py"]:
+        assert cite in header
+
+
+def test_no_cpu_fallback_in_the_product():
+    """Nothing under shallow-ntc_amd/ may import the oracle; without a GPU the ops raise."""
+    import torch
+    for f in (ROOT / "shallow-ntc_amd").rglob("*.py"):
+        src = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+        assert "torch.nn.functional" not in src and "F.conv" not in src, f
+    if not torch.cuda.is_available():
+        from shallow_ntc_amd import _capi, ops
+        from shallow_ntc_amd.mshyper.models import Model
+        from shallow_ntc_amd.mshyper import configs
+        assert _capi.device_count() == 0
+        with pytest.raises(_capi.SntcError):
+            Model(**configs.two_layer_syn())
+        with pytest.raises(_capi.SntcError):
+            ops.ConvPlan("conv", torch.zeros((1, 1, 32, 32)), None, 1)
+        with pytest.raises(ValueError):
+            ops.pad_reflect(torch.zeros((1, 4, 4, 3)), 8, 8)
+
+
+def test_registry_matches_reference_names():
+    """reference common/transforms.py:383-391."""
+    from shallow_ntc_amd.common.transforms import class_builder
+    assert set(class_builder) == {
+        "BLS2017Analysis", "BLS2017Synthesis", "CNNAnalysis", "CNNSynthesis", "HyperAnalysis", "HyperSynthesis",
+        "MBT2018Analysis", "MBT2018Synthesis", "HyperAnalysisSmall", "HyperSynthesisSmall", "ElicAnalysis",
+        "ElicSynthesis", "JPEGLikeSynthesis", "TwoLayerSynthesis", "TwoLayerResSynthesis", "JPEGLikeHyperSynthesis"}
+    t = class_builder.build("ElicAnalysis", channels=(192, 192, 192, 320))
+    assert t.num_params(3) == 7337792 and t.out_channels(3) == 320 and t.out_hw(512, 768) == (32, 48)
+    assert class_builder.build("TwoLayerResSynthesis").num_params(320) == 1299003
+    assert class_builder.build("TwoLayerSynthesis", channels=(24, 3)).num_params(320) == 1300347
+    assert class_builder.build("JPEGLikeSynthesis", kernel_size=18, strides=16).num_params(320) == 311043
+    assert class_builder.build("HyperAnalysis", bottleneck_size=320).num_params(320) == 6042560
+    assert class_builder.build("HyperSynthesis", bottleneck_size=320).num_params(320) == 9166240
+    assert class_builder.build("CNNAnalysis", channels_base=192, output_channels=320, activation_type="gdn").num_params(3) == 3431552
+    with pytest.raises(ValueError):
+        class_builder.build("ElicAnalysis", channels=(1, 2))
+    with pytest.raises(KeyError):
+        class_builder.build("NoSuchTransform")
+
+
+def test_product_and_oracle_inventories_agree():
+    from oracle import transforms_np as T
+    from shallow_ntc_amd.common.transforms import class_builder
+    cases = [("ElicAnalysis", dict(channels=(192, 192, 192, 320)), 3), ("TwoLayerResSynthesis", {}, 320),
+             ("BLS2017Analysis", dict(num_filters=256), 3), ("BLS2017Synthesis", dict(num_filters=256), 256),
+             ("MBT2018Analysis", dict(channels_base=192, output_channels=320), 3),
+             ("MBT2018Synthesis", dict(channels_base=192, output_channels=3), 320),
+             ("CNNAnalysis", dict(channels_base=256, output_channels=320), 3),
+             ("HyperSynthesis", dict(bottleneck_size=320), 320), ("ElicSynthesis", dict(channels=(192, 160, 128, 3)), 320)]
+    for cls, kw, cin in cases:
+        a = class_builder.build(cls, **kw).param_shapes(cin)
+        okw = dict(kw)
+        if cin != 3 or cls.endswith("Synthesis"):
+            okw["cin"] = cin
+        b = T.build(cls, **okw).param_shapes()
+        assert {k: tuple(v) for k, v in a.items()} == {k: tuple(v) for k, v in b.items()}, cls
+
+
+def test_configs_mirror_reference_files():
+    from shallow_ntc_amd.mshyper import configs
+    c = configs.two_layer_syn()
+    assert c["transform_config"]["analysis"] == dict(cls="ElicAnalysis", channels=(192, 192, 192, 320))
+    assert c["transform_config"]["synthesis"]["kernel_sizes"] == (13, 5) and c["transform_config"]["synthesis"]["strides"] == (8, 2)
+    assert configs.jpegl()["transform_config"]["synthesis"] == dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16)
+    assert configs.itinf()["latent_config"]["uq"] == dict(method="sga", tau_r=5e-4, tau_ub=0.5, tau_t0=200)
+    assert sorted(configs.RD_LAMBDAS) == [0.00125, 0.0025, 0.005, 0.01, 0.02, 0.04, 0.08]
+    assert set(configs.CONFIGS) == {"two_layer_syn", "jpegl", "mbt2018", "two_layer_syn2", "bls2017"}
+
+
+def test_metrics_and_psnr_host_math():
+    from shallow_ntc_amd.common import image_utils
+    from shallow_ntc_amd.common.train_lib import Metrics
+    pub = json.loads((ROOT / "tests" / "golden" / "published_rows.json").read_text())
+    for r in pub["2-layer_syn"]:
+        mses, psnrs = image_utils.mse_psnr_from_sse(np.array([r["mse"] * 1000.0]), 1000)
+        assert abs(psnrs[0] - r["psnr"]) < 2e-4
+    m = Metrics.make()
+    m.record_scalars(dict(bpp=0.5, psnr=30.0))
+    m2 = Metrics.make()
+    m2.record_scalars(dict(bpp=1.5, psnr=32.0))
+    assert Metrics.merge_metrics([m, m2]).scalars == dict(bpp=1.0, psnr=31.0)
+    assert m.scalars_float == dict(bpp=0.5, psnr=30.0)
+
+
+def test_sga_schedule_and_data_helpers():
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.common.latent_rvs_utils import sga_schedule_at_step
+    assert sga_schedule_at_step(0, 5e-4, 0.5) == 0.5
+    assert abs(sga_schedule_at_step(2200, 5e-4, 0.5) - 0.5 * math.exp(-1)) < 1e-12
+    img = data_lib.synthetic_images(1, 16, 24, seed=3)
+    assert img.dtype == np.uint8 and img.shape == (1, 16, 24, 3)
+    np.testing.assert_array_equal(img, data_lib.synthetic_images(1, 16, 24, seed=3))
+    x = data_lib.normalize_image(img)
+    assert x.dtype == np.float32 and x.min() >= -0.5 and x.max() <= 0.5
+    np.testing.assert_array_equal(np.rint(data_lib.unnormalize_image(x)).astype(np.uint8), img)

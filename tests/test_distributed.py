@@ -1,0 +1,66 @@
+"""The N > 1 path on CPU: two gloo processes shard the images round-robin and all-gather the
+per-image (bpp, psnr, mse) rows -- the only exchange the path has."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, num_items, q):
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as graft
+    graft.load_package()
+    from shallow_ntc_amd import distributed as D
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = D.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    idx = D.shard_indices(num_items, rank, world)
+    rows = np.array([[i + 0.25, 30.0 + i, 100.0 - i] for i in idx], np.float64).reshape(len(idx), 3)
+    table = D.gather_rows(rows, idx, num_items)
+    t = D.max_over_ranks(1.0 + rank)
+    D.barrier()
+    q.put((rank, table, t, idx))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_rows():
+    world, num_items = 2, 7          # ragged: rank 0 holds 4 images, rank 1 holds 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, num_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.array([[i + 0.25, 30.0 + i, 100.0 - i] for i in range(num_items)])
+    seen = []
+    for rank, table, t, idx in outs:
+        np.testing.assert_array_equal(table, want)     # every rank ends with the full table, ordered by image id
+        assert t == 2.0                                # max over ranks
+        seen += idx
+    assert sorted(seen) == list(range(num_items))      # a partition: no image decoded twice or dropped
+
+
+def test_single_process_paths():
+    sys.path.insert(0, str(ROOT))
+    from shallow_ntc_amd import distributed as D
+    assert D.shard_indices(24, 3, 8) == [3, 11, 19]
+    assert D.shard_indices(0, 0, 2) == []
+    t = D.gather_rows(np.array([[1.0, 2.0]]), [1], 3)
+    assert np.isnan(t[0]).all() and (t[1] == [1.0, 2.0]).all()
+    assert D.max_over_ranks(3.5) == 3.5

@@ -1,0 +1,123 @@
+"""Two independent restatements (float64 NumPy tap loops vs float32 torch library convolutions with
+explicit pad / crop arithmetic) must agree, and the oracle must reproduce its committed fixtures."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import model_np
+from oracle import ops_np as O
+from oracle import torch_ref as R
+from oracle import transforms_np as T
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("k,s,h,w", [(5, 2, 12, 10), (5, 2, 11, 13), (3, 1, 7, 9), (1, 1, 5, 6), (9, 4, 16, 20), (9, 4, 15, 18)])
+def test_conv_down(k, s, h, w):
+    rng = np.random.default_rng(k * 100 + h)
+    x = rng.standard_normal((2, h, w, 6)).astype(np.float32)
+    wk = rng.standard_normal((k, k, 6, 8)).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    a = O.conv2d(x, wk, b, s)
+    assert a.shape == (2, -(-h // s), -(-w // s), 8)
+    assert rel(R.to_nhwc(R.conv2d(R.as_input(x), wk, b, s)), a) < 2e-6
+    a = O.signal_conv_down(x, wk, b, s)
+    assert rel(R.to_nhwc(R.signal_conv_down(R.as_input(x), wk, b, s)), a) < 2e-6
+
+
+@pytest.mark.parametrize("k,s,h,w", [(5, 2, 6, 5), (3, 1, 7, 4), (13, 8, 3, 4), (18, 16, 2, 3), (16, 16, 2, 2), (6, 4, 3, 3), (9, 4, 3, 3)])
+def test_conv_up(k, s, h, w):
+    rng = np.random.default_rng(k * 100 + s)
+    x = rng.standard_normal((2, h, w, 6)).astype(np.float32)
+    wk = rng.standard_normal((k, k, 8, 6)).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    a = O.conv2d_transpose(x, wk, b, s)
+    assert a.shape == (2, h * s, w * s, 8)
+    assert rel(R.to_nhwc(R.conv2d_transpose(R.as_input(x), wk, b, s)), a) < 2e-6
+    # conv-transpose is the adjoint of the SAME conv with the same kernel array
+    yy = rng.standard_normal(a.shape)
+    assert abs((O.conv2d_transpose(x, wk, None, s) * yy).sum() - (x * O.conv2d(yy, wk, None, s)).sum()) < 1e-8 * np.abs(yy).sum()
+    if k % 2:
+        wk2 = rng.standard_normal((k, k, 6, 8)).astype(np.float32)
+        a = O.signal_conv_up(x, wk2, b, s)
+        assert rel(R.to_nhwc(R.signal_conv_up(R.as_input(x), wk2, b, s)), a) < 2e-6
+
+
+def test_signal_conv_differs_from_keras_same_by_one_sample():
+    """stride-2 'same_zeros' is the Keras SAME result shifted by one input sample."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 12, 12, 2))
+    wk = rng.standard_normal((5, 5, 2, 3))
+    a, b = O.signal_conv_down(x, wk, None, 2), O.conv2d(x, wk, None, 2)
+    assert not np.allclose(a, b)
+    np.testing.assert_allclose(O.conv2d(x, wk, None, 2, pad=((2, 2), (2, 2))), a, atol=1e-12)
+
+
+TRANSFORMS = [
+    ("ElicAnalysis", dict(channels=(16, 16, 32, 32)), (1, 64, 64, 3)),
+    ("ElicSynthesis", dict(channels=(16, 16, 16, 3), cin=32), (1, 2, 2, 32)),
+    ("TwoLayerResSynthesis", dict(cin=32), (1, 3, 4, 32)),
+    ("TwoLayerSynthesis", dict(cin=32), (1, 2, 3, 32)),
+    ("JPEGLikeSynthesis", dict(kernel_size=18, strides=16, cin=32), (1, 2, 3, 32)),
+    ("HyperAnalysis", dict(bottleneck_size=32), (1, 8, 12, 32)),
+    ("HyperSynthesis", dict(bottleneck_size=32), (1, 2, 3, 32)),
+    ("BLS2017Analysis", dict(num_filters=16), (1, 32, 32, 3)),
+    ("BLS2017Synthesis", dict(num_filters=16), (1, 2, 2, 16)),
+    ("MBT2018Analysis", dict(channels_base=16, output_channels=24, gdn_alpha=2, gdn_epsilon=0.5), (1, 32, 32, 3)),
+    ("MBT2018Synthesis", dict(channels_base=16, cin=24), (1, 2, 2, 24)),
+    ("CNNAnalysis", dict(channels_base=16, output_channels=24, activation_type="gdn"), (1, 32, 32, 3)),
+    ("JPEGLikeHyperSynthesis", dict(bottleneck_size=16), (1, 2, 2, 16)),
+]
+
+
+@pytest.mark.parametrize("cls,kw,shape", TRANSFORMS, ids=[t[0] + str(i) for i, t in enumerate(TRANSFORMS)])
+def test_transforms_agree(cls, kw, shape):
+    rng = np.random.default_rng(len(cls))
+    t = T.build(cls, **kw)
+    p = T.init_params(t.param_shapes(), rng)
+    for k in p:
+        if k.endswith("bias"):
+            p[k] = (0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    x = rng.standard_normal(shape).astype(np.float32)
+    assert rel(R.to_nhwc(t(p, x, be=R)), t(p, x)) < 5e-6
+
+
+def test_oracle_reproduces_ops_fixture():
+    g = np.load(GOLD / "ops.npz")
+    fns = {"conv": O.conv2d, "convT": O.conv2d_transpose, "sigdown": O.signal_conv_down, "sigup": O.signal_conv_up}
+    tags = sorted({k.split("/")[0] for k in g.files if k.endswith("/meta")})
+    assert len(tags) == 9
+    for tag in tags:
+        k, s, cin, cout = g[f"{tag}/meta"]
+        y = fns[tag.split("_")[0]](g[f"{tag}/x"], g[f"{tag}/w"], g[f"{tag}/b"], int(s))
+        np.testing.assert_allclose(y, g[f"{tag}/y"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(O.gdn(g["gdn/x"], g["gdn/beta"], g["gdn/gamma"], True), g["gdn/igdn1"], atol=1e-13)
+    np.testing.assert_allclose(O.gdn(g["gdn/x"], g["gdn/beta"], g["gdn/gamma"], False, 2, 0.5), g["gdn/classic"], atol=1e-13)
+    c = g["normal/y"].shape[-1]
+    mu, raw = g["normal/hyper"][..., :c], g["normal/hyper"][..., c:]
+    y_hat, bits, sym = O.scale_indexed_normal(g["normal/y"], mu, np.exp(raw.astype(np.float64)))
+    np.testing.assert_array_equal(sym.astype(np.int32), g["normal/symbols"])
+    np.testing.assert_allclose(bits, g["normal/bits"], rtol=1e-12)
+    np.testing.assert_array_equal(O.floats_to_pixels(g["pix/x_hat"], False), g["pix/pixels"])
+    np.testing.assert_array_equal(O.pad_images(g["pix/x"], 16).astype(np.float32), g["pix/padded16"])
+
+
+def test_oracle_reproduces_model_fixture():
+    import json
+    g = np.load(GOLD / "model_two_layer_small.npz")
+    tc = json.loads(str(g["config"]))
+    m = model_np.Model(tc, rd_lambda=float(g["rd_lambda"]))
+    p = {k[2:]: g[k] for k in g.files if k.startswith("w/")}
+    assert set(p) == set(m.param_shapes())
+    r = m.end_to_end(p, g["x"])
+    assert abs(r["bpp"] - float(g["bpp"])) < 1e-12 and abs(r["psnr"] - float(g["psnr"])) < 1e-10
+    np.testing.assert_array_equal(r["recon_pixels"], g["recon_pixels"])
+    assert abs(r["rd_loss"] - (r["bpp"] + 0.02 * r["mse"])) < 1e-12
+    # evaluate(): per-image generator (mshyper/models.py:415-433)
+    outs = list(m.evaluate(p, np.concatenate([g["x"], g["x"]])))
+    assert len(outs) == 2 and abs(outs[1]["bpp"] - float(g["bpp"])) < 1e-12
