@@ -82,7 +82,7 @@ def ops_fixture():
     d["pix/pixels"] = O.floats_to_pixels(xh, False)
     mses, psnrs = O.mse_psnr(O.floats_to_pixels(x, False), O.floats_to_pixels(xh, False))
     d["pix/mse"], d["pix/psnr"] = mses, psnrs
-    d["pix/padded16"] = O.pad_images(x, 16).astype(np.float32)
+    d["pix/padded8"] = O.pad_images(x, 8).astype(np.float32)
     np.savez_compressed(OUT / "ops.npz", **d)
 
 

@@ -104,7 +104,7 @@ def test_oracle_reproduces_ops_fixture():
     np.testing.assert_array_equal(sym.astype(np.int32), g["normal/symbols"])
     np.testing.assert_allclose(bits, g["normal/bits"], rtol=1e-12)
     np.testing.assert_array_equal(O.floats_to_pixels(g["pix/x_hat"], False), g["pix/pixels"])
-    np.testing.assert_array_equal(O.pad_images(g["pix/x"], 16).astype(np.float32), g["pix/padded16"])
+    np.testing.assert_array_equal(O.pad_images(g["pix/x"], 8).astype(np.float32), g["pix/padded8"])
 
 
 def test_oracle_reproduces_model_fixture():
