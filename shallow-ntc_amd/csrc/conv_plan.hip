@@ -131,6 +131,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     G.T = (int)hg.taps.size();
     G.Ncol = (int)hg.cols.size();
     G.K = ((G.T * d.cin + 31) / 32) * 32;
+    if ((int64_t)G.Ncol * G.K * 4 >= (1LL << 31)) return fail(SNTC_ERR_UNSUPPORTED, "packed weights of one phase group must be < 2 GiB");
     SNTC_HIP(hipMalloc(&G.taps, sizeof(int) * std::max(1, G.T)));
     SNTC_HIP(hipMalloc(&G.cols, sizeof(unsigned) * G.Ncol));
     SNTC_HIP(hipMalloc(&G.wp, sizeof(float) * (size_t)G.Ncol * std::max(32, G.K)));
@@ -290,12 +291,14 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   int rc = geometry(p, h, w, &g);
   if (rc) return rc;
   const int64_t M = (int64_t)n * g.Qh * g.Qw;
-  if (M > 0x7fffffffLL || (int64_t)n * h * w * d.cin > (1LL << 40))
-    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: tensor too large");
+  const int64_t x_bytes = (int64_t)n * h * w * d.cin * 4;
+  if (M > 0x7fffffffLL || x_bytes >= (1LL << 31))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: input tensor must be < 2 GiB (32-bit buffer offsets); split the batch");
   const int v = pick_variant(p, M);
   const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
   GGArgs a{};
   a.x = x; a.y = y; a.bias = p->bias; a.res = res; a.aux = aux;
+  a.x_bytes = (unsigned)x_bytes;
   a.N = n; a.H = h; a.W = w; a.Cin = d.cin;
   a.Qh = g.Qh; a.Qw = g.Qw; a.M = (int)M;
   a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = d.cout;

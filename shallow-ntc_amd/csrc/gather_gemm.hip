@@ -6,12 +6,16 @@
 // with pixels on the MFMA row (A) side and output columns on the column (B) side.
 //
 // Block: 256 threads = 4 waves arranged WM x WN; each wave owns TM x TN tiles of 32x32; BK = 32.
-//   global -> registers (16 B per lane, each tile row is one full 128-B line of the NHWC input /
-//   K-contiguous packed weight) -> LDS (128-B rows, 16-B chunks XOR-swizzled by (row>>1)&7 so the
-//   ds_read_b128 fragment reads are bank-conflict free) -> MFMA.  Two LDS buffers, one barrier
-//   per K step; the next step's global loads are issued before the MFMAs of the current one.
-//   Per lane a ds_read_b128 fetches k = 8g+4h..8g+4h+3 (h = lane>>5): MFMA j of k-group g sums
-//   k in {8g+j, 8g+4+j}; A and B use the same permutation, so the products pair up.
+//   HBM/L2 -> registers: buffer_load_dwordx4 through two wave-uniform descriptors (input, packed
+//   weights) with a 32-bit per-lane byte offset that changes only when the tap changes and a scalar
+//   offset that walks the channel slabs / K steps; a tile row is one full 128-B line; rows whose source
+//   pixel falls outside the image carry an out-of-range offset and read zeros from the bounds check
+//   (no branches, no 64-bit address arithmetic in the loop).
+//   registers -> LDS: 128-B rows, 16-B chunks XOR-swizzled by (row>>1)&7 so both the staging
+//   ds_write_b128 and the fragment ds_read_b128 are bank-conflict free without padding.
+//   Two LDS buffers, one barrier per K step; the next step's loads are issued before the MFMAs of
+//   the current one.  Per lane a ds_read_b128 fetches k = 8g+4h..8g+4h+3 (h = lane>>5): MFMA j of
+//   k-group g sums k in {8g+j, 8g+4+j}; A and B use the same permutation, so the products pair up.
 //   C/D layout: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
 #include "sntc_internal.h"
 
@@ -19,6 +23,9 @@ namespace sntc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kOutOfRange = 0x80000000u;   // > any in-range offset: buffers are < 2 GiB (host check)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -29,7 +36,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool VEC>
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO>
 __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -75,28 +87,30 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   const int c = tid & 7;     // 16-B chunk inside the 128-B K slab
   const int r0 = tid >> 3;   // row 0..31 (+32 i)
   int a_iy0[A_CH], a_ix0[A_CH];
-  const float* a_base[A_CH];
-  bool a_ok[A_CH];
+  unsigned a_img[A_CH];      // byte offset of the row's image (+ chunk), or kOutOfRange for padding rows
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int4 ri = rinfo[r0 + 32 * i];
-    a_ok[i] = ri.w != 0;
     a_iy0[i] = ri.y * a.sA + a.offy;
     a_ix0[i] = ri.z * a.sA + a.offx;
-    a_base[i] = a.x + (size_t)ri.x * a.H * a.W * a.Cin;
+    a_img[i] = ri.w ? (unsigned)ri.x * (unsigned)(a.H * a.W) * (unsigned)a.Cin * 4u + (unsigned)c * 16u : kOutOfRange;
   }
-  const float* b_ptr[B_CH];
+  unsigned b_off[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {   // rows past Ncol re-read the last column (finite, discarded)
     const int brow = min(n0 + r0 + 32 * i, G.Ncol - 1);
-    b_ptr[i] = G.wp + (size_t)brow * G.K + c * 4;
+    b_off[i] = (unsigned)brow * (unsigned)G.K * 4u + (unsigned)c * 16u;
   }
+  const __amdgpu_buffer_rsrc_t xs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ws =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 4, 0x00020000);
 
   const int nsteps = G.K >> 5;
   const int ncc = VEC ? (a.Cin >> 5) : 1;
   const int ktrue = G.T * a.Cin;
   int ld_t = 0, ld_cc = 0, ld_step = 0;
-  const float* a_ptr[A_CH];
+  unsigned a_off[A_CH];
 
   auto set_tap = [&](int t) {
     const int tap = G.taps[t];
@@ -105,8 +119,9 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
     for (int i = 0; i < A_CH; ++i) {
       const int iy = a_iy0[i] + ty * a.tstep;
       const int ix = a_ix0[i] + tx * a.tstep;
-      const bool ok = a_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      a_ptr[i] = ok ? a_base[i] + ((size_t)iy * a.W + ix) * a.Cin + c * 4 : nullptr;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a_img[i] & kOutOfRange);
+      const unsigned pix = (unsigned)(iy * a.W + ix) * (unsigned)a.Cin * 4u;
+      a_off[i] = ok ? a_img[i] + pix : kOutOfRange;
     }
   };
   if (VEC && G.T > 0) set_tap(0);
@@ -114,12 +129,9 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   f32x4 ra[A_CH], rb[B_CH];
   auto load_regs = [&]() {
     if (VEC) {
+      const unsigned soff = (unsigned)ld_cc * 128u;
 #pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (a_ptr[i]) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ld_cc * 32);
-        ra[i] = v;
-      }
+      for (int i = 0; i < A_CH; ++i) ra[i] = buf_load(xs, a_off[i], soff);
     } else {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
@@ -127,21 +139,22 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int k = ld_step * 32 + c * 4 + e;
-          if (k < ktrue && a_ok[i]) {
+          if (k < ktrue && !(a_img[i] & kOutOfRange)) {
             const int t = k / a.Cin;
             const int ch = k - t * a.Cin;
             const int tap = G.taps[t];
             const int iy = a_iy0[i] + (tap >> 16) * a.tstep;
             const int ix = a_ix0[i] + (tap & 0xffff) * a.tstep;
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-              v[e] = a_base[i][((size_t)iy * a.W + ix) * a.Cin + ch];
+              v[e] = a.x[(size_t)(a_img[i] >> 2) - c * 4 + ((size_t)iy * a.W + ix) * a.Cin + ch];
           }
         }
         ra[i] = v;
       }
     }
+    const unsigned wsoff = (unsigned)ld_step * 128u;
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + ld_step * 32);
+    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load(ws, b_off[i], wsoff);
     ++ld_step;
     if (VEC) {
       if (++ld_cc == ncc) {
@@ -157,10 +170,12 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
     for (int i = 0; i < A_CH; ++i) {
       const int r = r0 + 32 * i;
       f32x4 v = ra[i];
-      if (a.pro == SNTC_PRO_ABS) {
-        v[0] = fabsf(v[0]); v[1] = fabsf(v[1]); v[2] = fabsf(v[2]); v[3] = fabsf(v[3]);
-      } else if (a.pro == SNTC_PRO_SQUARE) {
-        v = v * v;
+      if (PRO) {
+        if (a.pro == SNTC_PRO_ABS) {
+          v[0] = fabsf(v[0]); v[1] = fabsf(v[1]); v[2] = fabsf(v[2]); v[3] = fabsf(v[3]);
+        } else if (a.pro == SNTC_PRO_SQUARE) {
+          v = v * v;
+        }
       }
       *reinterpret_cast<f32x4*>(Ab + r * 32 + ((c ^ ((r >> 1) & 7)) << 2)) = v;
     }
@@ -262,11 +277,13 @@ static size_t lds_bytes(int v) {
 }
 
 template <int TM, int TN, int WM, int WN>
-static int launch_t(bool vec, const GGArgs& args, int nblocks, size_t lds, hipStream_t stream) {
-  if (vec)
-    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, true>), dim3(nblocks), dim3(256), lds, stream, args);
+static int launch_t(bool vec, bool pro, const GGArgs& args, int nblocks, size_t lds, hipStream_t stream) {
+  if (vec && !pro)
+    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, true, false>), dim3(nblocks), dim3(256), lds, stream, args);
+  else if (vec)
+    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, true, true>), dim3(nblocks), dim3(256), lds, stream, args);
   else
-    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, false>), dim3(nblocks), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, false, true>), dim3(nblocks), dim3(256), lds, stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
   return SNTC_OK;
@@ -274,10 +291,13 @@ static int launch_t(bool vec, const GGArgs& args, int nblocks, size_t lds, hipSt
 
 template <int TM, int TN, int WM, int WN>
 static hipError_t set_attr(size_t lds) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false>),
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -300,15 +320,16 @@ int gg_init() {
 
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {
   const size_t lds = lds_bytes(variant);
+  const bool pro = args.pro != SNTC_PRO_NONE;
   switch (variant) {
-    case 1: return launch_t<1, 1, 4, 1>(vec, args, nblocks, lds, stream);
-    case 2: return launch_t<1, 2, 4, 1>(vec, args, nblocks, lds, stream);
-    case 3: return launch_t<1, 3, 4, 1>(vec, args, nblocks, lds, stream);
-    case 4: return launch_t<1, 4, 4, 1>(vec, args, nblocks, lds, stream);
-    case 5: return launch_t<1, 5, 4, 1>(vec, args, nblocks, lds, stream);
-    case 6: return launch_t<1, 6, 4, 1>(vec, args, nblocks, lds, stream);
-    case 7: return launch_t<1, 7, 4, 1>(vec, args, nblocks, lds, stream);
-    case 8: return launch_t<1, 1, 2, 2>(vec, args, nblocks, lds, stream);
+    case 1: return launch_t<1, 1, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 2: return launch_t<1, 2, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 3: return launch_t<1, 3, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 4: return launch_t<1, 4, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 5: return launch_t<1, 5, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 6: return launch_t<1, 6, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 7: return launch_t<1, 7, 4, 1>(vec, pro, args, nblocks, lds, stream);
+    case 8: return launch_t<1, 1, 2, 2>(vec, pro, args, nblocks, lds, stream);
     default: return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
   }
 }

@@ -44,6 +44,7 @@ struct GGArgs {
   const float* bias;   // [Cout] or nullptr
   const float* res;    // epilogue operand (output shape) or nullptr
   const float* aux;    // second epilogue operand or nullptr
+  unsigned x_bytes;    // size of x (< 2 GiB: 32-bit buffer offsets)
   int N, H, W, Cin;
   int Qh, Qw, M;
   int Ho, Wo, Cout;

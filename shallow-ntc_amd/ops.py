@@ -18,6 +18,7 @@ ACTS = {None: capi.ACT_NONE, "none": capi.ACT_NONE, "relu": capi.ACT_RELU, "leak
 KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SIGNAL_DOWN, "sigup": capi.SIGNAL_UP}
 
 
+MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
 
 
@@ -94,6 +95,16 @@ class ConvPlan:
         for t in (res, aux):
             if t is not None and tuple(t.shape) != tuple(y.shape):
                 raise ValueError(f"epilogue operand shape {tuple(t.shape)} != output shape {tuple(y.shape)}")
+        if x.numel() * 4 >= MAX_INPUT_BYTES and n > 1:
+            # the kernel addresses its input with 32-bit buffer offsets: split the batch (images are independent)
+            half = n // 2
+            r0 = None if res is None else res[:half]
+            r1 = None if res is None else res[half:]
+            a0 = None if aux is None else aux[:half]
+            a1 = None if aux is None else aux[half:]
+            self.__call__(x[:half], r0, a0, out=y[:half])
+            self.__call__(x[half:], r1, a1, out=y[half:])
+            return y
         prof = PROFILE
         if prof is not None:     # bench.py: HIP events on the launch stream around this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
