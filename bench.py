@@ -154,8 +154,8 @@ def main():
             decode_step()
             torch.cuda.synchronize()
             for e in ops.PROFILE:
-                name = f"gg_kernel<1,{e['variant']},4,1,{'vec' if e['vec'] else 'scalar'}>" if e["variant"] != 8 \
-                    else f"gg_kernel<1,1,2,2,{'vec' if e['vec'] else 'scalar'}>"
+                vec = "true,false" if e["vec"] else "false,true"      # <TM,TN,WM,WN,VEC,PRO> as rocprof prints it
+                name = f"gg_kernel<1, {e['variant']}, 4, 1, {vec}>" if e["variant"] != 8 else f"gg_kernel<1, 1, 2, 2, {vec}>"
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
                 k["flops"] += e["flops"]

@@ -230,6 +230,73 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   }
 
   // ---------------- epilogue ----------------
+  // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private 8-KB LDS
+  // slice (the staging buffers are dead after the last barrier) so that every lane owns 4
+  // consecutive channels of one pixel: bias / residual / gate operands are read and the output is
+  // written with 16-B accesses, 256 contiguous bytes per 16 lanes.
+  if ((a.Cout & 3) == 0) {
+    static_assert(TM == 1, "wide epilogue assumes one M tile per wave");
+    float* stage = reinterpret_cast<float*>(smem) + wave * 2048;   // 32 rows x 64 floats
+#pragma unroll
+    for (int j0 = 0; j0 < TN; j0 += 2) {
+      const int ct = (TN - j0) >= 2 ? 2 : 1;          // tiles in this chunk
+      const int wfl = ct * 32;                         // chunk width in floats
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if (jj < ct) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * h) * wfl + jj * 32 + l31] = acc[0][j0 + jj][r];
+        }
+      }
+      const int lanes_per_row = wfl >> 2;              // 16 or 8
+      const int rows_per_pass = 64 / lanes_per_row;    // 4 or 8
+      const int c4 = (lane % lanes_per_row) << 2;
+      const int rsub = lane / lanes_per_row;
+      const int col = n0 + (wn * TN + j0) * 32 + c4;
+      const bool col_ok = col < G.Ncol;
+      unsigned ce = 0;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (col_ok) {
+        ce = G.cols[col];
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (ce & 0xffff));
+      }
+      const int ch = ce & 0xffff;
+      const int oyo = (int)((ce >> 24) & 0xff) - 128;
+      const int oxo = (int)((ce >> 16) & 0xff) - 128;
+      for (int rp = 0; rp < 32; rp += rows_per_pass) {
+        const int rloc = rp + rsub;
+        const int4 ri = rinfo[wm * 32 + rloc];
+        const int oy = ri.y * a.sO + oyo;
+        const int ox = ri.z * a.sO + oxo;
+        if (!col_ok || !ri.w || (unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
+        const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * wfl + c4) + bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+        if (a.epi != SNTC_EPI_STORE) {
+          const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + idx);
+          switch (a.epi) {
+            case SNTC_EPI_ADD: v = v + rs; break;
+            case SNTC_EPI_GATE: v = rs + *reinterpret_cast<const f32x4*>(a.aux + idx) * v; break;
+            case SNTC_EPI_RES_DIV: v = rs / v; break;
+            case SNTC_EPI_RES_MUL: v = rs * v; break;
+            case SNTC_EPI_RES_DIV_SQRT:
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rs[e] / sqrtf(v[e]);
+              break;
+            case SNTC_EPI_RES_MUL_SQRT:
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rs[e] * sqrtf(v[e]);
+              break;
+            default: break;
+          }
+        }
+        *reinterpret_cast<f32x4*>(a.y + idx) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + l31;
