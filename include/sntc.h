@@ -70,7 +70,9 @@ enum {                       /* epilogue, v = act(conv + bias) */
   SNTC_EPI_RES_DIV = 3,      /* y = res / v                (GDN1 forward, transforms.py:63)     */
   SNTC_EPI_RES_MUL = 4,      /* y = res * v                (GDN1 inverse, transforms.py:61)     */
   SNTC_EPI_RES_DIV_SQRT = 5, /* y = res / sqrt(v)          (classic tfc.GDN)                    */
-  SNTC_EPI_RES_MUL_SQRT = 6  /* y = res * sqrt(v)          (classic inverse tfc.GDN)            */
+  SNTC_EPI_RES_MUL_SQRT = 6, /* y = res * sqrt(v)          (classic inverse tfc.GDN)            */
+  SNTC_EPI_MASK_RELU = 7,    /* y = res > 0 ? v : 0        (relu backward; res = forward output) */
+  SNTC_EPI_MASK_LEAKY = 8    /* y = res >= 0 ? v : 0.2 v   (leaky-relu backward)                 */
 };
 
 typedef struct sntc_conv_desc {
@@ -177,6 +179,45 @@ int sntc_entropy_scale_normal(const float* y, const float* hyper, int n, int64_t
 /* Decoder-side dequantisation: y_hat = symbols + mu  (mu = hyper[..., :C]). */
 int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n, int64_t hw, int c,
                               float* y_hat, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SGA iterative inference (config 5): element-wise pieces of Model.itinf_train_step,
+ *   mshyper/models.py:397-408 with frame_loss_given_latent_rvs(training=True), :260-268,285-291,343.
+ *   The contractions of the backward pass are sntc_conv_forward calls: the input gradient of
+ *   Conv2DTranspose(k, s, SAME) with kernel W[kh,kw,Cout,Cin] is SNTC_CONV2D with the same array
+ *   read as [kh,kw,Cin'=Cout,Cout'=Cin]; relu / leaky-relu masks ride on SNTC_EPI_MASK_*.
+ * sga_round (common/latent_rvs_utils.py:8-48): logits = (-atanh(clip(u - floor u))/tau,
+ *   -atanh(clip(ceil u - u))/tau), w = softmax((logits + Gumbel)/tau), sample = w0 floor + w1 ceil.
+ *   noise: NULL -> counter-based generator keyed by (seed, step, element); else float [.., 2]
+ *   Gumbel values (deterministic tests).
+ * ------------------------------------------------------------------------------------------ */
+/* z~ = sga_round(z_loc, tau); bits[n] = -sum log2 p_DF(z~); sprime = d z~/d z_loc;
+ * dbits_dz = d(-log2 p)/d z~ per element. */
+int sntc_sga_factorized_fwd(const sntc_prior* prior, const float* z_loc, int n, int64_t hw, float tau,
+                            const float* noise, uint64_t seed, uint64_t step, float* z_tilde, float* sprime,
+                            float* dbits_dz, double* bits, void* stream);
+/* y~ = sga_round(y_loc - mu, tau) + mu with (mu, raw) = hyper halves; bits[n] = -sum log2 p_N(y~ - mu; sigma);
+ * sprime = d sga/d u; dbits_dv = d bits/d (y~ - mu); dbits_draw = d bits/d raw (through exp, clamp, SCALE_FN). */
+int sntc_sga_normal_fwd(const float* y_loc, const float* hyper, int n, int64_t hw, int c, float tau,
+                        const float* noise, uint64_t seed, uint64_t step, float* y_tilde, float* sprime,
+                        float* dbits_dv, float* dbits_draw, double* bits, void* stream);
+/* g_yloc = (g_ytilde + weight dbits_dv) sprime;  g_hyper = [g_ytilde (1 - sprime) - weight dbits_dv sprime | weight dbits_draw] */
+int sntc_sga_normal_bwd(const float* g_ytilde, const float* sprime, const float* dbits_dv, const float* dbits_draw,
+                        float weight, int64_t npix, int c, float* g_yloc, float* g_hyper, void* stream);
+/* out = (g + weight dbits) sprime */
+int sntc_sga_chain(const float* g, const float* dbits, const float* sprime, float weight, int64_t total, float* out,
+                   void* stream);
+/* Training-mode distortion (common/data_lib.py:48-52, no rounding): sse[n] = sum (255 (x - x_hat))^2 over the
+ * un-padded h x w region; g_xhat[n,hs,ws,c] = scale (x_hat - x), zero in the padded margin. */
+int sntc_distortion_grad(const float* x, const float* x_hat, int n, int h, int w, int c, int hs, int ws, float scale,
+                         float* g_xhat, double* sse, void* stream);
+/* Backward of the activation + residual split of sntc_two_layer_tail: t is the forward input, g_h the gradient
+ * w.r.t. h; g_t[npix, cp] = [d act(base) | g_h (if has_res) | zeros up to cp]. */
+int sntc_two_layer_tail_bwd(const float* t, const float* g_h, int64_t npix, int ch, int has_res, int act_kind,
+                            const float* beta, const float* gamma, int cp, float* g_t, void* stream);
+/* Keras Adam (tf.keras.optimizers.Adam, no amsgrad) on one flat tensor; t = 1-based step. */
+int sntc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int64_t t, void* stream);
 
 #ifdef __cplusplus
 }

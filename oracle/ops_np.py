@@ -203,11 +203,12 @@ def normalize_image(img):
 
 
 def floats_to_pixels(x, training):
-    """data_lib.py:48-52 + image_utils.py:22-23: (x+.5)*255, eval: tf.round (half-to-even) then
-    saturate_cast uint8.  Evaluated in float32 like the reference so ties land identically."""
-    x = (np.asarray(x, np.float32) + np.float32(0.5)) * np.float32(255.0)
+    """data_lib.py:48-52 + image_utils.py:22-23: (x+.5)*255; eval: tf.round (half-to-even) then
+    saturate_cast uint8, evaluated in float32 like the reference so ties land identically.
+    training: no rounding; kept in float64 so finite differences of the loss are clean."""
     if training:
-        return x.astype(F64)
+        return (np.asarray(x, F64) + 0.5) * 255.0
+    x = (np.asarray(x, np.float32) + np.float32(0.5)) * np.float32(255.0)
     return np.clip(np.rint(x), 0, 255).astype(np.uint8)
 
 

@@ -17,7 +17,7 @@ OK, ERR_BAD_SHAPE, ERR_UNSUPPORTED, ERR_HIP, ERR_NONFINITE, ERR_NO_DEVICE = rang
 CONV2D, CONV2D_TRANSPOSE, SIGNAL_DOWN, SIGNAL_UP = range(4)
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID = range(4)
 PRO_NONE, PRO_ABS, PRO_SQUARE = range(3)
-EPI_STORE, EPI_ADD, EPI_GATE, EPI_RES_DIV, EPI_RES_MUL, EPI_RES_DIV_SQRT, EPI_RES_MUL_SQRT = range(7)
+EPI_STORE, EPI_ADD, EPI_GATE, EPI_RES_DIV, EPI_RES_MUL, EPI_RES_DIV_SQRT, EPI_RES_MUL_SQRT, EPI_MASK_RELU, EPI_MASK_LEAKY = range(9)
 
 
 class SntcError(RuntimeError):
@@ -63,6 +63,14 @@ SIGNATURES = {
     "sntc_entropy_factorized": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P]),
     "sntc_entropy_scale_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, C.c_int, _P]),
     "sntc_dequant_scale_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "sntc_sga_factorized_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_float, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
+    "sntc_sga_normal_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, _P, C.c_uint64, C.c_uint64, _P, _P, _P,
+                                      _P, _P, _P]),
+    "sntc_sga_normal_bwd": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, C.c_int, _P, _P, _P]),
+    "sntc_sga_chain": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, _P, _P]),
+    "sntc_distortion_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
+    "sntc_two_layer_tail_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    "sntc_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _P]),
 }
 
 _lib = None

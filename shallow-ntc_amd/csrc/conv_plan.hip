@@ -163,7 +163,7 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
       d.cout > 65535)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_create: bad kernel / stride / channel sizes");
   if (d.act < SNTC_ACT_NONE || d.act > SNTC_ACT_SIGMOID || d.prologue < 0 || d.prologue > SNTC_PRO_SQUARE ||
-      d.epilogue < 0 || d.epilogue > SNTC_EPI_RES_MUL_SQRT)
+      d.epilogue < 0 || d.epilogue > SNTC_EPI_MASK_LEAKY)
     return fail(SNTC_ERR_UNSUPPORTED, "unknown activation / prologue / epilogue");
   int rc = gg_init();
   if (rc) return rc;

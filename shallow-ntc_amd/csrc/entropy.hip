@@ -121,16 +121,6 @@ __global__ void __launch_bounds__(256) dequant_kernel(const int32_t* __restrict_
 }
 
 // ----------------------------- deep factorized -----------------------------
-constexpr int kMaxW = 4;   // max hidden width
-constexpr int kMaxL = 5;   // max affine layers
-
-struct DFDesc {
-  int nl;
-  int w[kMaxL + 1];
-  int off_m[kMaxL], off_b[kMaxL], off_f[kMaxL];
-  int stride;   // floats per channel record
-};
-
 // record holds softplus(matrix), bias, tanh(factor) for one channel
 __device__ __forceinline__ float df_logits(const float* __restrict__ rec, const DFDesc& d, float x) {
   float hcur[kMaxW] = {x, 0.f, 0.f, 0.f};
@@ -184,12 +174,6 @@ __global__ void __launch_bounds__(256) factorized_kernel(const float* __restrict
 }  // namespace sntc
 
 using namespace sntc;
-
-struct sntc_prior {
-  int channels = 0;
-  DFDesc d{};
-  float* rec = nullptr;
-};
 
 extern "C" void sntc_prior_destroy(sntc_prior* p) {
   if (!p) return;

@@ -289,6 +289,14 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = rs[e] * sqrtf(v[e]);
               break;
+            case SNTC_EPI_MASK_RELU:
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rs[e] > 0.0f ? v[e] : 0.0f;
+              break;
+            case SNTC_EPI_MASK_LEAKY:
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rs[e] >= 0.0f ? v[e] : 0.2f * v[e];
+              break;
             default: break;
           }
         }
@@ -325,6 +333,8 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
           case SNTC_EPI_RES_MUL: v = a.res[idx] * v; break;
           case SNTC_EPI_RES_DIV_SQRT: v = a.res[idx] / sqrtf(v); break;
           case SNTC_EPI_RES_MUL_SQRT: v = a.res[idx] * sqrtf(v); break;
+          case SNTC_EPI_MASK_RELU: v = a.res[idx] > 0.0f ? v : 0.0f; break;
+          case SNTC_EPI_MASK_LEAKY: v = a.res[idx] >= 0.0f ? v : 0.2f * v; break;
           default: break;
         }
         a.y[idx] = v;

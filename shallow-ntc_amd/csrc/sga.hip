@@ -1,0 +1,426 @@
+// sga.hip -- element-wise kernels of SGA iterative inference:
+//   stochastic Gumbel annealing sample + its derivative, rate terms and their gradients for both
+//   entropy models, distortion gradient, two-layer-tail backward, fused Adam on the latents.
+// The contractions of the backward pass (input gradients of the transposed convolutions) reuse the
+// gather-GEMM: the adjoint of Conv2DTranspose(k, s, SAME) with kernel W[kh,kw,Cout,Cin] is
+// Conv2D(k, s, SAME) with the same array read as HWIO.
+//
+// Reference: common/latent_rvs_utils.py:8-48 (sga_round), mshyper/models.py:260-268,285-291,343,
+// 397-408 (loss terms and the variables that receive gradients), common/data_lib.py:48-52.
+#include <cmath>
+#include "sntc_internal.h"
+
+namespace sntc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLogScaleMin = -2.2072749131897207f;
+constexpr float kScaleFactor = 0.12305479932808384f;
+constexpr float kInvLn2 = 1.4426950408889634f;
+constexpr float kSgaEps = 1e-5f;           // latent_rvs_utils.py:9 epsilon
+
+// ---- counter-based uniform -> Gumbel (statistical parity with tfp's RelaxedOneHotCategorical) ----
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float gumbel_from(unsigned long long seed, unsigned long long step, unsigned long long idx, int k) {
+  const unsigned long long r = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + 2 * idx + k);
+  const float u = ((float)(r >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+  return -logf(-logf(u));
+}
+
+// out = w0 floor(mu) + w1 ceil(mu), w = softmax((logits + g) / tau); also d out / d mu.
+__device__ __forceinline__ void sga_sample(float mu, float tau, float g0, float g1, float* out, float* dout) {
+  const float fl = floorf(mu), ce = ceilf(mu);
+  const float a = fminf(fmaxf(mu - fl, -1.0f + kSgaEps), 1.0f - kSgaEps);
+  const float b = fminf(fmaxf(ce - mu, -1.0f + kSgaEps), 1.0f - kSgaEps);
+  const float l0 = -atanhf(a) / tau, l1 = -atanhf(b) / tau;
+  const float d = ((l1 + g1) - (l0 + g0)) / tau;
+  const float w1 = 1.0f / (1.0f + expf(-d));
+  *out = (1.0f - w1) * fl + w1 * ce;
+  // d l0 / d mu = -1/(tau (1-a^2)) unless clipped; d l1 / d mu = +1/(tau (1-b^2)) unless clipped
+  const bool a_free = (mu - fl) < 1.0f - kSgaEps, b_free = (ce - mu) < 1.0f - kSgaEps;
+  const float dl0 = a_free ? -1.0f / (tau * (1.0f - a * a)) : 0.0f;
+  const float dl1 = b_free ? 1.0f / (tau * (1.0f - b * b)) : 0.0f;
+  *dout = (ce - fl) * w1 * (1.0f - w1) * (dl1 - dl0) / tau;
+}
+
+__device__ __forceinline__ float log_ndtr_f(float x) {
+  const float t = x * 0.70710678118654752f;
+  if (x > 0.0f) return log1pf(-0.5f * erfcf(t));
+  if (x > -10.0f) return logf(0.5f * erfcf(-t));
+  const float x2 = x * x, ix2 = 1.0f / x2;
+  return -0.5f * x2 - logf(-x) - 0.91893853320467274f + logf(1.0f - ix2 * (1.0f - 3.0f * ix2 * (1.0f - 5.0f * ix2)));
+}
+
+__device__ __forceinline__ void block_sum_to(double v, double* dst) {
+  __shared__ double part[8];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
+    atomicAdd(dst, s);
+  }
+}
+
+// ---- normal (y) : forward sample + rate + partial derivatives ----
+// bits(v, sigma) = -log2 [Phi((v+.5)/s) - Phi((v-.5)/s)];  d bits/d v, d bits/d raw (through
+// idx = clamp(exp(raw), 0, 63), sigma = exp(c0 + c1 idx)).
+__global__ void __launch_bounds__(256) sga_normal_fwd_kernel(const float* __restrict__ y_loc, const float* __restrict__ hyper,
+                                                             int64_t hw, int c, float tau, const float* __restrict__ noise,
+                                                             unsigned long long seed, unsigned long long step,
+                                                             float* __restrict__ y_tilde, float* __restrict__ sprime,
+                                                             float* __restrict__ dbits_dv, float* __restrict__ dbits_draw,
+                                                             double* __restrict__ bits) {
+  const int img = blockIdx.y;
+  const int64_t per = hw * c;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c;
+    const int ch = (int)(i - p * c);
+    const int64_t gi = img * per + i;
+    const float mu = hyper[(img * hw + p) * 2 * c + ch];
+    const float raw = hyper[(img * hw + p) * 2 * c + c + ch];
+    const float g0 = noise ? noise[2 * gi] : gumbel_from(seed, step, (unsigned long long)gi, 0);
+    const float g1 = noise ? noise[2 * gi + 1] : gumbel_from(seed, step, (unsigned long long)gi, 1);
+    float v, sp;
+    sga_sample(y_loc[gi] - mu, tau, g0, g1, &v, &sp);
+    const float e = expf(raw);
+    const float idx = fminf(fmaxf(e, 0.0f), 63.0f);
+    const float sigma = expf(kLogScaleMin + kScaleFactor * idx);
+    const float hi = (v + 0.5f) / sigma, lo = (v - 0.5f) / sigma;
+    const bool right = hi > 0.0f;
+    const float big = log_ndtr_f(right ? -lo : hi), small = log_ndtr_f(right ? -hi : lo);
+    const float logp = big + log1pf(-expf(small - big));
+    // phi(x)/p in the log domain
+    const float lphi_hi = -0.5f * hi * hi - 0.91893853320467274f - logp;
+    const float lphi_lo = -0.5f * lo * lo - 0.91893853320467274f - logp;
+    const float r_hi = expf(lphi_hi), r_lo = expf(lphi_lo);
+    const float dlogp_dv = (r_hi - r_lo) / sigma;
+    const float dlogp_ds = -(r_hi * hi - r_lo * lo) / sigma;
+    const float dsig_draw = (e > 0.0f && e < 63.0f) ? sigma * kScaleFactor * e : 0.0f;
+    y_tilde[gi] = v + mu;
+    sprime[gi] = sp;
+    dbits_dv[gi] = -dlogp_dv * kInvLn2;
+    dbits_draw[gi] = -dlogp_ds * dsig_draw * kInvLn2;
+    acc += (double)(-logp * kInvLn2);
+  }
+  block_sum_to(acc, bits + img);
+}
+
+// g_yloc = (g_yt + w dbits_dv) s';  g_mu = g_yt (1 - s') - w dbits_dv s';  g_raw = w dbits_draw
+__global__ void __launch_bounds__(256) sga_normal_bwd_kernel(const float* __restrict__ g_yt, const float* __restrict__ sprime,
+                                                             const float* __restrict__ dbits_dv, const float* __restrict__ dbits_draw,
+                                                             float w, int64_t npix, int c, float* __restrict__ g_yloc,
+                                                             float* __restrict__ g_hyper) {
+  const int64_t total = npix * c;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c;
+    const int ch = (int)(i - p * c);
+    const float g = g_yt[i], sp = sprime[i], dv = w * dbits_dv[i];
+    g_yloc[i] = (g + dv) * sp;
+    g_hyper[p * 2 * c + ch] = g * (1.0f - sp) - dv * sp;
+    g_hyper[p * 2 * c + c + ch] = w * dbits_draw[i];
+  }
+}
+
+// ---- deep factorized (z) ----
+// logits L(x) and dL/dx
+__device__ __forceinline__ void df_logits_grad(const float* __restrict__ rec, const DFDesc& d, float x, float* L, float* dL) {
+  float hv[kMaxW] = {x, 0.f, 0.f, 0.f}, hd[kMaxW] = {1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kMaxL; ++k) {
+    if (k < d.nl) {
+      const int fi = d.w[k], fo = d.w[k + 1];
+      float nv[kMaxW] = {0.f, 0.f, 0.f, 0.f}, nd[kMaxW] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) {
+        if (o < fo) {
+          float s = rec[d.off_b[k] + o], ds = 0.0f;
+#pragma unroll
+          for (int i = 0; i < kMaxW; ++i)
+            if (i < fi) {
+              const float m = rec[d.off_m[k] + o * fi + i];
+              s += m * hv[i];
+              ds += m * hd[i];
+            }
+          if (k < d.nl - 1) {
+            const float f = rec[d.off_f[k] + o], th = tanhf(s);
+            ds *= 1.0f + f * (1.0f - th * th);
+            s += f * th;
+          }
+          nv[o] = s;
+          nd[o] = ds;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) { hv[o] = nv[o]; hd[o] = nd[o]; }
+    }
+  }
+  *L = hv[0];
+  *dL = hd[0];
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+
+__global__ void __launch_bounds__(256) sga_factorized_fwd_kernel(const float* __restrict__ rec_all, DFDesc d,
+                                                                 const float* __restrict__ z_loc, int64_t hw, int c, float tau,
+                                                                 const float* __restrict__ noise, unsigned long long seed,
+                                                                 unsigned long long step, float* __restrict__ z_tilde,
+                                                                 float* __restrict__ sprime, float* __restrict__ dbits_dz,
+                                                                 double* __restrict__ bits) {
+  const int img = blockIdx.y;
+  const int64_t per = hw * c;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const int64_t gi = img * per + i;
+    const float g0 = noise ? noise[2 * gi] : gumbel_from(seed ^ 0xA5A5A5A5ull, step, (unsigned long long)gi, 0);
+    const float g1 = noise ? noise[2 * gi + 1] : gumbel_from(seed ^ 0xA5A5A5A5ull, step, (unsigned long long)gi, 1);
+    float v, sp;
+    sga_sample(z_loc[gi], tau, g0, g1, &v, &sp);
+    const float* rec = rec_all + (size_t)ch * d.stride;
+    float hi, dhi, lo, dlo;
+    df_logits_grad(rec, d, v + 0.5f, &hi, &dhi);
+    df_logits_grad(rec, d, v - 0.5f, &lo, &dlo);
+    const bool right = hi > 0.0f;
+    const float big = log_sigmoid_f(right ? -lo : hi), small = log_sigmoid_f(right ? -hi : lo);
+    const float ratio = expf(small - big);                      // in [0, 1)
+    const float logp = big + log1pf(-ratio);
+    // dp/dv = s(hi) s(-hi) L'hi - s(lo) s(-lo) L'lo, divided by exp(big)
+    float num;
+    if (!right) num = sigmoid_f(-hi) * dhi - ratio * sigmoid_f(-lo) * dlo;   // / s(hi)
+    else num = ratio * sigmoid_f(hi) * dhi - sigmoid_f(lo) * dlo;           // / s(-lo); equals -(...)? see below
+    // right branch: p = s(-lo) - s(-hi); dp/dv = s(hi)s(-hi)L'hi - s(lo)s(-lo)L'lo; / s(-lo):
+    //   = [s(-hi)/s(-lo)] s(hi) L'hi - s(lo) L'lo = ratio s(hi) L'hi - s(lo) L'lo  (matches num above)
+    const float dlogp = num / (1.0f - ratio);
+    z_tilde[gi] = v;
+    sprime[gi] = sp;
+    dbits_dz[gi] = -dlogp * kInvLn2;
+    acc += (double)(-logp * kInvLn2);
+  }
+  block_sum_to(acc, bits + img);
+}
+
+// out = (g + w d) * s'
+__global__ void __launch_bounds__(256) sga_chain_kernel(const float* __restrict__ g, const float* __restrict__ dbits,
+                                                        const float* __restrict__ sprime, float w, int64_t total,
+                                                        float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (g[i] + w * dbits[i]) * sprime[i];
+}
+
+// ---- distortion: sse[n] of 255 (x - x_hat) and g_xhat = scale (x_hat - x) (zeros in the padded margin) ----
+__global__ void __launch_bounds__(256) distortion_grad_kernel(const float* __restrict__ x, const float* __restrict__ xh, int h, int w,
+                                                              int c, int hs, int ws, float scale, float* __restrict__ g,
+                                                              double* __restrict__ sse) {
+  const int img = blockIdx.y;
+  const int64_t per_s = (int64_t)hs * ws * c;
+  const int rowlen_s = ws * c;
+  double acc = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per_s; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / rowlen_s);
+    const int o = (int)(i - (int64_t)r * rowlen_s);
+    float gv = 0.0f;
+    if (r < h && o < w * c) {
+      const float d = xh[img * per_s + i] - x[((int64_t)img * h + r) * w * c + o];
+      gv = scale * d;
+      const float d255 = 255.0f * d;
+      acc += (double)(d255 * d255);
+    }
+    g[img * per_s + i] = gv;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sse + img, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---- two-layer tail backward: g_t[..., :CH] = d act(base) (g_h), g_t[..., CH:2CH] = g_h (residual), zero padding to CP ----
+// IGDN1: y_j = x_j n_j, n_j = beta_j + sum_i |x_i| gamma_ij  =>  dx_i = g_i n_i + sign(x_i) sum_j g_j x_j gamma_ij
+// GDN1 : y_j = x_j / n_j                                         =>  dx_i = g_i / n_i - sign(x_i) sum_j g_j x_j gamma_ij / n_j^2
+template <int CH>
+__global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__ t, const float* __restrict__ gh, int64_t npix,
+                                                       int has_res, int act_kind, const float* __restrict__ beta,
+                                                       const float* __restrict__ gamma, int cp, float* __restrict__ gt) {
+  __shared__ float sg[CH * CH];
+  __shared__ float sb[CH];
+  const bool use_gdn = act_kind == 1 || act_kind == 2;
+  if (use_gdn) {
+    for (int i = threadIdx.x; i < CH * CH; i += blockDim.x) sg[i] = gamma[i];
+    for (int i = threadIdx.x; i < CH; i += blockDim.x) sb[i] = beta[i];
+  }
+  __syncthreads();
+  const int c2 = has_res ? 2 * CH : CH;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    float xv[CH], g[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(t + p * c2 + i);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(gh + p * CH + i);
+      xv[i] = a[0]; xv[i + 1] = a[1]; xv[i + 2] = a[2]; xv[i + 3] = a[3];
+      g[i] = b[0]; g[i + 1] = b[1]; g[i + 2] = b[2]; g[i + 3] = b[3];
+    }
+    float* dst = gt + p * cp;
+    if (use_gdn) {
+      float u[CH];   // per-j factor multiplying gamma_ij
+      float nrm[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float n = sb[j];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) n += fabsf(xv[i]) * sg[i * CH + j];
+        nrm[j] = n;
+        u[j] = act_kind == 1 ? g[j] * xv[j] : -g[j] * xv[j] / (n * n);
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) s += u[j] * sg[i * CH + j];
+        const float sgn = xv[i] > 0.0f ? 1.0f : (xv[i] < 0.0f ? -1.0f : 0.0f);
+        dst[i] = (act_kind == 1 ? g[i] * nrm[i] : g[i] / nrm[i]) + sgn * s;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        float m = 1.0f;
+        if (act_kind == 3) m = xv[i] > 0.0f ? 1.0f : 0.0f;
+        if (act_kind == 4) m = xv[i] >= 0.0f ? 1.0f : 0.2f;
+        dst[i] = g[i] * m;
+      }
+    }
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) dst[CH + i] = g[i];
+    }
+    for (int i = c2; i < cp; ++i) dst[i] = 0.0f;
+  }
+}
+
+// ---- Keras Adam (non-amsgrad): alpha = lr sqrt(1-b2^t)/(1-b1^t); p -= alpha m / (sqrt(v) + eps) ----
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= alpha * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace sntc
+
+using namespace sntc;
+
+static int grid_for(int64_t items) {
+  int64_t b = (items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int sntc_sga_normal_fwd(const float* y_loc, const float* hyper, int n, int64_t hw, int c, float tau,
+                                   const float* noise, uint64_t seed, uint64_t step, float* y_tilde, float* sprime,
+                                   float* dbits_dv, float* dbits_draw, double* bits, void* stream) {
+  if (!y_loc || !hyper || !y_tilde || !sprime || !dbits_dv || !dbits_draw || !bits)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_normal_fwd: null argument");
+  if (n < 1 || hw < 1 || c < 1 || !(tau > 0.0f)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_normal_fwd: bad sizes / tau");
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  hipLaunchKernelGGL(sga_normal_fwd_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, y_loc, hyper, hw, c, tau, noise,
+                     (unsigned long long)seed, (unsigned long long)step, y_tilde, sprime, dbits_dv, dbits_draw, bits);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_sga_normal_bwd(const float* g_ytilde, const float* sprime, const float* dbits_dv, const float* dbits_draw,
+                                   float weight, int64_t npix, int c, float* g_yloc, float* g_hyper, void* stream) {
+  if (!g_ytilde || !sprime || !dbits_dv || !dbits_draw || !g_yloc || !g_hyper)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_normal_bwd: null argument");
+  hipLaunchKernelGGL(sga_normal_bwd_kernel, dim3(grid_for(npix * c)), dim3(256), 0, (hipStream_t)stream, g_ytilde, sprime,
+                     dbits_dv, dbits_draw, weight, npix, c, g_yloc, g_hyper);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_sga_factorized_fwd(const sntc_prior* prior, const float* z_loc, int n, int64_t hw, float tau,
+                                       const float* noise, uint64_t seed, uint64_t step, float* z_tilde, float* sprime,
+                                       float* dbits_dz, double* bits, void* stream) {
+  if (!prior || !z_loc || !z_tilde || !sprime || !dbits_dz || !bits)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_factorized_fwd: null argument");
+  if (n < 1 || hw < 1 || !(tau > 0.0f)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_factorized_fwd: bad sizes / tau");
+  const int c = prior->channels;
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  hipLaunchKernelGGL(sga_factorized_fwd_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, prior->rec,
+                     prior->d, z_loc, hw, c, tau, noise, (unsigned long long)seed,
+                     (unsigned long long)step, z_tilde, sprime, dbits_dz, bits);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_sga_chain(const float* g, const float* dbits, const float* sprime, float weight, int64_t total,
+                              float* out, void* stream) {
+  if (!g || !dbits || !sprime || !out || total < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_chain: null argument");
+  hipLaunchKernelGGL(sga_chain_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, dbits, sprime, weight,
+                     total, out);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_distortion_grad(const float* x, const float* x_hat, int n, int h, int w, int c, int hs, int ws,
+                                    float scale, float* g_xhat, double* sse, void* stream) {
+  if (!x || !x_hat || !g_xhat || !sse) return fail(SNTC_ERR_BAD_SHAPE, "sntc_distortion_grad: null argument");
+  if (n < 1 || h < 1 || w < 1 || c < 1 || hs < h || ws < w) return fail(SNTC_ERR_BAD_SHAPE, "sntc_distortion_grad: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(sse, 0, sizeof(double) * n, s));
+  int b = grid_for((int64_t)hs * ws * c);
+  if (b > 512) b = 512;
+  hipLaunchKernelGGL(distortion_grad_kernel, dim3(b, n), dim3(256), 0, s, x, x_hat, h, w, c, hs, ws, scale, g_xhat, sse);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+template <int CH>
+static int launch_tail_bwd(const float* t, const float* gh, int64_t npix, int has_res, int act_kind, const float* beta,
+                           const float* gamma, int cp, float* gt, hipStream_t s) {
+  hipLaunchKernelGGL((tail_bwd_kernel<CH>), dim3(grid_for(npix)), dim3(256), 0, s, t, gh, npix, has_res, act_kind, beta, gamma,
+                     cp, gt);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_two_layer_tail_bwd(const float* t, const float* g_h, int64_t npix, int ch, int has_res, int act_kind,
+                                       const float* beta, const float* gamma, int cp, float* g_t, void* stream) {
+  if (!t || !g_h || !g_t || npix < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: null argument");
+  if (cp < ch * (has_res ? 2 : 1)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: padded channel count too small");
+  if ((act_kind == 1 || act_kind == 2) && (!beta || !gamma))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: GDN parameters missing");
+  hipStream_t s = (hipStream_t)stream;
+  switch (ch) {
+    case 12: return launch_tail_bwd<12>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, s);
+    case 24: return launch_tail_bwd<24>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, s);
+    case 48: return launch_tail_bwd<48>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, s);
+    default: return fail(SNTC_ERR_UNSUPPORTED, "sntc_two_layer_tail_bwd: hidden channels must be 12, 24 or 48");
+  }
+}
+
+extern "C" int sntc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, int64_t t, void* stream) {
+  if (!param || !grad || !m || !v || n < 1 || t < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_adam_step: bad argument");
+  const double alpha = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, (float)alpha,
+                     beta1, beta2, eps);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}

@@ -62,4 +62,20 @@ int gg_variant_bn(int v);
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream);
 int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent)
 
+// ---- deep-factorized prior (entropy.hip, sga.hip) ----
+constexpr int kMaxW = 4;   // max hidden width
+constexpr int kMaxL = 5;   // max affine layers
+struct DFDesc {
+  int nl;
+  int w[kMaxL + 1];
+  int off_m[kMaxL], off_b[kMaxL], off_f[kMaxL];
+  int stride;   // floats per channel record: softplus(matrix), bias, tanh(factor) per layer
+};
+
 }  // namespace sntc
+
+struct sntc_prior {
+  int channels = 0;
+  sntc::DFDesc d{};
+  float* rec = nullptr;
+};

@@ -173,7 +173,7 @@ class Model:
     # -- schedules (reference :151-209) ----------------------------------------------------------
     @property
     def global_step(self):
-        return self._step
+        return self._itinf_step if self.itinf else self._step
 
     @property
     def _scheduled_lr(self):
@@ -319,12 +319,48 @@ class Model:
             sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
         return px, sse
 
-    # -- iterative inference (reference :389-413) -------------------------------------------------
+    # -- iterative inference (reference :389-413, common/itinf_lib.py:26-93) ----------------------------
     def initialize_itinf(self, image_batch):
-        raise NotImplementedError("SGA iterative inference is the next scope row (DESIGN.md)")
+        """latent_rvs = trainable copy of the encoder's latents; fresh Adam state (:389-395)."""
+        from ..sga import SGAEngine
+        if self.factorized:
+            raise NotImplementedError("SGA is implemented for the mean-scale hyperprior model")
+        if self._optimizer_config.get("global_clipnorm") is not None:
+            raise NotImplementedError("gradient clipping is not used by the reference's itinf config")
+        self.latent_rvs = self.infer_latent_rvs(image_batch).get_trainable_copy()
+        self._sga = getattr(self, "_sga", None) or SGAEngine(self)
+        self._adam = [dict(m=torch.zeros_like(rv.loc), v=torch.zeros_like(rv.loc)) for rv in self.latent_rvs.uq]
+        self.itinf = True
+        self._itinf_step = 0
 
-    def itinf_train_step(self, image_batch):
-        raise NotImplementedError("SGA iterative inference is the next scope row (DESIGN.md)")
+    @property
+    def itinf_trainable_variables(self):
+        return self.latent_rvs.trainable_variables
 
-    def itinf_validation_step(self, image_batch, training=False):
-        raise NotImplementedError("SGA iterative inference is the next scope row (DESIGN.md)")
+    def itinf_train_step(self, image_batch, noise=None, seed=0):
+        """One SGA step: loss = bpp + lambda * MSE(unrounded 0-255 floats), gradients to [z_loc, y_loc] only,
+        Keras-Adam update (:397-408).  ``noise`` = (gumbel_z, gumbel_y) makes the step deterministic."""
+        x = self._as_device_images(image_batch)
+        cfg = self.latent_config["uq"]
+        if cfg.get("method") != "sga":
+            raise NotImplementedError("itinf_train_step implements latent_config uq.method == 'sga'")
+        tau = cfg["tau"]
+        lr = self._scheduled_lr
+        z_loc, y_loc = self.latent_rvs.uq[0].loc, self.latent_rvs.uq[1].loc
+        with torch.cuda.device(self.device):
+            r = self._sga.loss_and_grads(x, z_loc, y_loc, tau, self._scheduled_rd_lambda, step=self._itinf_step, seed=seed,
+                                         noise_z=None if noise is None else noise[0],
+                                         noise_y=None if noise is None else noise[1])
+            t = self._itinf_step + 1
+            for p, g, st in ((z_loc, r["g_z"], self._adam[0]), (y_loc, r["g_y"], self._adam[1])):
+                ops.adam_step(p, g, st["m"], st["v"], lr, t, self._optimizer_config.get("beta_1", 0.9),
+                              self._optimizer_config.get("beta_2", 0.999), self._optimizer_config.get("epsilon", 1e-7))
+            host = torch.stack([r["bits_z"], r["bits_y"], r["sse"]]).cpu().numpy()
+        _, metrics = self._finish_metrics(x.shape, host[0], host[1], host[2])
+        self._itinf_step += 1
+        self.last_grads = (r["g_z"], r["g_y"])
+        return metrics
+
+    def itinf_validation_step(self, image_batch, training=False) -> Metrics:
+        _, metrics = self.frame_loss_given_latent_rvs(image_batch, latent_rvs=self.latent_rvs, training=training)
+        return metrics

@@ -261,3 +261,75 @@ def dequant_scale_normal(symbols, hyper):
     y_hat = torch.empty(symbols.shape, dtype=torch.float32, device=symbols.device)
     capi.call("sntc_dequant_scale_normal", _ptr(symbols), _ptr(hyper), n, hw, c, _ptr(y_hat), _stream())
     return y_hat
+
+
+# ------------------------------------------------------------------------------------------
+# SGA iterative inference (include/sntc.h "SGA" section)
+# ------------------------------------------------------------------------------------------
+def sga_factorized_fwd(prior, z_loc, tau, noise=None, seed=0, step=0):
+    """-> (z_tilde, sprime, dbits_dz, bits[n])."""
+    _check_nhwc(z_loc, prior.channels)
+    n, hw = z_loc.shape[0], z_loc.shape[1] * z_loc.shape[2]
+    zt, sp, db = torch.empty_like(z_loc), torch.empty_like(z_loc), torch.empty_like(z_loc)
+    bits = torch.empty((n,), dtype=torch.float64, device=z_loc.device)
+    capi.call("sntc_sga_factorized_fwd", prior._h, _ptr(z_loc), n, hw, float(tau), _ptr(noise), int(seed), int(step),
+              _ptr(zt), _ptr(sp), _ptr(db), _ptr(bits), _stream())
+    return zt, sp, db, bits
+
+
+def sga_normal_fwd(y_loc, hyper, tau, noise=None, seed=0, step=0):
+    """-> (y_tilde, sprime, dbits_dv, dbits_draw, bits[n])."""
+    _check_nhwc(y_loc)
+    c = y_loc.shape[-1]
+    _check_nhwc(hyper, 2 * c)
+    n, hw = y_loc.shape[0], y_loc.shape[1] * y_loc.shape[2]
+    yt, sp, dv, dr = (torch.empty_like(y_loc) for _ in range(4))
+    bits = torch.empty((n,), dtype=torch.float64, device=y_loc.device)
+    capi.call("sntc_sga_normal_fwd", _ptr(y_loc), _ptr(hyper), n, hw, c, float(tau), _ptr(noise), int(seed), int(step),
+              _ptr(yt), _ptr(sp), _ptr(dv), _ptr(dr), _ptr(bits), _stream())
+    return yt, sp, dv, dr, bits
+
+
+def sga_normal_bwd(g_ytilde, sprime, dbits_dv, dbits_draw, weight):
+    """-> (g_yloc, g_hyper[.., 2C])."""
+    _check_nhwc(g_ytilde)
+    n, h, w, c = g_ytilde.shape
+    g_y = torch.empty_like(g_ytilde)
+    g_h = torch.empty((n, h, w, 2 * c), dtype=torch.float32, device=g_ytilde.device)
+    capi.call("sntc_sga_normal_bwd", _ptr(g_ytilde), _ptr(sprime), _ptr(dbits_dv), _ptr(dbits_draw), float(weight),
+              n * h * w, c, _ptr(g_y), _ptr(g_h), _stream())
+    return g_y, g_h
+
+
+def sga_chain(g, dbits, sprime, weight):
+    out = torch.empty_like(g)
+    capi.call("sntc_sga_chain", _ptr(g), _ptr(dbits), _ptr(sprime), float(weight), g.numel(), _ptr(out), _stream())
+    return out
+
+
+def distortion_grad(x, x_hat, scale):
+    """-> (g_xhat with x_hat's (padded) shape, sse[n] float64 of 255 (x - x_hat) over the un-padded region)."""
+    _check_nhwc(x)
+    _check_nhwc(x_hat, x.shape[-1])
+    n, h, w, c = x.shape
+    g = torch.empty_like(x_hat)
+    sse = torch.empty((n,), dtype=torch.float64, device=x.device)
+    capi.call("sntc_distortion_grad", _ptr(x), _ptr(x_hat), n, h, w, c, x_hat.shape[1], x_hat.shape[2], float(scale),
+              _ptr(g), _ptr(sse), _stream())
+    return g, sse
+
+
+def two_layer_tail_bwd(t, g_h, ch, has_res, act_kind, beta, gamma, cp):
+    _check_nhwc(t, ch * (2 if has_res else 1))
+    _check_nhwc(g_h, ch)
+    n, hh, wh, _ = t.shape
+    g_t = torch.empty((n, hh, wh, cp), dtype=torch.float32, device=t.device)
+    capi.call("sntc_two_layer_tail_bwd", _ptr(t), _ptr(g_h), n * hh * wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma),
+              cp, _ptr(g_t), _stream())
+    return g_t
+
+
+def adam_step(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-7):
+    """In-place Keras Adam update of ``param`` (and its moments m, v); t is the 1-based step."""
+    capi.call("sntc_adam_step", _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(t), _stream())
