@@ -71,6 +71,8 @@ def main():
     rank, local_rank, world = D.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
+    if os.environ.get("SNTC_SHARE_GPU"):          # 2-rank dry run of the distributed flow on a 1-GPU box (gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -25,7 +25,7 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SNTC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -45,7 +45,7 @@ def barrier():
 def max_over_ranks(value, device="cpu"):
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -65,6 +65,8 @@ def gather_rows(local_rows, indices, num_items, device="cpu"):
     if len(indices):
         buf[:len(indices), 0] = torch.as_tensor(indices, dtype=torch.float64)
         buf[:len(indices), 1:] = torch.as_tensor(local_rows)
+    if dist.get_backend() == "gloo":
+        buf = buf.cpu()
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf)
     out = np.full((num_items, k), np.nan)
