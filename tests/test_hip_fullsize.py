@@ -1,0 +1,142 @@
+"""Full-size (BASELINE.json configs 2-4 shapes) property tests on the GPU, where the float64 oracle
+would take minutes: size-independent identities instead of element-wise comparison (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def kodak_model(dev):
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.02))
+    w = dict(model.get_weights())
+    rng = np.random.default_rng(0)
+    b = w["hyper_synthesis/layer_2/bias"].copy()
+    b[320:] = rng.uniform(-2.0, 2.5, size=320)
+    w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
+    model.set_weights(w)
+    model._step = 10**9
+    return model
+
+
+def test_full_model_shapes_and_batch_invariance(kodak_model, dev):
+    """y (n,32,48,320), z (n,8,12,320), x_hat (n,512,768,3) (get_flops.ipynb cell 26); a batch gives, image
+    by image, bit-identical symbols / pixels to single-image evaluation (tile choice is speed only)."""
+    from shallow_ntc_amd.common import data_lib
+    m = kodak_model
+    x = data_lib.normalize_image(data_lib.synthetic_images(3, 512, 768, seed=2))
+    xd = t(x, dev)
+    lat = m.infer_latent_rvs(xd)
+    assert tuple(lat.uq[1].loc.shape) == (3, 32, 48, 320) and tuple(lat.uq[0].loc.shape) == (3, 8, 12, 320)
+    z_hat, sym, bz, by = m.encode(xd)
+    px, sse = m.decode(z_hat, sym, (512, 768), reference=xd)
+    assert tuple(px.shape) == (3, 512, 768, 3) and px.dtype == torch.uint8
+    for i in range(3):
+        zi, si, bzi, byi = m.encode(xd[i:i + 1].contiguous())
+        assert torch.equal(zi, z_hat[i:i + 1]) and torch.equal(si, sym[i:i + 1])
+        assert abs(float(bzi[0]) - float(bz[i])) <= 1e-9 * abs(float(bz[i]))
+        assert abs(float(byi[0]) - float(by[i])) <= 1e-9 * abs(float(by[i]))
+        pi, ssei = m.decode(zi, si, (512, 768), reference=xd[i:i + 1].contiguous())
+        assert torch.equal(pi, px[i:i + 1]) and int(ssei[0]) == int(sse[i])
+    # decode is deterministic and the metrics follow the published identities
+    px2, sse2 = m.decode(z_hat, sym, (512, 768), reference=xd)
+    assert torch.equal(px, px2) and torch.equal(sse, sse2)
+    rows = m.evaluate_batched(xd)
+    for i, r in enumerate(rows):
+        mse = int(sse[i]) / (512 * 768 * 3)
+        assert abs(r["mse"] - mse) < 1e-3 * mse
+        assert abs(r["psnr"] - 10 * np.log10(255.0 ** 2 / mse)) < 1e-3
+        assert abs(r["rd_loss"] - (r["bpp"] + 0.02 * r["mse"])) < 1e-4 * r["rd_loss"]
+        assert abs(r["bpp"] - (float(bz[i]) + float(by[i])) / (512 * 768)) < 1e-6 * r["bpp"]
+    # the integer checksum of the decoded pixels equals the one of the evaluation path
+    assert int(px.to(torch.int64).sum()) == int(m.decode(z_hat, sym, (512, 768)).to(torch.int64).sum())
+
+
+def test_portrait_and_padded_sizes(kodak_model, dev):
+    """768 x 512 (Kodak portrait) and a 500 x 750 image that reflect-pads to 512 x 768."""
+    from shallow_ntc_amd.common import data_lib
+    m = kodak_model
+    xp = t(data_lib.normalize_image(data_lib.synthetic_images(1, 768, 512, seed=3)), dev)
+    z_hat, sym, _, _ = m.encode(xp)
+    assert tuple(sym.shape) == (1, 48, 32, 320) and tuple(m.decode(z_hat, sym, (768, 512)).shape) == (1, 768, 512, 3)
+    xo = t(data_lib.normalize_image(data_lib.synthetic_images(1, 500, 750, seed=4)), dev)
+    z_hat, sym, _, _ = m.encode(xo)
+    assert tuple(sym.shape) == (1, 32, 48, 320)
+    px = m.decode(z_hat, sym, (500, 750))
+    assert tuple(px.shape) == (1, 500, 750, 3)
+    met = next(iter(m.evaluate(xo))).scalars_float
+    assert np.isfinite(met["bpp"]) and np.isfinite(met["psnr"])
+
+
+@pytest.mark.parametrize("kind,k,s,cin,cout,h,w", [("convT", 13, 8, 320, 24, 32, 48), ("convT", 5, 2, 320, 480, 16, 24),
+                                                   ("convT", 3, 1, 480, 640, 32, 48), ("convT", 18, 16, 320, 3, 32, 48),
+                                                   ("conv", 5, 2, 192, 192, 128, 192), ("conv", 3, 1, 96, 96, 64, 96)])
+def test_linearity_and_adjoint_at_full_width(kind, k, s, cin, cout, h, w, dev):
+    """T(a u + b v) = a T(u) + b T(v), and <T(u), g> = <u, T*(g)> where T* is the SAME conv / transposed conv
+    on the same kernel array (the identity SGA's backward relies on)."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(k * 7 + s)
+    wshape = (k, k, cout, cin) if kind == "convT" else (k, k, cin, cout)
+    wk = t((rng.standard_normal(wshape) / np.sqrt(k * k * cin / 4)), dev)
+    plan = ops.ConvPlan(kind, wk, None, s)
+    u, v = t(rng.standard_normal((2, h, w, cin)), dev), t(rng.standard_normal((2, h, w, cin)), dev)
+    a, b = 0.75, -1.5
+    lhs = plan((a * u + b * v).contiguous())
+    rhs = a * plan(u) + b * plan(v)
+    assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
+    if kind == "convT":      # adjoint: Conv2D SAME stride s with the same array read as HWIO (I = cout, O = cin)
+        adj = ops.ConvPlan("conv", wk, None, s)
+        tu = plan(u)
+        g = t(rng.standard_normal(tuple(tu.shape)), dev)
+        left = float((tu.double() * g.double()).sum())
+        right = float((u.double() * adj(g).double()).sum())
+        assert abs(left - right) <= 1e-5 * (abs(left) + float(tu.abs().mean()) * float(g.abs().mean()) * tu.numel() ** 0.5)
+
+
+def test_zero_input_is_bias_full_size(dev):
+    """vis_syn_filters.ipynb: JPEG-like synthesis (k = 18, s = 16, 320 channels) of zeros is its bias."""
+    from shallow_ntc_amd.common.transforms import class_builder
+    tr = class_builder.build("JPEGLikeSynthesis", kernel_size=18, strides=16)
+    tr.build(320, dev)
+    w = dict(tr.get_weights())
+    w["conv/bias"] = np.array([-0.00739, -0.04296, -0.08146], np.float32)
+    tr.set_weights(w)
+    out = tr(torch.zeros((2, 32, 48, 320), device=dev)).cpu().numpy()
+    assert out.shape == (2, 512, 768, 3)
+    np.testing.assert_array_equal(out, np.broadcast_to(w["conv/bias"], out.shape))
+
+
+def test_batches_beyond_the_32bit_offset_limit_are_split(dev):
+    """Inputs of >= 2 GiB are processed in halves (ops.ConvPlan); the result equals per-image calls."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(1)
+    wk = t(rng.standard_normal((1, 1, 192, 32)) * 0.1, dev)
+    plan = ops.ConvPlan("conv", wk, None, 1, "relu")
+    x = torch.randn((8, 512, 768, 192), device=dev)          # 2.4 GB
+    assert x.numel() * 4 >= ops.MAX_INPUT_BYTES
+    y = plan(x)
+    for i in (0, 3, 7):
+        assert torch.equal(y[i:i + 1], plan(x[i:i + 1].contiguous()))
+    from shallow_ntc_amd import _capi
+    with pytest.raises(_capi.SntcError):                        # the C ABI itself refuses instead of wrapping around
+        _capi.call("sntc_conv_forward", plan._h, ops._ptr(x), 8, 512, 768, ops._ptr(y), None, None, ops._stream())
+
+
+def test_edge_shapes(dev):
+    from shallow_ntc_amd import _capi, ops
+    rng = np.random.default_rng(2)
+    wk = t(rng.standard_normal((5, 5, 32, 32)) * 0.1, dev)
+    plan = ops.ConvPlan("conv", wk, None, 2)
+    assert tuple(plan(torch.randn((1, 1, 1, 32), device=dev)).shape) == (1, 1, 1, 32)       # 1 x 1 image
+    assert tuple(plan(torch.randn((3, 2, 7, 32), device=dev)).shape) == (3, 1, 4, 32)
+    with pytest.raises(_capi.SntcError):
+        plan(torch.zeros((0, 4, 4, 32), device=dev))                                        # empty batch
+    with pytest.raises(ValueError):
+        plan(torch.zeros((1, 4, 4, 16), device=dev))                                        # wrong channels
