@@ -60,6 +60,9 @@ def main():
                     help="only launch decode kernels (the command profiles/ is recorded with): skips the "
                          "encode+decode loop, the (bpp, PSNR) evaluation and the CPU baseline")
     ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
+                         "the host already runs ahead of the GPU)")
     args = ap.parse_args()
 
     graft.load_package()
@@ -108,11 +111,20 @@ def main():
         codes.append((z_hat, sym, (h, wd), x))
     torch.cuda.synchronize()
 
-    def decode_step():
-        out = []
-        for z_hat, sym, hw, _x in codes:
-            out.append(model.decode(z_hat, sym, hw))
-        return out
+    def decode_eager():
+        return [model.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
+
+    if not args.graph:
+        decode_step = decode_eager
+    else:                                  # one captured HIP graph per batch shape, replayed every step
+        from shallow_ntc_amd.graphs import DecodeGraph
+        graphs = [DecodeGraph(model, z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
+        # the graph output must equal the eager output bit for bit
+        for g, ref in zip(graphs, decode_eager()):
+            assert torch.equal(g(), ref), "HIP-graph replay differs from eager decode"
+
+        def decode_step():
+            return [g() for g in graphs]
 
     def e2e_step():
         for ids, x, hw in batches:
@@ -153,10 +165,10 @@ def main():
         per_kernel = {}
         for _rep in range(3):
             ops.PROFILE = []
-            decode_step()
+            decode_eager()
             torch.cuda.synchronize()
             for e in ops.PROFILE:
-                vec = "true,false" if e["vec"] else "false,true"      # <TM,TN,WM,WN,VEC,PRO> as rocprof prints it
+                vec = "true, false" if e["vec"] else "false, true"      # <TM,TN,WM,WN,VEC,PRO> as rocprof prints it
                 name = f"gg_kernel<1, {e['variant']}, 4, 1, {vec}>" if e["variant"] != 8 else f"gg_kernel<1, 1, 2, 2, {vec}>"
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
@@ -165,8 +177,16 @@ def main():
             ops.PROFILE = None
         name, k = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None       # HBM-side bytes per launch from the committed PMC passes (separate runs)
+        for f in sorted((ROOT / "profiles").glob("*_pmc_summary.json"), reverse=True):
+            for kn, e in json.loads(f.read_text()).items():
+                if name in kn and "hbm_side_bytes_per_launch" in e:
+                    traffic, traffic_src = e["hbm_side_bytes_per_launch"], f"profiles/{f.name}"
+            if traffic is not None:
+                break
         roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        traffic_source=traffic_src,
                         avg_launch_ms=round(k["ms"] / k["launches"], 4), launches_per_step=k["launches"] // 3,
                         precision="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                         all_kernels={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
@@ -209,6 +229,7 @@ def main():
                                  f"Kodak-24-shaped synthetic set per GPU ({len(shapes)} images: 512x768 / 768x512), "
                                  f"random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
                         timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels",
+                        launch="hipGraph replay (one graph per batch shape)" if args.graph else "eager",
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))"),
             encode_decode_mpixels_per_s=None if e2e_value is None else round(e2e_value, 2),
             rd=rd, roofline=roofline, cpu_baseline=cpu_baseline,

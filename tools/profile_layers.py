@@ -23,6 +23,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=[512, 768])
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--config", default="two_layer_syn")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--decode-only", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 model = Model(device=dev, **configs.CONFIGS[args.config]())
@@ -57,4 +58,5 @@ def run(fn, label):
 
 z_hat, sym, _, _ = model.encode(x)
 run(lambda: model.decode(z_hat, sym, (h, w)), "decode")
-run(lambda: model.encode(x), "encode")
+if not args.decode_only:
+    run(lambda: model.encode(x), "encode")

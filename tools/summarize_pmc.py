@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 --pmc counter_collection CSVs into profiles/<tag>_pmc_summary.json.
+
+    python tools/summarize_pmc.py r01 gpurun_out/pmc_sq gpurun_out/pmc_fetch gpurun_out/pmc_write
+
+Per kernel (sntc::* only): launches, mean of every counter per launch, and
+hbm_side_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE / WRITE_SIZE are in KiB and on
+gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); both count
+the L2's memory-side requests, Infinity-Cache hits included."""
+import collections
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+tag, dirs = sys.argv[1], sys.argv[2:]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in dirs:
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "sntc" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, v in agg.items():
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    e = dict(launches=max(len(x) for x in v.values()), counters_mean_per_launch={c: round(val, 1) for c, val in m.items()})
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        e["hbm_side_bytes_per_launch"] = int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("SQ_BUSY_CYCLES"):
+        e["mfma_busy_over_sq_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"], 3)
+    if m.get("SQ_WAVE_CYCLES"):
+        e["wave_cycle_shares"] = {c: round(m[c] / m["SQ_WAVE_CYCLES"], 3) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c in m}
+    out[k] = e
+p = Path(__file__).resolve().parent.parent / "profiles" / f"{tag}_pmc_summary.json"
+p.write_text(json.dumps(out, indent=1))
+print(p, len(out), "kernels")
