@@ -140,3 +140,54 @@ def test_edge_shapes(dev):
         plan(torch.zeros((0, 4, 4, 32), device=dev))                                        # empty batch
     with pytest.raises(ValueError):
         plan(torch.zeros((1, 4, 4, 16), device=dev))                                        # wrong channels
+
+
+BASELINE_CONFIGS = [  # BASELINE.json configs 1-5 at their real widths; (name, factorized, batch, h, w)
+    ("bls2017", True, 1, 256, 256),
+    ("mbt2018", False, 8, 256, 256),
+    ("jpegl", False, 2, 512, 768),
+    ("two_layer_syn2", False, 1, 1200, 1200),     # Tecnick: pads to 1216 x 1216
+]
+
+
+@pytest.mark.parametrize("name,factorized,n,h,w", BASELINE_CONFIGS, ids=[c[0] for c in BASELINE_CONFIGS])
+def test_every_baseline_config_runs_at_full_size(name, factorized, n, h, w, dev):
+    """Each reference config builds from its dict, evaluates a full-size batch, and satisfies the metric
+    identities; decode(encode(x)) reproduces the evaluation's distortion exactly (integer SSE)."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.factorized.models import Model as FModel
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = configs.CONFIGS[name](rd_lambda=0.02)
+    model = (FModel if factorized else Model)(device=dev, **cfg)
+    model._step = 10**9
+    x = t(data_lib.normalize_image(data_lib.synthetic_images(n, h, w, seed=11)), dev)
+    rows = model.evaluate_batched(x)
+    assert len(rows) == n
+    codes = model.encode(x)
+    px, sse = model.decode(codes[0], codes[1], (h, w), reference=x)
+    assert tuple(px.shape) == (n, h, w, 3)
+    for i, r in enumerate(rows):
+        assert np.isfinite(r["bpp"]) and r["bpp"] > 0 and np.isfinite(r["psnr"])
+        assert abs(r["rd_loss"] - (r["bpp"] + 0.02 * r["mse"])) <= 1e-4 * r["rd_loss"]
+        assert abs(r["mse"] - int(sse[i]) / (h * w * 3)) <= 1e-4 * r["mse"]
+    expected_factor = 16 if factorized else 64
+    assert model.downsample_factor == expected_factor
+
+
+def test_sga_step_at_tecnick_shape(dev):
+    """BASELINE config 5: two_layer_syn2 (hidden 24) + itinf overrides, one 1200 x 1200 image, three SGA steps."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = {**configs.two_layer_syn2(rd_lambda=0.02, hidden_channels=24), **configs.itinf()}
+    model = Model(device=dev, **cfg)
+    x = t(data_lib.normalize_image(data_lib.synthetic_images(1, 1200, 1200, seed=12)), dev)
+    model.initialize_itinf(x)
+    assert tuple(model.latent_rvs.uq[1].loc.shape) == (1, 76, 76, 320) and tuple(model.latent_rvs.uq[0].loc.shape) == (1, 19, 19, 320)
+    first = model.itinf_train_step(x, seed=1).scalars_float
+    for _ in range(2):
+        last = model.itinf_train_step(x, seed=1).scalars_float
+    assert np.isfinite(first["rd_loss"]) and np.isfinite(last["rd_loss"]) and model.global_step == 3
+    val = model.itinf_validation_step(x).scalars_float
+    assert np.isfinite(val["psnr"])
