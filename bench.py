@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=24, help="images per rank (Kodak-24 shaped set)")
+    ap.add_argument("--workload", choices=["kodak24", "w1"], default="kodak24",
+                    help="kodak24: the metric's configuration (default); w1: SURVEY 8d synthetic batches of "
+                         "--images (default 64) 256x256 crops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-only", action="store_true",
                     help="only launch decode kernels (the command profiles/ is recorded with): skips the "
@@ -89,7 +92,10 @@ def main():
     w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
     model.set_weights(w)
 
-    shapes = KODAK_SHAPES[:args.images] if args.images <= 24 else [KODAK_SHAPES[i % 24] for i in range(args.images)]
+    if args.workload == "w1":
+        shapes = [(256, 256)] * (64 if args.images == 24 else args.images)
+    else:
+        shapes = KODAK_SHAPES[:args.images] if args.images <= 24 else [KODAK_SHAPES[i % 24] for i in range(args.images)]
     groups = {}
     for i, s in enumerate(shapes):
         groups.setdefault(s, []).append(i)
@@ -226,8 +232,9 @@ def main():
             ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype="f32", data="synthetic",
             config=dict(workload=f"mshyper/configs/two_layer_syn.py (ElicAnalysis 192,192,192,320 + TwoLayerResSynthesis 12,3), "
-                                 f"Kodak-24-shaped synthetic set per GPU ({len(shapes)} images: 512x768 / 768x512), "
-                                 f"random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
+                                 + (f"W1 synthetic batch per GPU ({len(shapes)} x 256x256), " if args.workload == "w1" else
+                                    f"Kodak-24-shaped synthetic set per GPU ({len(shapes)} images: 512x768 / 768x512), ") +
+                                 "random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
                         timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels",
                         launch="hipGraph replay (one graph per batch shape)" if args.graph else "eager",
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))"),
