@@ -60,7 +60,7 @@ TRANSFORMS = [  # cls, kwargs, input shape (n,h,w,c)
 @pytest.mark.parametrize("cls,kwargs,shape", TRANSFORMS, ids=[f"{c}-{i}" for i, (c, _, _) in enumerate(TRANSFORMS)])
 def test_transform_parity(cls, kwargs, shape, dev):
     from shallow_ntc_amd.common.transforms import class_builder
-    rng = np.random.default_rng(abs(hash(cls)) % 1000)
+    rng = np.random.default_rng(len(cls) * 31 + len(kwargs))
     t = class_builder.build(cls, **kwargs)
     cin = shape[-1]
     okw = dict(kwargs)
