@@ -181,6 +181,20 @@ int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n,
                               float* y_hat, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * SSIM / MS-SSIM statistics (eval-only quality metrics, reference mshyper/models.py:321-336 ->
+ *   tf.image.ssim / tf.image.ssim_multiscale).  Images are float NHWC holding pixel
+ *   values (0..max_val), c in {1, 3}.
+ * ------------------------------------------------------------------------------------------ */
+/* One scale: 11 x 11 Gaussian (sigma 1.5) VALID moments; ssim_sum[n*c] = sum over filter outputs of
+ * luminance*cs, cs_sum[n*c] = sum of cs (both OVERWRITTEN).  Divide by (h-10)(w-10) for the means. */
+int sntc_ssim_scale(const float* a, const float* b, int n, int h, int w, int c, float max_val, double* ssim_sum,
+                    double* cs_sum, void* stream);
+/* 2 x 2 average pooling to ceil(h/2) x ceil(w/2); odd sizes repeat the last row / column (tf.pad SYMMETRIC). */
+int sntc_avgpool2_symmetric(const float* x, int n, int h, int w, int c, float* y, void* stream);
+/* crop + floats_to_pixels (round-half-even, clamp 0..255) kept as float: the SSIM input. */
+int sntc_pixels_float(const float* x_hat, int n, int h, int w, int c, int hs, int ws, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * SGA iterative inference (config 5): element-wise pieces of Model.itinf_train_step,
  *   mshyper/models.py:397-408 with frame_loss_given_latent_rvs(training=True), :260-268,285-291,343.
  *   The contractions of the backward pass are sntc_conv_forward calls: the input gradient of

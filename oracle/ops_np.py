@@ -341,3 +341,84 @@ def sga_round(mu, tau, gumbel, offset=None, epsilon=1e-5):
     e0 = np.exp(a0 - m)
     e1 = np.exp(a1 - m)
     return (e0 * fl + e1 * ce) / (e0 + e1)
+
+
+# --------------------------------------------------------------------------
+# SSIM / MS-SSIM  (reference mshyper/models.py:321-336 -> tf.image.ssim / tf.image.ssim_multiscale,
+# TF 2.10 image_ops_impl.py).  Restated from the published algorithm: 11x11 Gaussian
+# (sigma 1.5, normalised by a softmax over the 2-D grid == outer product of normalised 1-D windows),
+# VALID depthwise filtering, k1 = .01, k2 = .03, compensation 1.0, 5 scales with weights
+# (0.0448, 0.2856, 0.3001, 0.2363, 0.1333), 2x2 average pooling between scales after SYMMETRIC padding of
+# odd sizes at the bottom/right, relu on every factor, mean over channels last.
+# --------------------------------------------------------------------------
+MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def _gauss_window(size=11, sigma=1.5):
+    c = np.arange(size, dtype=F64) - (size - 1) / 2.0
+    g = np.exp(-0.5 * c * c / (sigma * sigma))
+    return g / g.sum()
+
+
+def _filter_valid(x, win):
+    """Depthwise separable VALID filter over H and W of [n,h,w,c]."""
+    k = len(win)
+    n, h, w, c = x.shape
+    t = np.zeros((n, h - k + 1, w, c), F64)
+    for i in range(k):
+        t += win[i] * x[:, i:i + h - k + 1]
+    o = np.zeros((n, h - k + 1, w - k + 1, c), F64)
+    for j in range(k):
+        o += win[j] * t[:, :, j:j + w - k + 1]
+    return o
+
+
+def ssim_per_channel(a, b, max_val=255.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """-> (ssim[n,c], cs[n,c]) spatial means of luminance*cs and of cs."""
+    a = np.asarray(a, F64)
+    b = np.asarray(b, F64)
+    win = _gauss_window(filter_size, filter_sigma)
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    m0, m1 = _filter_valid(a, win), _filter_valid(b, win)
+    num0 = m0 * m1 * 2.0
+    den0 = m0 * m0 + m1 * m1
+    lum = (num0 + c1) / (den0 + c1)
+    num1 = _filter_valid(a * b, win) * 2.0
+    den1 = _filter_valid(a * a + b * b, win)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return (lum * cs).mean(axis=(1, 2)), cs.mean(axis=(1, 2))
+
+
+def ssim(a, b, max_val=255.0):
+    return ssim_per_channel(a, b, max_val)[0].mean(axis=-1)
+
+
+def _avg_pool2_symmetric(x):
+    n, h, w, c = x.shape
+    if h % 2 or w % 2:
+        x = np.pad(x, ((0, 0), (0, h % 2), (0, w % 2), (0, 0)), mode="symmetric")
+    n, h, w, c = x.shape
+    return x.reshape(n, h // 2, 2, w // 2, 2, c).mean(axis=(2, 4))
+
+
+def ms_ssim(a, b, max_val=255.0, power_factors=MSSSIM_WEIGHTS):
+    a = np.asarray(a, F64)
+    b = np.asarray(b, F64)
+    mcs = []
+    for k in range(len(power_factors)):
+        if k > 0:
+            a, b = _avg_pool2_symmetric(a), _avg_pool2_symmetric(b)
+        s, cs = ssim_per_channel(a, b, max_val)
+        mcs.append(np.maximum(cs, 0.0))
+    mcs.pop()
+    stack = np.stack(mcs + [np.maximum(s, 0.0)], axis=-1)            # [n, c, scales]
+    return np.prod(stack ** np.asarray(power_factors), axis=-1).mean(axis=-1)
+
+
+def image_quality(a, b, max_val=255.0):
+    """mshyper/models.py:321-331: single-scale SSIM when both sides are < 160, MS-SSIM otherwise;
+    msssim_db = -10 log10(1 - msssim)."""
+    h, w = a.shape[1], a.shape[2]
+    v = ssim(a, b, max_val) if (h < 160 and w < 160) else ms_ssim(a, b, max_val)
+    with np.errstate(divide="ignore"):
+        return v, -10.0 * np.log10(1.0 - v)

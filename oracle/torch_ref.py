@@ -154,3 +154,36 @@ def analysis_only(model_np, params, x):
 
 import sys as _sys
 _SELF = _sys.modules[__name__]
+
+
+def ms_ssim_torch(a, b, max_val=255.0):
+    """Independent float32 restatement of tf.image.ssim_multiscale: 2-D 11x11 kernel from a softmax over
+    the grid (as TF's _fspecial_gauss), depthwise F.conv2d VALID, F.avg_pool2d after replicate padding."""
+    a = torch.as_tensor(np.asarray(a, np.float32)).permute(0, 3, 1, 2)
+    b = torch.as_tensor(np.asarray(b, np.float32)).permute(0, 3, 1, 2)
+    c = a.shape[1]
+    coords = torch.arange(11, dtype=torch.float32) - 5.0
+    g = -0.5 * coords ** 2 / 1.5 ** 2
+    k2d = torch.softmax((g.view(1, -1) + g.view(-1, 1)).reshape(-1), 0).view(1, 1, 11, 11).repeat(c, 1, 1, 1)
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    weights = torch.tensor([0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
+
+    def per_channel(x, y):
+        red = lambda t: F.conv2d(t, k2d, groups=c)
+        m0, m1 = red(x), red(y)
+        num0, den0 = 2 * m0 * m1, m0 * m0 + m1 * m1
+        lum = (num0 + c1) / (den0 + c1)
+        cs = (2 * red(x * y) - num0 + c2) / (red(x * x + y * y) - den0 + c2)
+        return (lum * cs).mean(dim=(2, 3)), cs.mean(dim=(2, 3))
+
+    mcs = []
+    for k in range(5):
+        if k > 0:
+            ph, pw = a.shape[2] % 2, a.shape[3] % 2
+            if ph or pw:
+                a, b = F.pad(a, (0, pw, 0, ph), mode="replicate"), F.pad(b, (0, pw, 0, ph), mode="replicate")
+            a, b = F.avg_pool2d(a, 2), F.avg_pool2d(b, 2)
+        s, cs = per_channel(a, b)
+        mcs.append(torch.relu(cs))
+    mcs[-1] = torch.relu(s)
+    return torch.prod(torch.stack(mcs, -1) ** weights, -1).mean(-1).numpy()

@@ -63,6 +63,9 @@ SIGNATURES = {
     "sntc_entropy_factorized": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P]),
     "sntc_entropy_scale_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, C.c_int, _P]),
     "sntc_dequant_scale_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "sntc_ssim_scale": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
+    "sntc_avgpool2_symmetric": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sntc_pixels_float": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_sga_factorized_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_float, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     "sntc_sga_normal_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, _P, C.c_uint64, C.c_uint64, _P, _P, _P,
                                       _P, _P, _P]),

@@ -75,7 +75,8 @@ class Model:
 
     def __init__(self, scheduled_num_steps=1500000, rd_lambda=0.01, offset_heuristic=True,
                  transform_config=EMPTY_DICT, optimizer_config=EMPTY_DICT,
-                 latent_config=None, profile=False, device=None, prior_num_filters=(3, 3), seed=4321):
+                 latent_config=None, profile=False, device=None, prior_num_filters=(3, 3), seed=4321,
+                 quality_metrics=True):
         capi.require_gpu()
         self._scheduled_num_steps = scheduled_num_steps
         self._rd_lambda = rd_lambda
@@ -90,6 +91,7 @@ class Model:
         self._profile = profile
         self._prior_num_filters = tuple(prior_num_filters)
         self._seed = seed
+        self._quality_metrics = quality_metrics     # MS-SSIM at eval (reference :321-331); LPIPS is not vendored
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self._step = 0
         self._prior = None
@@ -236,11 +238,19 @@ class Model:
             r = self._rate_and_reconstruction(latent_rvs)
             sse, _ = ops.pixels_sse(x, r["recon"])                    # unpad + floats_to_pixels + mse fused
             host = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)]).cpu().numpy()
-        rd_loss, metrics = self._finish_metrics(x.shape, host[0], host[1], host[2])
+            msssim = self._msssim(x, r["recon"])
+        rd_loss, metrics = self._finish_metrics(x.shape, host[0], host[1], host[2], msssim)
         metrics.record_image("reconstruction", r["recon"])
         return rd_loss, metrics
 
-    def _finish_metrics(self, x_shape, bits_z, bits_y, sse):
+    def _msssim(self, x, recon):
+        """Per-image (MS-)SSIM of the uint8-quantised images (reference :321-331), or None."""
+        if not self._quality_metrics or min(x.shape[1], x.shape[2]) < 11:
+            return None
+        h, w = x.shape[1], x.shape[2]
+        return ops.image_quality(ops.pixels_float(x, h, w), ops.pixels_float(recon, h, w), 255.0)
+
+    def _finish_metrics(self, x_shape, bits_z, bits_y, sse, msssim=None):
         n, h, w, c = x_shape
         num_pixels = np.float32(h * w)                                                  # :302
         bits_z = None if bits_z is None else bits_z.astype(np.float32)
@@ -261,6 +271,11 @@ class Model:
         metrics.record_scalar("sched_rd_lambda", lam)
         if self.latent_config["uq"].get("method") == "sga":
             metrics.record_scalar("tau", self.latent_config["uq"]["tau"])
+        if msssim is not None:                                                          # :321-331
+            ms = np.float32(np.asarray(msssim, np.float32).mean(dtype=np.float32))
+            with np.errstate(divide="ignore"):
+                db = np.float32((-10.0 * np.log10(1.0 - np.asarray(msssim, np.float64))).mean())
+            metrics.record_scalars(dict(msssim=float(ms), msssim_db=float(db)))
         metrics.record_scalars(dict(rd_loss=float(rd_loss), bpp=float(bpp), mse=float(mse), psnr=float(psnr),
                                     scheduled_lr=self._scheduled_lr))
         return float(rd_loss), metrics
@@ -290,9 +305,11 @@ class Model:
             r = self._rate_and_reconstruction(self.infer_latent_rvs(x))
             sse, _ = ops.pixels_sse(x, r["recon"])
             host = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)]).cpu().numpy()
+            msssim = self._msssim(x, r["recon"])
         out = []
         for i in range(x.shape[0]):
-            _, m = self._finish_metrics((1,) + tuple(x.shape[1:]), host[0][i:i + 1], host[1][i:i + 1], host[2][i:i + 1])
+            _, m = self._finish_metrics((1,) + tuple(x.shape[1:]), host[0][i:i + 1], host[1][i:i + 1], host[2][i:i + 1],
+                                        None if msssim is None else msssim[i:i + 1])
             out.append(m.scalars_float)
         return out
 

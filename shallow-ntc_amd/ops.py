@@ -333,3 +333,55 @@ def adam_step(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-7):
     """In-place Keras Adam update of ``param`` (and its moments m, v); t is the 1-based step."""
     capi.call("sntc_adam_step", _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), float(lr), float(beta1),
               float(beta2), float(eps), int(t), _stream())
+
+
+# ------------------------------------------------------------------------------------------
+# SSIM / MS-SSIM (eval-only quality metrics)
+# ------------------------------------------------------------------------------------------
+MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def pixels_float(x_hat, h, w):
+    """crop + (v+.5)*255 + round-half-even + clamp, as float32 [n,h,w,c]."""
+    _check_nhwc(x_hat)
+    n, hs, ws, c = x_hat.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x_hat.device)
+    capi.call("sntc_pixels_float", _ptr(x_hat), n, h, w, c, hs, ws, _ptr(out), _stream())
+    return out
+
+
+def _ssim_scale(a, b, max_val, out):
+    """out: float64 [2, n, c] slice that receives the spatial sums of luminance*cs and of cs."""
+    n, h, w, c = a.shape
+    capi.call("sntc_ssim_scale", _ptr(a), _ptr(b), n, h, w, c, float(max_val), _ptr(out[0]), _ptr(out[1]), _stream())
+    return float((h - 10) * (w - 10))
+
+
+def _avgpool2(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float32, device=x.device)
+    capi.call("sntc_avgpool2_symmetric", _ptr(x), n, h, w, c, _ptr(y), _stream())
+    return y
+
+
+def image_quality(a, b, max_val=255.0):
+    """reference mshyper/models.py:321-331 on pixel-valued float images [n,h,w,c]: tf.image.ssim when both
+    sides are < 160, tf.image.ssim_multiscale otherwise.  -> per-image msssim as a float64 host array.
+    The kernels leave per-(image, channel) sums; the 5-factor geometric mean is finished on the host."""
+    _check_nhwc(a)
+    _check_nhwc(b, a.shape[-1])
+    n, h, w, c = a.shape
+    single = h < 160 and w < 160
+    scales = 1 if single else len(MSSSIM_WEIGHTS)
+    sums = torch.empty((scales, 2, n, c), dtype=torch.float64, device=a.device)
+    counts = []
+    for k in range(scales):
+        if k > 0:
+            a, b = _avgpool2(a), _avgpool2(b)
+        counts.append(_ssim_scale(a, b, max_val, sums[k]))
+    means = sums.cpu().numpy() / np.asarray(counts).reshape(-1, 1, 1, 1)        # [scales, 2, n, c]
+    if single:
+        return means[0, 0].mean(axis=-1)
+    factors = [np.maximum(means[k, 1], 0.0) for k in range(scales - 1)] + [np.maximum(means[-1, 0], 0.0)]
+    stack = np.stack(factors, axis=-1)                                          # [n, c, scales]
+    return np.prod(stack ** np.asarray(MSSSIM_WEIGHTS), axis=-1).mean(axis=-1)

@@ -125,6 +125,10 @@ def test_mshyper_model_parity(synth, dev):
     assert abs(m["bpp"] - ref["bpp"]) <= 1e-3 and abs(m["psnr"] - ref["psnr"]) <= 1e-2
     assert abs(m["rd_loss"] - (m["bpp"] + 0.02 * m["mse"])) < 1e-5   # results/readme.md identity
     assert abs(np.mean([d["psnr"] for d in per_image]) - m["psnr"]) < 1e-4
+    # eval JSON schema (common/eval_lib.py:92-102 rows carry msssim): 100 x 150 < 160 -> single-scale SSIM
+    from oracle import ops_np as O
+    q, qdb = O.image_quality(O.floats_to_pixels(x, False).astype(np.float64), ref["recon_pixels"].astype(np.float64))
+    assert abs(m["msssim"] - q.mean()) < 5e-4 and abs(m["msssim_db"] - qdb.mean()) < 5e-2
     # end to end against the oracle's own latents: same numbers up to the counted flips
     ref_e2e = ref_model.end_to_end(w, x)
     assert abs(m["bpp"] - ref_e2e["bpp"]) <= 2e-3 and abs(m["psnr"] - ref_e2e["psnr"]) <= 2e-2

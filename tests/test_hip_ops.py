@@ -288,3 +288,23 @@ def test_conv_family_fuzz(case, dev):
     got = ops.ConvPlan(kind, dev_t(wk, dev), dev_t(b, dev), s, act)(dev_t(x, dev)).cpu().numpy()
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= TOL * max(np.abs(ref).max(), 1.0)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 176, 200), (1, 161, 187), (2, 100, 120), (1, 512, 768), (1, 11, 40)])
+def test_ms_ssim(n, h, w, dev):
+    """tf.image.ssim / ssim_multiscale statistics (mshyper/models.py:321-331) against the float64 oracle,
+    incl. odd sizes (symmetric padding before the 2x2 average pool) and the < 160 single-scale branch."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(h + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.clip(np.rint(np.stack([128 + 70 * np.sin(xx / 11 + c) * np.cos(yy / 6 - c) for c in range(3)], -1)[None]
+                        + rng.normal(0, 6, size=(n, h, w, 3))), 0, 255).astype(np.float32)
+    b = np.clip(np.rint(a + rng.normal(0, 9, size=a.shape)), 0, 255).astype(np.float32)
+    ref, _ = O.image_quality(a, b)
+    got = ops.image_quality(dev_t(a, dev), dev_t(b, dev))
+    np.testing.assert_allclose(got, ref, rtol=3e-5)
+    # pixels_float == the uint8 quantiser, kept as float
+    x = (a / np.float32(255) - np.float32(0.5) + rng.normal(0, 0.01, size=a.shape)).astype(np.float32)
+    xp = np.pad(x, ((0, 0), (0, 5), (0, 3), (0, 0)))
+    np.testing.assert_array_equal(ops.pixels_float(dev_t(xp, dev), h, w).cpu().numpy(),
+                                  O.floats_to_pixels(x, False).astype(np.float32))

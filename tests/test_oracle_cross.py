@@ -121,3 +121,20 @@ def test_oracle_reproduces_model_fixture():
     # evaluate(): per-image generator (mshyper/models.py:415-433)
     outs = list(m.evaluate(p, np.concatenate([g["x"], g["x"]])))
     assert len(outs) == 2 and abs(outs[1]["bpp"] - float(g["bpp"])) < 1e-12
+
+
+@pytest.mark.parametrize("h,w", [(176, 200), (161, 185)])
+def test_ms_ssim_restatements_agree(h, w):
+    """float64 separable NumPy vs float32 torch (2-D softmax kernel, depthwise conv, replicate pad + avg_pool)."""
+    rng = np.random.default_rng(h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.clip(np.rint(np.stack([128 + 70 * np.sin(xx / 11 + c) * np.cos(yy / 6 - c) for c in range(3)], -1)[None]
+                        + rng.normal(0, 6, size=(2, h, w, 3))), 0, 255)
+    b = np.clip(np.rint(a + rng.normal(0, 9, size=a.shape)), 0, 255)
+    ref = O.ms_ssim(a, b)
+    assert ref.shape == (2,) and np.all(ref > 0.5) and np.all(ref < 1)
+    np.testing.assert_allclose(R.ms_ssim_torch(a, b), ref, rtol=2e-5)
+    np.testing.assert_allclose(O.ms_ssim(a, a), 1.0, atol=1e-12)
+    v, db = O.image_quality(a[:, :100, :120], b[:, :100, :120])          # both sides < 160: single-scale SSIM
+    np.testing.assert_allclose(v, O.ssim(a[:, :100, :120], b[:, :100, :120]))
+    np.testing.assert_allclose(db, -10 * np.log10(1 - v))
