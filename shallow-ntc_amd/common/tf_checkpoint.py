@@ -1,0 +1,534 @@
+"""TensorFlow checkpoint (TensorBundle) reader + the variable mapping of the reference's Model
+(reference common/eval_lib.py:11-53, common/train_lib.py:123-126).
+
+Pure Python + NumPy, no TensorFlow.  ``tf.train.Checkpoint(model=model).save`` writes
+
+    ckpt-N.index                 a LevelDB-format table: "" -> BundleHeaderProto, key -> BundleEntryProto
+    ckpt-N.data-00000-of-00001   raw little-endian tensor bytes at (offset, size)
+
+and one string tensor ``_CHECKPOINTABLE_OBJECT_GRAPH`` (a TrackableObjectGraph proto) that records the
+Python object graph; variables are addressed through it (``children`` by attribute name, Keras layers of
+a Sequential as ``layer_with_weights-i``), so the mapping below walks the *graph*, not key strings.
+
+STATUS: the container format (table blocks, varints, masked CRC32C, protos, string tensors) is implemented
+from its published layout and exercised on bundles written by ``write_bundle`` in this file; no checkpoint
+produced by TensorFlow itself was available in the build environment (no TF, no network, the trained
+checkpoints are an external download -- reference README.md:21,106).  ``load_reference_checkpoint`` fails
+loudly, listing the children it saw, wherever the object graph differs from what the reference source implies.
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+
+TABLE_MAGIC = 0xDB4775248B80FB57
+OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+VAR_SUFFIX = "/.ATTRIBUTES/VARIABLE_VALUE"
+DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 4: np.uint8, 5: np.int16, 6: np.int8, 9: np.int64, 10: np.bool_,
+          19: np.float16, 17: np.uint16, 22: np.uint32, 23: np.uint64}
+DT_STRING = 7
+_DT_OF = {np.dtype(v): k for k, v in DTYPES.items()}
+
+
+# ------------------------------------------------------------------------------------------ crc32c
+def _crc_table():
+    t = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        t.append(c)
+    return t
+
+
+_CRC = _crc_table()
+
+
+def crc32c(data: bytes, crc=0) -> int:
+    """CRC-32C (Castagnoli), byte-wise table walk (pure Python: ~1 MB/s, see read_bundle(verify_crc=...))."""
+    crc ^= 0xFFFFFFFF
+    tbl = _CRC
+    for b in data:
+        crc = tbl[(crc ^ b) & 0xFF] ^ (crc >> 8)
+    return crc ^ 0xFFFFFFFF
+
+
+def mask_crc(c: int) -> int:
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------ varints / protos
+def _get_varint(buf, pos):
+    r, shift = 0, 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        r |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return r, pos
+        shift += 7
+
+
+def _put_varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def parse_proto(buf) -> list:
+    """Minimal protobuf wire parser -> [(field, wire_type, value)]; length-delimited values stay bytes."""
+    out, pos = [], 0
+    while pos < len(buf):
+        tag, pos = _get_varint(buf, pos)
+        f, wt = tag >> 3, tag & 7
+        if wt == 0:
+            v, pos = _get_varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]
+            pos += 8
+        elif wt == 2:
+            ln, pos = _get_varint(buf, pos)
+            v = bytes(buf[pos:pos + ln])
+            pos += ln
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]
+            pos += 4
+        else:
+            raise ValueError(f"unsupported protobuf wire type {wt}")
+        out.append((f, wt, v))
+    return out
+
+
+def _field(f, wt, payload) -> bytes:
+    tag = _put_varint((f << 3) | wt)
+    if wt == 0:
+        return tag + _put_varint(payload)
+    if wt == 2:
+        return tag + _put_varint(len(payload)) + payload
+    if wt == 5:
+        return tag + struct.pack("<I", payload)
+    raise ValueError(wt)
+
+
+def _signed64(v):
+    return v - (1 << 64) if v >= 1 << 63 else v
+
+
+# ------------------------------------------------------------------------------------------ snappy (decode only)
+def snappy_decompress(buf: bytes) -> bytes:
+    n, pos = _get_varint(buf, 0)
+    out = bytearray()
+    while pos < len(buf):
+        tag = buf[pos]
+        pos += 1
+        kind = tag & 3
+        if kind == 0:
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(buf[pos:pos + nb], "little")
+                pos += nb
+            ln += 1
+            out += buf[pos:pos + ln]
+            pos += ln
+            continue
+        if kind == 1:
+            ln = ((tag >> 2) & 7) + 4
+            off = ((tag >> 5) << 8) | buf[pos]
+            pos += 1
+        elif kind == 2:
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(buf[pos:pos + 2], "little")
+            pos += 2
+        else:
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(buf[pos:pos + 4], "little")
+            pos += 4
+        for _ in range(ln):
+            out.append(out[-off])
+    if len(out) != n:
+        raise ValueError("snappy: length mismatch")
+    return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------ LevelDB table
+def _read_block(data: bytes, offset: int, size: int, verify=True) -> bytes:
+    raw = data[offset:offset + size]
+    ctype = data[offset + size]
+    stored = struct.unpack_from("<I", data, offset + size + 1)[0]
+    if verify and mask_crc(crc32c(raw + bytes([ctype]))) != stored:
+        raise ValueError("table block checksum mismatch")
+    if ctype == 0:
+        return raw
+    if ctype == 1:
+        return snappy_decompress(raw)
+    raise ValueError(f"unknown block compression {ctype}")
+
+
+def _block_entries(block: bytes):
+    nrestarts = struct.unpack_from("<I", block, len(block) - 4)[0]
+    limit = len(block) - 4 - 4 * nrestarts
+    pos, key = 0, b""
+    while pos < limit:
+        shared, pos = _get_varint(block, pos)
+        non_shared, pos = _get_varint(block, pos)
+        vlen, pos = _get_varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        yield key, block[pos:pos + vlen]
+        pos += vlen
+
+
+def read_table(path) -> "OrderedDict[bytes, bytes]":
+    data = Path(path).read_bytes()
+    if len(data) < 48 or struct.unpack_from("<Q", data, len(data) - 8)[0] != TABLE_MAGIC:
+        raise ValueError(f"{path}: not a TensorBundle index (bad table magic)")
+    footer = data[-48:]
+    _, p = _get_varint(footer, 0)            # metaindex handle (unused)
+    _, p = _get_varint(footer, p)
+    ioff, p = _get_varint(footer, p)
+    isize, p = _get_varint(footer, p)
+    out = OrderedDict()
+    for _, handle in _block_entries(_read_block(data, ioff, isize)):
+        boff, q = _get_varint(handle, 0)
+        bsize, _ = _get_varint(handle, q)
+        for k, v in _block_entries(_read_block(data, boff, bsize)):
+            out[k] = v
+    return out
+
+
+def _build_block(entries) -> bytes:
+    body = bytearray()
+    for k, v in entries:                        # restart interval 1: no prefix sharing, every entry is a restart
+        body += _put_varint(0) + _put_varint(len(k)) + _put_varint(len(v)) + k + v
+    restarts, pos = [], 0
+    for k, v in entries:
+        restarts.append(pos)
+        pos += len(_put_varint(0)) + len(_put_varint(len(k))) + len(_put_varint(len(v))) + len(k) + len(v)
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        body += struct.pack("<I", r)
+    body += struct.pack("<I", len(restarts))
+    return bytes(body)
+
+
+def write_table(path, items: "list[tuple[bytes, bytes]]", entries_per_block=16):
+    items = sorted(items)
+    out = bytearray()
+    index = []
+
+    def emit(block):
+        off = len(out)
+        out.extend(block)
+        out.append(0)
+        out.extend(struct.pack("<I", mask_crc(crc32c(block + b"\x00"))))
+        return off, len(block)
+
+    for i in range(0, len(items), entries_per_block):
+        chunk = items[i:i + entries_per_block]
+        off, size = emit(_build_block(chunk))
+        index.append((chunk[-1][0], _put_varint(off) + _put_varint(size)))
+    moff, msize = emit(_build_block([]))
+    ioff, isize = emit(_build_block(index))
+    footer = _put_varint(moff) + _put_varint(msize) + _put_varint(ioff) + _put_varint(isize)
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC)
+    out.extend(footer)
+    Path(path).write_bytes(bytes(out))
+
+
+# ------------------------------------------------------------------------------------------ bundle
+def _parse_entry(buf):
+    e = dict(dtype=0, shape=[], shard=0, offset=0, size=0, crc=None)
+    for f, wt, v in parse_proto(buf):
+        if f == 1:
+            e["dtype"] = v
+        elif f == 2:
+            for f2, _, v2 in parse_proto(v):
+                if f2 == 2:
+                    dim = dict((a, c) for a, _, c in parse_proto(v2))
+                    e["shape"].append(_signed64(dim.get(1, 0)))
+        elif f == 3:
+            e["shard"] = v
+        elif f == 4:
+            e["offset"] = v
+        elif f == 5:
+            e["size"] = v
+        elif f == 6:
+            e["crc"] = v
+        elif f == 7:
+            raise NotImplementedError("sliced (partitioned) variables are not used by the reference")
+    return e
+
+
+def read_bundle(prefix, verify_crc="auto") -> "OrderedDict[str, np.ndarray | bytes]":
+    """{key: ndarray} for every tensor of the checkpoint ``prefix`` (e.g. '.../checkpoints/ckpt-180');
+    string tensors come back as bytes (scalar) or lists of bytes.  verify_crc: True = every tensor, "auto" =
+    tensors up to 64 KiB (the pure-Python CRC is slow; table blocks are always verified), False = none."""
+    prefix = str(prefix)
+    table = read_table(prefix + ".index")
+    header = dict((f, v) for f, _, v in parse_proto(table.get(b"", b"")))
+    num_shards = header.get(1, 1)
+    if header.get(2, 0) != 0:
+        raise NotImplementedError("big-endian bundles")
+    shards = {}
+    out = OrderedDict()
+    for key, val in table.items():
+        if key == b"":
+            continue
+        e = _parse_entry(val)
+        if e["shard"] not in shards:
+            shards[e["shard"]] = Path(f"{prefix}.data-{e['shard']:05d}-of-{num_shards:05d}").read_bytes()
+        raw = shards[e["shard"]][e["offset"]:e["offset"] + e["size"]]
+        if len(raw) != e["size"]:
+            raise ValueError(f"{key!r}: data shard is truncated")
+        name = key.decode()
+        if e["dtype"] == DT_STRING:
+            n = int(np.prod(e["shape"])) if e["shape"] else 1
+            pos, lens = 0, []
+            for _ in range(n):
+                ln, pos = _get_varint(raw, pos)
+                lens.append(ln)
+            pos += 4                                        # masked crc32c of the length varints
+            strs = []
+            for ln in lens:
+                strs.append(bytes(raw[pos:pos + ln]))
+                pos += ln
+            out[name] = strs[0] if not e["shape"] else strs
+            continue
+        if e["dtype"] not in DTYPES:
+            raise NotImplementedError(f"{name}: DataType {e['dtype']}")
+        check = verify_crc is True or (verify_crc == "auto" and len(raw) <= 65536)
+        if check and e["crc"] is not None and mask_crc(crc32c(raw)) != e["crc"]:
+            raise ValueError(f"{name}: tensor checksum mismatch")
+        out[name] = np.frombuffer(raw, dtype=np.dtype(DTYPES[e["dtype"]]).newbyteorder("<")).reshape(e["shape"]).copy()
+    return out
+
+
+def write_bundle(prefix, tensors: dict):
+    """Writer used by the tests to hand-build bundles (single shard, no compression)."""
+    prefix = str(prefix)
+    data = bytearray()
+    items = [(b"", _field(1, 0, 1) + _field(3, 2, _field(1, 0, 1)))]      # num_shards = 1, version.producer = 1
+    for name in sorted(tensors):
+        v = tensors[name]
+        off = len(data)
+        if isinstance(v, (bytes, str)):
+            b = v.encode() if isinstance(v, str) else v
+            lens = _put_varint(len(b))
+            data += lens + struct.pack("<I", mask_crc(crc32c(lens))) + b
+            entry = _field(1, 0, DT_STRING) + _field(2, 2, b"") + _field(4, 0, off) + _field(5, 0, len(data) - off)
+            entry += _field(6, 5, mask_crc(crc32c(bytes(data[off:]))))
+        else:
+            a = np.asarray(v)                    # (ascontiguousarray would turn a scalar into shape (1,))
+            raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
+            data += raw
+            shape = b"".join(_field(2, 2, _field(1, 0, int(d))) for d in a.shape)
+            entry = _field(1, 0, _DT_OF[a.dtype]) + _field(2, 2, shape) + _field(4, 0, off) + _field(5, 0, len(raw))
+            entry += _field(6, 5, mask_crc(crc32c(raw)))
+        items.append((name.encode(), entry))
+    write_table(prefix + ".index", items)
+    Path(prefix + ".data-00000-of-00001").write_bytes(bytes(data))
+
+
+# ------------------------------------------------------------------------------------------ object graph
+class ObjectGraph:
+    """TrackableObjectGraph: nodes[i] = (children {local_name: node_id}, attributes {name: checkpoint_key})."""
+
+    def __init__(self, blob: bytes):
+        self.children, self.attrs = [], []
+        for f, _, node in parse_proto(blob):
+            if f != 1:
+                continue
+            ch, at = OrderedDict(), OrderedDict()
+            for f2, _, v in parse_proto(node):
+                if f2 == 1:
+                    d = dict((a, c) for a, _, c in parse_proto(v))
+                    ch[d.get(2, b"").decode()] = d.get(1, 0)
+                elif f2 == 2:
+                    d = dict((a, c) for a, _, c in parse_proto(v))
+                    at[d.get(1, b"").decode()] = d.get(3, b"").decode()
+            self.children.append(ch)
+            self.attrs.append(at)
+
+    def child(self, node, *names):
+        """Follow the first existing local name among ``names`` (alternatives for private/public spellings)."""
+        for n in names:
+            if n in self.children[node]:
+                return self.children[node][n]
+        raise KeyError(f"none of {names} among children {list(self.children[node])} of node {node}")
+
+    def has(self, node, name):
+        return name in self.children[node]
+
+    def path(self, node, *path):
+        for p in path:
+            node = self.child(node, *(p if isinstance(p, tuple) else (p,)))
+        return node
+
+    def variable_key(self, node):
+        at = self.attrs[node]
+        if "VARIABLE_VALUE" not in at:
+            raise KeyError(f"node {node} is not a variable (attributes {list(at)}, children {list(self.children[node])})")
+        return at["VARIABLE_VALUE"]
+
+    def layers_with_weights(self, node):
+        out, i = [], 0
+        while f"layer_with_weights-{i}" in self.children[node]:
+            out.append(self.children[node][f"layer_with_weights-{i}"])
+            i += 1
+        return out
+
+    @staticmethod
+    def serialize(nodes) -> bytes:
+        """nodes: list of (children {name: id}, attributes {name: checkpoint_key}) -> proto bytes (tests)."""
+        out = b""
+        for ch, at in nodes:
+            body = b"".join(_field(1, 2, _field(1, 0, i) + _field(2, 2, n.encode())) for n, i in ch.items())
+            body += b"".join(_field(2, 2, _field(1, 2, n.encode()) + _field(3, 2, k.encode())) for n, k in at.items())
+            out += _field(1, 2, body)
+        return out
+
+
+# ------------------------------------------------------------------------------------------ TFC re-parameterisations
+GDN_PEDESTAL = 2.0 ** -36                    # tfc GDNParameter: offset = 2^-18, pedestal = offset^2
+
+
+def gdn_parameter_value(variable, minimum):
+    """tfc.layers.GDNParameter: value = max(variable, sqrt(minimum + pedestal))^2 - pedestal
+    (beta: minimum 1e-6, gamma: minimum 0)."""
+    v = np.asarray(variable, np.float64)
+    bound = np.sqrt(minimum + GDN_PEDESTAL)
+    return (np.maximum(v, bound) ** 2 - GDN_PEDESTAL).astype(np.float32)
+
+
+def gdn_parameter_variable(value):
+    """Inverse (what TFC stores for a given effective value): sqrt(max(value + pedestal, pedestal))."""
+    return np.sqrt(np.maximum(np.asarray(value, np.float64) + GDN_PEDESTAL, GDN_PEDESTAL)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ reference Model mapping
+class CheckpointMapper:
+    """Collects {our variable name: ndarray} by walking the object graph the way the reference's classes are
+    written (attribute names from reference common/elic.py, common/transforms.py, mshyper/models.py)."""
+
+    def __init__(self, tensors, graph: ObjectGraph):
+        self.t, self.g = tensors, graph
+        self.out = OrderedDict()
+
+    def var(self, node):
+        return self.t[self.g.variable_key(node)]
+
+    def conv(self, node, name, bias=True):
+        self.out[f"{name}/kernel"] = self.var(self.g.child(node, "kernel"))
+        if bias:
+            self.out[f"{name}/bias"] = self.var(self.g.child(node, "bias"))
+
+    def residual_block(self, node, name):                     # elic.py:57-64: self._block = Sequential([...])
+        convs = self.g.layers_with_weights(self.g.child(node, "_block"))
+        if len(convs) != 3:
+            raise KeyError(f"{name}: expected 3 convolutions in a ResidualBlock, found {len(convs)}")
+        for i, c in enumerate(convs):
+            self.conv(c, f"{name}/conv{i}")
+
+    def attention(self, node, name):                          # elic.py:83-95
+        for i, rb in enumerate(self.g.layers_with_weights(self.g.child(node, "_trunk"))):
+            self.residual_block(rb, f"{name}/trunk/rb{i}")
+        branch = self.g.layers_with_weights(self.g.child(node, "_attention_branch"))
+        for i, rb in enumerate(branch[:-1]):
+            self.residual_block(rb, f"{name}/branch/rb{i}")
+        self.conv(branch[-1], f"{name}/branch/conv")
+
+    def elic_analysis(self, node, prefix):                    # elic.py:141-163
+        seq = self.g.layers_with_weights(self.g.child(node, "_transform"))
+        nconv = nrb = natt = 0
+        for layer in seq:
+            if self.g.has(layer, "_block"):
+                self.residual_block(layer, f"{prefix}rb{nrb}")
+                nrb += 1
+            elif self.g.has(layer, "_trunk"):
+                self.attention(layer, f"{prefix}attn{natt}")
+                natt += 1
+            else:
+                self.conv(layer, f"{prefix}conv{nconv}")
+                nconv += 1
+
+    def sequential_convs(self, node, prefix, names):          # HyperAnalysis / HyperSynthesis / CNN* (transforms.py:179-232)
+        layers = self.g.layers_with_weights(node)
+        if len(layers) != len(names):
+            raise KeyError(f"{prefix}: expected {len(names)} layers with weights, found {len(layers)}")
+        for layer, n in zip(layers, names):
+            self.conv(layer, prefix + n)
+
+    def gdn1(self, node, name):                                # tfc.GDN with trainable beta / gamma GDNParameters
+        beta = self.g.path(node, ("beta_parameter", "_beta_parameter", "beta"), "variable")
+        gamma = self.g.path(node, ("gamma_parameter", "_gamma_parameter", "gamma"), "variable")
+        self.out[f"{name}/beta"] = gdn_parameter_value(self.var(beta), 1e-6)
+        self.out[f"{name}/gamma"] = gdn_parameter_value(self.var(gamma), 0.0)
+
+    def two_layer_res(self, node, prefix):                    # transforms.py:331-357
+        self.conv(self.g.child(node, "base_conv"), prefix + "base_conv")
+        self.conv(self.g.child(node, "res"), prefix + "res")
+        self.conv(self.g.child(node, "out_conv"), prefix + "out_conv")
+        if self.g.has(node, "activation"):
+            self.gdn1(self.g.child(node, "activation"), prefix + "act")
+
+    def two_layer(self, node, prefix):                        # transforms.py:307-313
+        self.conv(self.g.child(node, "conv1"), prefix + "conv1")
+        self.conv(self.g.child(node, "conv2"), prefix + "conv2")
+        c1 = self.g.child(node, "conv1")
+        if self.g.has(c1, "activation"):
+            self.gdn1(self.g.child(c1, "activation"), prefix + "act")
+
+    def jpeg_like(self, node, prefix):                        # transforms.py:284-287
+        self.conv(self.g.child(node, "conv"), prefix + "conv")
+
+    def deep_factorized(self, node):                          # tfc NoisyDeepFactorized -> base DeepFactorized lists
+        base = self.g.child(node, "_base", "base") if (self.g.has(node, "_base") or self.g.has(node, "base")) else node
+        for kind, ours in (("_matrices", "matrix"), ("_biases", "bias"), ("_factors", "factor")):
+            lst = self.g.child(base, kind, kind.lstrip("_"))
+            i = 0
+            while self.g.has(lst, str(i)):
+                v = self.var(self.g.child(lst, str(i)))
+                self.out[f"prior/{ours}_{i}"] = v.reshape(v.shape[0], v.shape[1]) if (ours != "matrix" and v.ndim == 3) else v
+                i += 1
+
+
+SYNTHESIS_MAPPERS = {"TwoLayerResSynthesis": "two_layer_res", "TwoLayerSynthesis": "two_layer", "JPEGLikeSynthesis": "jpeg_like"}
+
+
+def load_reference_checkpoint(prefix, transform_config):
+    """-> flat {name: ndarray} accepted by ``Model.set_weights`` for a checkpoint written by the reference's
+    training loop (``tf.train.Checkpoint(model=model)``, common/train_lib.py:123-126) for the mean-scale
+    hyperprior model with an ELIC / CNN analysis and a two-layer / JPEG-like synthesis."""
+    tensors = read_bundle(prefix)
+    if OBJECT_GRAPH_KEY not in tensors:
+        raise KeyError(f"{prefix}: no {OBJECT_GRAPH_KEY}; not an object-based checkpoint")
+    g = ObjectGraph(tensors[OBJECT_GRAPH_KEY])
+    m = CheckpointMapper(tensors, g)
+    model = g.child(0, "model")
+    a_cls = transform_config["analysis"]["cls"]
+    ana = g.child(model, "_analysis")
+    if a_cls == "ElicAnalysis":
+        m.elic_analysis(ana, "analysis/")
+    elif a_cls == "CNNAnalysis":
+        m.sequential_convs(ana, "analysis/", [f"layer_{i}" for i in range(4)])
+    else:
+        raise NotImplementedError(f"checkpoint import for analysis {a_cls} (SignalConv2D stores an RDFT-parameterised kernel)")
+    s_cls = transform_config["synthesis"]["cls"]
+    if s_cls not in SYNTHESIS_MAPPERS:
+        raise NotImplementedError(f"checkpoint import for synthesis {s_cls}")
+    getattr(m, SYNTHESIS_MAPPERS[s_cls])(g.child(model, "_synthesis"), "synthesis/")
+    m.sequential_convs(g.child(model, "_hyper_analysis"), "hyper_analysis/", ["layer_0", "layer_1", "layer_2"])
+    m.sequential_convs(g.child(model, "_hyper_synthesis"), "hyper_synthesis/", ["layer_0", "layer_1", "layer_2"])
+    m.deep_factorized(g.child(model, "_prior"))
+    return m.out

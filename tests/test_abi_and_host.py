@@ -128,3 +128,31 @@ def test_sga_schedule_and_data_helpers():
     x = data_lib.normalize_image(img)
     assert x.dtype == np.float32 and x.min() >= -0.5 and x.max() <= 0.5
     np.testing.assert_array_equal(np.rint(data_lib.unnormalize_image(x)).astype(np.uint8), img)
+
+
+def test_eval_lib_runname_and_rows():
+    """reference common/utils.py:159-169 docstring examples + eval_lib.py:92-102 row schema."""
+    from shallow_ntc_amd.common import eval_lib
+    from shallow_ntc_amd.common.train_lib import Metrics
+    assert list(eval_lib.parse_runname("dir-lamb=2-arch=2_4_8/tau=1.0-step=0-kerasckpt").items()) == \
+        [("lamb", "2"), ("arch", "2_4_8"), ("tau", "1.0"), ("step", "0")]
+    p = eval_lib.parse_runname("rd-ms2020-latent_depth=320-lmbda=1e-06-dataset=basenji-bpp=0.000-psnr=19.875.npz", True)
+    assert p["latent_depth"] == 320 and p["lmbda"] == 1e-06 and p["dataset"] == "basenji" and p["psnr"] == 19.875
+    assert eval_lib.parse_runname("k1=13-arch=2_4_8", True)["arch"] == (2, 4, 8)
+    m = Metrics.make()
+    m.record_scalars(dict(bpp=0.5, psnr=30.0, mse=65.0, rd_loss=0.825))
+    rows = eval_lib.results_rows([m, m], "mshyper-rd_lambda=0.005-bottleneck_size=320")
+    assert rows[1]["instance_id"] == 1 and rows[0]["rd_lambda"] == 0.005 and rows[0]["bottleneck_size"] == 320
+    pub = json.loads((ROOT / "tests" / "golden" / "published_rows.json").read_text())["2-layer_syn"][0]
+    assert set(pub) <= set(rows[0]) | {"msssim", "lpips"}            # published rows carry the same keys (+ metrics)
+
+
+def test_latest_checkpoint_resolution(tmp_path):
+    from shallow_ntc_amd.common import eval_lib
+    d = tmp_path / "train" / "checkpoints"
+    d.mkdir(parents=True)
+    for n in (9, 10):
+        (d / f"ckpt-{n}.index").write_bytes(b"")
+    assert eval_lib.latest_checkpoint(d).name == "ckpt-10"
+    (d / "checkpoint").write_text('model_checkpoint_path: "ckpt-9"\nall_model_checkpoint_paths: "ckpt-9"\n')
+    assert eval_lib.latest_checkpoint(d).name == "ckpt-9"

@@ -168,3 +168,34 @@ def test_factorized_model_parity(dev):
     assert abs(m["bpp"] - ref["bpp"]) <= 1e-4 and abs(m["psnr"] - ref["psnr"]) <= 1e-3
     # lambda warm-up (mshyper/models.py:168-184): rd_lambda <= 0.01 is scaled x10 at step 0
     assert abs(m["sched_rd_lambda"] - 0.1) < 1e-9
+
+
+def test_eval_workdir_from_checkpoint(tmp_path, dev):
+    """reference eval.py flow: workdir/config.json + train/checkpoints/ckpt-N (TensorBundle) -> Model ->
+    evaluate -> per-image results JSON; the numbers equal evaluating the in-memory model."""
+    import json
+    from shallow_ntc_amd.common import data_lib, eval_lib
+    from shallow_ntc_amd.mshyper.models import Model
+    from test_tf_checkpoint import _reference_like_checkpoint
+    tc = _small_cfg(dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5),
+                         activation_type="igdn", res_type="conv"))
+    cfg = dict(rd_lambda=0.02, transform_config=tc)
+    model = Model(device=dev, **cfg)
+    w = randomize(model.get_weights(), np.random.default_rng(4))
+    model.set_weights(w)
+    workdir = tmp_path / "4242" / "wid=3-mshyper-rd_lambda=0.02-bottleneck_size=64"
+    ckdir = workdir / "train" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    (workdir / "config.json").write_text(json.dumps(dict(model_config=cfg)))
+    prefix = _reference_like_checkpoint(ckdir, w)
+    (ckdir / "checkpoint").write_text(f'model_checkpoint_path: "{prefix.name}"\n')
+    x = data_lib.normalize_image(data_lib.synthetic_images(2, 64, 128, seed=6))
+    out = eval_lib.eval_workdir(workdir, x, tmp_path / "results", device=dev)
+    assert out.name == "mshyper-rd_lambda=0.02-bottleneck_size=64-step=  3-xid=4242.json"
+    rows = json.loads(out.read_text())
+    model._step = 3
+    want = [m.scalars_float for m in model.evaluate(x)]
+    assert len(rows) == 2 and rows[1]["instance_id"] == 1 and rows[0]["rd_lambda"] == 0.02 and rows[0]["bottleneck_size"] == 64
+    for r, wnt in zip(rows, want):
+        for k in ("bpp", "psnr", "mse", "msssim"):
+            assert abs(r[k] - wnt[k]) <= 1e-6 * max(1.0, abs(wnt[k])), k
