@@ -101,7 +101,12 @@ int64_t sntc_conv_flops(const sntc_conv_plan* plan, int n, int h, int w);
 /* y[n,ho,wo,cout] = epilogue(act(conv(prologue(x[n,h,w,cin])) + bias), res, aux).
  * res / aux are NHWC tensors of the OUTPUT shape (NULL unless the epilogue uses them). */
 int sntc_conv_forward(const sntc_conv_plan* plan, const float* x, int n, int h, int w, float* y,
-                      const float* res, const float* aux, void* stream);
+                      const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream);
+/* Device scratch the call above needs (0 for most shapes).  Layers that offer few output tiles per image but a
+ * long contraction (hyper transforms, SGA input-gradient convolutions) are split along K into slabs that a second
+ * kernel adds in a fixed order; the split depends on the layer and the image shape only, so results are
+ * bit-identical for any batch size. */
+int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int w);
 /* Tile-selection override for experiments: 0 = heuristic. Returns previous value. */
 int sntc_conv_set_tile_override(int variant);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64) the heuristic picks for this call shape,

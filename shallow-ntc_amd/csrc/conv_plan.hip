@@ -268,23 +268,57 @@ static int pick_variant(const sntc_conv_plan* p, int64_t M) {
   return bestv;
 }
 
+// Deterministic split-K factor: a function of the layer and the per-image geometry only (never of the
+// batch size), so a given image gets bit-identical results alone or inside any batch.  Used where one
+// image offers few output tiles but a long K loop (hyper transforms, SGA input-gradient convolutions).
+static int pick_ksplit(const sntc_conv_plan* p, const Geo& g) {
+  int steps_min = 1 << 30, steps_max = 0;
+  int64_t bpi = 0;
+  const int64_t mt = ((int64_t)g.Qh * g.Qw + 127) / 128;
+  for (int gi = 0; gi < p->ngroups; ++gi) {
+    const int steps = p->g[gi].K / 32;
+    steps_min = std::min(steps_min, steps);
+    steps_max = std::max(steps_max, steps);
+    bpi += mt * ((p->g[gi].Ncol + 63) / 64);
+  }
+  if (steps_max < 64 || bpi > 32) return 1;
+  const int want = (int)((128 + bpi - 1) / bpi);
+  return std::max(1, std::min({8, want, std::max(1, steps_min / 8)}));
+}
+
+static int64_t workspace_floats(const sntc_conv_plan* p, int64_t M, int ksplit) {
+  if (ksplit <= 1) return 0;
+  int64_t cols = 0;
+  for (int gi = 0; gi < p->ngroups; ++gi) cols += p->g[gi].Ncol;
+  return (int64_t)ksplit * M * cols;
+}
+
+extern "C" int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* p, int n, int h, int w) {
+  if (!p) return 0;
+  Geo g;
+  if (geometry(p, h, w, &g)) return 0;
+  return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, pick_ksplit(p, g));
+}
+
 extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int w, int* variant, int* nblocks) {
   if (!p || !variant || !nblocks) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_launch_info: null argument");
   Geo g;
   int rc = geometry(p, h, w, &g);
   if (rc) return rc;
   const int64_t M = (int64_t)n * g.Qh * g.Qw;
-  const int v = pick_variant(p, M);
+  const int ksplit = pick_ksplit(p, g);
+  const int v = pick_variant(p, M * ksplit);
   const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
   int64_t nb = 0;
-  for (int gi = 0; gi < p->ngroups; ++gi) nb += (int64_t)((p->g[gi].Ncol + bn - 1) / bn) * ((M + bm - 1) / bm);
+  for (int gi = 0; gi < p->ngroups; ++gi) nb += (int64_t)((p->g[gi].Ncol + bn - 1) / bn) * ((M + bm - 1) / bm) * ksplit;
   *variant = v;
   *nblocks = (int)nb;
   return SNTC_OK;
 }
 
 extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n, int h, int w, float* y,
-                                 const float* res, const float* aux, void* stream) {
+                                 const float* res, const float* aux, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: null argument");
   if (n < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: empty batch");
   const sntc_conv_desc& d = p->d;
@@ -297,9 +331,15 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   const int64_t x_bytes = (int64_t)n * h * w * d.cin * 4;
   if (M > 0x7fffffffLL || x_bytes >= (1LL << 31))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: input tensor must be < 2 GiB (32-bit buffer offsets); split the batch");
-  const int v = pick_variant(p, M);
+  const int ksplit = pick_ksplit(p, g);
+  const int64_t ws_floats = workspace_floats(p, M, ksplit);
+  if (ws_floats > 0 && (!workspace || workspace_bytes < (size_t)ws_floats * 4))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: this call needs sntc_conv_workspace_bytes() of workspace (split-K)");
+  const int v = pick_variant(p, M * ksplit);      // the split multiplies the number of workgroups
   const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
   GGArgs a{};
+  a.ksplit = ksplit;
+  a.slab = static_cast<float*>(workspace);
   a.x = x; a.y = y; a.bias = p->bias; a.res = res; a.aux = aux;
   a.x_bytes = (unsigned)x_bytes;
   a.N = n; a.H = h; a.W = w; a.Cin = d.cin;
@@ -310,13 +350,18 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   a.ntm = (int)((M + bm - 1) / bm);
   a.ngroups = p->ngroups;
   int nb = 0;
+  size_t slab_off = 0;
   for (int gi = 0; gi < p->ngroups; ++gi) {
     GGGroup& G = a.g[gi];
     G.wp = p->g[gi].wp; G.taps = p->g[gi].taps; G.cols = reinterpret_cast<const int*>(p->g[gi].cols);
     G.T = p->g[gi].T; G.K = p->g[gi].K; G.Ncol = p->g[gi].Ncol;
     G.ntn = (G.Ncol + bn - 1) / bn;
     G.blk0 = nb;
-    nb += G.ntn * a.ntm;
+    nb += G.ntn * a.ntm * ksplit;
+    G.slab_off = slab_off;
+    slab_off += (size_t)ksplit * M * G.Ncol;
   }
-  return gg_launch(v, p->vec, a, nb, (hipStream_t)stream);
+  rc = gg_launch(v, p->vec, a, nb, (hipStream_t)stream);
+  if (rc || ksplit <= 1) return rc;
+  return gg_reduce_launch(a, (hipStream_t)stream);
 }

@@ -17,6 +17,7 @@
 //   the current one.  Per lane a ds_read_b128 fetches k = 8g+4h..8g+4h+3 (h = lane>>5): MFMA j of
 //   k-group g sums k in {8g+j, 8g+4+j}; A and B use the same permutation, so the products pair up.
 //   C/D layout: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+#include <algorithm>
 #include "sntc_internal.h"
 
 namespace sntc {
@@ -63,7 +64,9 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   for (int i = 1; i < kMaxGroups; ++i)
     if (i < a.ngroups && (int)blockIdx.x >= a.g[i].blk0) gi = i;
   const GGGroup G = a.g[gi];
-  const int lb = blockIdx.x - G.blk0;
+  const int lb0 = blockIdx.x - G.blk0;
+  const int split = lb0 % a.ksplit;          // K range of this block (deterministic split-K)
+  const int lb = lb0 / a.ksplit;
   const int mt = lb % a.ntm;
   const int nt = lb / a.ntm;
   const int m0 = mt * BM;
@@ -106,10 +109,14 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   const __amdgpu_buffer_rsrc_t ws =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 4, 0x00020000);
 
-  const int nsteps = G.K >> 5;
+  const int nsteps_all = G.K >> 5;
+  const int ks0 = (int)(((long long)split * nsteps_all) / a.ksplit);
+  const int ks1 = (int)(((long long)(split + 1) * nsteps_all) / a.ksplit);
+  const int nsteps = ks1 - ks0;
   const int ncc = VEC ? (a.Cin >> 5) : 1;
   const int ktrue = G.T * a.Cin;
-  int ld_t = 0, ld_cc = 0, ld_step = 0;
+  int ld_step = ks0;
+  int ld_t = VEC ? ks0 / ncc : 0, ld_cc = VEC ? ks0 % ncc : 0;
   unsigned a_off[A_CH];
 
   auto set_tap = [&](int t) {
@@ -124,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
       a_off[i] = ok ? a_img[i] + pix : kOutOfRange;
     }
   };
-  if (VEC && G.T > 0) set_tap(0);
+  if (VEC && ld_t < G.T) set_tap(ld_t);
 
   f32x4 ra[A_CH], rb[B_CH];
   auto load_regs = [&]() {
@@ -234,6 +241,24 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   // slice (the staging buffers are dead after the last barrier) so that every lane owns 4
   // consecutive channels of one pixel: bias / residual / gate operands are read and the output is
   // written with 16-B accesses, 256 contiguous bytes per 16 lanes.
+  if (a.ksplit > 1) {
+    // split-K: raw partial sums go to slab[group][split][m][col]; gg_reduce_kernel adds the splits in a
+    // fixed order and applies bias / activation / epilogue, so the result does not depend on scheduling.
+    float* slab = a.slab + G.slab_off + (size_t)split * a.M * G.Ncol;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= G.Ncol) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < a.M) slab[(size_t)m * G.Ncol + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   if ((a.Cout & 3) == 0) {
     static_assert(TM == 1, "wide epilogue assumes one M tile per wave");
     float* stage = reinterpret_cast<float*>(smem) + wave * 2048;   // 32 rows x 64 floats
@@ -341,6 +366,52 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
       }
     }
   }
+}
+
+// Split-K finish: y = epilogue(act(sum_{s = 0..S-1} slab[g][s][m][col] + bias)), splits added in index
+// order (deterministic; the K ranges depend only on the layer and the image shape, never on the batch).
+__global__ void __launch_bounds__(256) gg_reduce_kernel(const GGArgs a) {
+  const GGGroup G = a.g[blockIdx.y];
+  const size_t total = (size_t)a.M * G.Ncol;
+  const int per = a.Qh * a.Qw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / G.Ncol);
+    const int col = (int)(i - (size_t)m * G.Ncol);
+    float v = 0.0f;
+    for (int sp = 0; sp < a.ksplit; ++sp) v += a.slab[G.slab_off + (size_t)sp * total + i];
+    const unsigned ce = G.cols[col];
+    const int ch = ce & 0xffff;
+    const int n = m / per;
+    const int rem = m - n * per;
+    const int qy = rem / a.Qw, qx = rem - qy * a.Qw;
+    const int oy = qy * a.sO + (int)((ce >> 24) & 0xff) - 128;
+    const int ox = qx * a.sO + (int)((ce >> 16) & 0xff) - 128;
+    if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
+    const size_t idx = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
+    v = apply_act(v + (a.bias ? a.bias[ch] : 0.0f), a.act);
+    switch (a.epi) {
+      case SNTC_EPI_ADD: v = v + a.res[idx]; break;
+      case SNTC_EPI_GATE: v = a.res[idx] + a.aux[idx] * v; break;
+      case SNTC_EPI_RES_DIV: v = a.res[idx] / v; break;
+      case SNTC_EPI_RES_MUL: v = a.res[idx] * v; break;
+      case SNTC_EPI_RES_DIV_SQRT: v = a.res[idx] / sqrtf(v); break;
+      case SNTC_EPI_RES_MUL_SQRT: v = a.res[idx] * sqrtf(v); break;
+      case SNTC_EPI_MASK_RELU: v = a.res[idx] > 0.0f ? v : 0.0f; break;
+      case SNTC_EPI_MASK_LEAKY: v = a.res[idx] >= 0.0f ? v : 0.2f * v; break;
+      default: break;
+    }
+    a.y[idx] = v;
+  }
+}
+
+int gg_reduce_launch(const GGArgs& args, hipStream_t stream) {
+  size_t most = 0;
+  for (int gi = 0; gi < args.ngroups; ++gi) most = std::max(most, (size_t)args.M * args.g[gi].Ncol);
+  int blocks = (int)std::min<size_t>((most + 255) / 256, 2048);
+  hipLaunchKernelGGL(gg_reduce_kernel, dim3(blocks, args.ngroups), dim3(256), 0, stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "split-K reduce launch");
+  return SNTC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct GGGroup {
   int Ncol;           // real columns
   int ntn;            // N tiles for the launched variant
   int blk0;           // first block of this group
+  size_t slab_off;    // float offset of this group's split-K slabs [ksplit][M][Ncol]
 };
 
 struct GGArgs {
@@ -51,6 +52,8 @@ struct GGArgs {
   int sA, tstep, offy, offx, sO;
   int act, epi, pro;
   int ntm;
+  int ksplit;          // >= 1: number of K ranges (blocks per tile)
+  float* slab;         // split-K partial sums (workspace) or nullptr
   int ngroups;
   GGGroup g[kMaxGroups];
 };
@@ -60,6 +63,7 @@ constexpr int kNumVariants = 8;
 int gg_variant_bm(int v);
 int gg_variant_bn(int v);
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream);
+int gg_reduce_launch(const GGArgs& args, hipStream_t stream);
 int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent)
 
 // ---- deep-factorized prior (entropy.hip, sga.hip) ----

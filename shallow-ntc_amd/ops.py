@@ -109,7 +109,9 @@ class ConvPlan:
         if prof is not None:     # bench.py: HIP events on the launch stream around this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        capi.call("sntc_conv_forward", self._h, _ptr(x), n, h, w, _ptr(y), _ptr(res), _ptr(aux), _stream())
+        ws_bytes = int(capi.load().sntc_conv_workspace_bytes(self._h, n, h, w))
+        ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=x.device) if ws_bytes else None
+        capi.call("sntc_conv_forward", self._h, _ptr(x), n, h, w, _ptr(y), _ptr(res), _ptr(aux), _ptr(ws), ws_bytes, _stream())
         if prof is not None:
             e1.record()
             v, nb = self.launch_info(n, h, w)

@@ -126,7 +126,7 @@ def test_batches_beyond_the_32bit_offset_limit_are_split(dev):
         assert torch.equal(y[i:i + 1], plan(x[i:i + 1].contiguous()))
     from shallow_ntc_amd import _capi
     with pytest.raises(_capi.SntcError):                        # the C ABI itself refuses instead of wrapping around
-        _capi.call("sntc_conv_forward", plan._h, ops._ptr(x), 8, 512, 768, ops._ptr(y), None, None, ops._stream())
+        _capi.call("sntc_conv_forward", plan._h, ops._ptr(x), 8, 512, 768, ops._ptr(y), None, None, None, 0, ops._stream())
 
 
 def test_edge_shapes(dev):

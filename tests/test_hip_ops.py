@@ -308,3 +308,28 @@ def test_ms_ssim(n, h, w, dev):
     xp = np.pad(x, ((0, 0), (0, 5), (0, 3), (0, 0)))
     np.testing.assert_array_equal(ops.pixels_float(dev_t(xp, dev), h, w).cpu().numpy(),
                                   O.floats_to_pixels(x, False).astype(np.float32))
+
+
+@pytest.mark.parametrize("kind,k,s,cin,cout,h,w,act", [("conv", 5, 2, 320, 320, 16, 24, "relu"), ("conv", 5, 2, 480, 320, 32, 48, None),
+                                                       ("convT", 5, 2, 320, 320, 8, 12, "relu"), ("conv", 3, 1, 256, 40, 6, 5, None)])
+def test_split_k_layers(kind, k, s, cin, cout, h, w, act, dev):
+    """Few output tiles per image + a long contraction -> deterministic split-K (workspace slabs added in a
+    fixed order).  Same oracle tolerance, and a batch gives bit-identical rows to single-image calls."""
+    from shallow_ntc_amd import _capi, ops
+    rng = np.random.default_rng(k * cin + cout)
+    wshape = (k, k, cout, cin) if kind == "convT" else (k, k, cin, cout)
+    wk = (rng.standard_normal(wshape) / np.sqrt(k * k * cin / 4)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    x = rng.standard_normal((3, h, w, cin)).astype(np.float32)
+    plan = ops.ConvPlan(kind, dev_t(wk, dev), dev_t(b, dev), s, act)
+    assert _capi.load().sntc_conv_workspace_bytes(plan._h, 3, h, w) > 0          # these shapes do take the split path
+    fn = {"conv": O.conv2d, "convT": O.conv2d_transpose}[kind]
+    ref = O.ACTIVATIONS[act](fn(x, wk, b, s))
+    xd = dev_t(x, dev)
+    got = plan(xd)
+    assert rel_err(got.cpu().numpy(), ref) < TOL
+    for i in range(3):
+        assert torch.equal(plan(xd[i:i + 1].contiguous()), got[i:i + 1])
+    assert torch.equal(plan(xd), got)                                            # run-to-run deterministic
+    with pytest.raises(_capi.SntcError):                                         # workspace is mandatory, never silently skipped
+        _capi.call("sntc_conv_forward", plan._h, ops._ptr(xd), 3, h, w, ops._ptr(got), None, None, None, 0, ops._stream())
