@@ -52,8 +52,10 @@ struct sntc_conv_plan {
   int pt = 0, pl = 0;       // fixed pads (transposed / SignalConv2D); Keras Conv2D SAME is per call
   int ngroups = 0;
   bool vec = false;
+  bool exact_grid = false;  // phase mode: every group has one grid origin -> macro grid == input grid (no +1 row/col)
   struct Grp {
     int T = 0, K = 0, Ncol = 0;
+    int q0y = 0, q0x = 0;
     float* wp = nullptr;
     int* taps = nullptr;
     unsigned* cols = nullptr;
@@ -83,7 +85,7 @@ extern "C" void sntc_conv_plan_destroy(sntc_conv_plan* p) {
 static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias, hipStream_t stream) {
   const sntc_conv_desc& d = p->d;
   const int k = d.kh, s = d.stride;
-  struct HostGrp { std::vector<int> taps; std::vector<unsigned> cols; };
+  struct HostGrp { std::vector<int> taps; std::vector<unsigned> cols; int q0y = 0, q0x = 0; bool uniform = true; };
   std::vector<HostGrp> groups;
   auto enc = [](int oyo, int oxo, int ch) { return ((unsigned)(oyo + 128) << 24) | ((unsigned)(oxo + 128) << 16) | (unsigned)ch; };
 
@@ -118,6 +120,12 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
         for (int py : a.second)
           for (int px : b.second)
             for (int ch = 0; ch < d.cout; ++ch) hg.cols.push_back(enc(py - p->pt, px - p->pl, ch));
+        // first valid macro row of a phase: oy = q s + phi - pt >= 0  ->  q0 = 1 iff phi < pt (pt < s here)
+        auto q0 = [&](int phi, int pad) { return phi < pad ? 1 : 0; };
+        hg.q0y = q0(a.second[0], p->pt);
+        hg.q0x = q0(b.second[0], p->pl);
+        for (int py : a.second) hg.uniform &= q0(py, p->pt) == hg.q0y;
+        for (int px : b.second) hg.uniform &= q0(px, p->pl) == hg.q0x;
         groups.push_back(std::move(hg));
       }
     std::stable_sort(groups.begin(), groups.end(),
@@ -125,9 +133,12 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
   }
   if ((int)groups.size() > kMaxGroups) return fail(SNTC_ERR_UNSUPPORTED, "too many phase groups");
   p->ngroups = (int)groups.size();
+  p->exact_grid = p->phase_mode && p->pt < s && p->pl < s;
+  for (auto& hg : groups) p->exact_grid = p->exact_grid && hg.uniform;
   for (int gi = 0; gi < p->ngroups; ++gi) {
     auto& hg = groups[gi];
     auto& G = p->g[gi];
+    if (p->exact_grid) { G.q0y = hg.q0y; G.q0x = hg.q0x; }
     G.T = (int)hg.taps.size();
     G.Ncol = (int)hg.cols.size();
     G.K = ((G.T * d.cin + 31) / 32) * 32;
@@ -216,7 +227,10 @@ static int geometry(const sntc_conv_plan* p, int h, int w, Geo* g) {
     *g = Geo{h, w, h, w, 1, -1, p->pt, p->pl, 1};
   } else {
     const int ho = h * s, wo = w * s;
-    *g = Geo{ho, wo, (ho - 1 + p->pt) / s + 1, (wo - 1 + p->pl) / s + 1, 1, -1, 0, 0, s};
+    if (p->exact_grid)      // each phase has exactly h x w valid macro pixels, offset by the group's origin
+      *g = Geo{ho, wo, h, w, 1, -1, 0, 0, s};
+    else
+      *g = Geo{ho, wo, (ho - 1 + p->pt) / s + 1, (wo - 1 + p->pl) / s + 1, 1, -1, 0, 0, s};
   }
   return SNTC_OK;
 }
@@ -359,6 +373,7 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
     G.blk0 = nb;
     nb += G.ntn * a.ntm * ksplit;
     G.slab_off = slab_off;
+    G.q0y = p->g[gi].q0y; G.q0x = p->g[gi].q0x;
     slab_off += (size_t)ksplit * M * G.Ncol;
   }
   rc = gg_launch(v, p->vec, a, nb, (hipStream_t)stream);

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
       const int n = m / per;
       const int rem = m - n * per;
       const int qy = rem / a.Qw;
-      ri = make_int4(n, qy, rem - qy * a.Qw, 1);
+      ri = make_int4(n, qy + G.q0y, rem - qy * a.Qw + G.q0x, 1);   // per-group origin of the macro grid
     }
     rinfo[r] = ri;
   }
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) gg_reduce_kernel(const GGArgs a) {
     const int ch = ce & 0xffff;
     const int n = m / per;
     const int rem = m - n * per;
-    const int qy = rem / a.Qw, qx = rem - qy * a.Qw;
+    const int qy = rem / a.Qw + G.q0y, qx = rem - (rem / a.Qw) * a.Qw + G.q0x;
     const int oy = qy * a.sO + (int)((ce >> 24) & 0xff) - 128;
     const int ox = qx * a.sO + (int)((ce >> 16) & 0xff) - 128;
     if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;

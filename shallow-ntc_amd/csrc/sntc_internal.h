@@ -37,6 +37,7 @@ struct GGGroup {
   int ntn;            // N tiles for the launched variant
   int blk0;           // first block of this group
   size_t slab_off;    // float offset of this group's split-K slabs [ksplit][M][Ncol]
+  int q0y, q0x;       // origin of this group's macro-pixel grid (phase groups whose first valid q is 1)
 };
 
 struct GGArgs {
