@@ -143,13 +143,11 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
   constexpr int TQ = 16, TH = TQ + 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sh = reinterpret_cast<float*>(smem);   // [TH][TH][CH]
-  float* sw = sh + TH * TH * CH;                 // [5][5][3][CH]
-  float* sg = sw + 75 * CH;                      // [CH][CH]
+  float* sg = sh + TH * TH * CH;                 // [CH][CH]
   float* sb = sg + CH * CH;                      // [CH]
   const int img = blockIdx.z;
   const int qy0 = blockIdx.y * TQ, qx0 = blockIdx.x * TQ;
   const int c2 = has_res ? 2 * CH : CH;
-  for (int i = threadIdx.x; i < 75 * CH; i += 256) sw[i] = w2[i];
   const bool use_gdn = act_kind == 1 || act_kind == 2;
   if (use_gdn) {
     for (int i = threadIdx.x; i < CH * CH; i += 256) sg[i] = gamma[i];
@@ -217,7 +215,9 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
         for (int jx = 0; jx < 3 - px; ++jx) {
           const int ky = py + 2 * jy, kx = px + 2 * jx;
           const float* hp = sh + ((ty + 2 - jy) * TH + (tx + 2 - jx)) * CH;
-          const float* wp = sw + (ky * 5 + kx) * 3 * CH;
+          // compile-time offsets from a kernel-argument pointer: the weights arrive by scalar loads (SGPRs),
+          // not through LDS -- 3/4 of the LDS reads of this loop were weight reads
+          const float* wp = w2 + (ky * 5 + kx) * 3 * CH;
 #pragma unroll
           for (int i = 0; i < CH; i += 4) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + i);
@@ -326,7 +326,7 @@ extern "C" int sntc_gdn_small(const float* x, int64_t npix, int c, const float* 
 template <int CH>
 static int launch_tail(const float* t, int n, int hh, int wh, int has_res, int act_kind, const float* beta,
                        const float* gamma, const float* w2, const float* b2, float* x_hat, hipStream_t s) {
-  const size_t lds = sizeof(float) * (18 * 18 * CH + 75 * CH + CH * CH + CH);
+  const size_t lds = sizeof(float) * (18 * 18 * CH + CH * CH + CH);
   static thread_local int attr_dev = -1;
   int dev = 0;
   SNTC_HIP(hipGetDevice(&dev));
