@@ -186,6 +186,34 @@ int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n,
                               float* y_hat, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bitstream: table-driven rANS, 16-bit quantised CDFs, one stream per (image, group of
+ *   `group` consecutive channels), symbols position-major / channel-minor inside a stream.
+ *   The reference evaluates its entropy models with compression=False (mshyper/models.py:246-251), i.e. it
+ *   reports estimated rates; this is this build's own wire format, not TFC's range coder.
+ *   Elements live at ((image * positions + p) * channels + c); table t = cdf[tab_off[t] .. + tab_n[t]] (tab_n[t] + 1
+ *   entries ending in 65536); symbol 0 of table t is the value tab_min[t]; the last symbol is ESCAPE.
+ * ------------------------------------------------------------------------------------------ */
+/* scratch: uint16 [nstreams][cap_words], nstreams = nimages * ceil(channels / group), cap_words >= 2 * positions *
+ * group + 4; stream s ends up in the LAST len_words[s] words of its row. */
+int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t positions, int channels,
+                     int group, const uint32_t* cdf, const int32_t* tab_off, const int32_t* tab_n, const int32_t* tab_min,
+                     int cap_words, uint16_t* scratch, int32_t* len_words, void* stream);
+/* payload[offsets[s] .. offsets[s] + len_words[s]) = stream s (offsets: exclusive prefix sum of len_words). */
+int sntc_rans_compact(const uint16_t* scratch, int cap_words, const int32_t* len_words, const int64_t* offsets,
+                      int nstreams, uint16_t* payload, void* stream);
+/* offsets has nstreams + 1 entries.  bad_streams (int32[1]) counts streams that did not end exactly at their initial
+ * state / length (corruption). */
+int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
+                     int64_t positions, int channels, int group, const uint32_t* cdf, const int32_t* tab_off, const int32_t* tab_n,
+                     const int32_t* tab_min, int32_t* values, int32_t* bad_streams, void* stream);
+/* table id of every y element: round(clamp(exp(raw), 0, 63)), raw = hyper[..., C:]  (the integer scale table). */
+int sntc_scale_table_ids(const float* hyper, int64_t npix, int c, uint16_t* table_ids, void* stream);
+/* table id = channel (deep-factorized prior: one table per channel). */
+int sntc_channel_table_ids(int64_t npix, int c, uint16_t* table_ids, void* stream);
+int sntc_round_to_int(const float* x, int64_t total, int32_t* out, void* stream);
+int sntc_int_to_float(const int32_t* x, int64_t total, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * SSIM / MS-SSIM statistics (eval-only quality metrics, reference mshyper/models.py:321-336 ->
  *   tf.image.ssim / tf.image.ssim_multiscale).  Images are float NHWC holding pixel
  *   values (0..max_val), c in {1, 3}.

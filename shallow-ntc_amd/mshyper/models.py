@@ -158,6 +158,7 @@ class Model:
             pw[k] = a
         self._prior_weights = pw
         self._prior = None
+        self._codec = None
 
     def _prior_channels(self):
         return self._hyper_bottleneck_size
@@ -335,6 +336,21 @@ class Model:
                 return ops.to_pixels(recon, image_hw[0], image_hw[1])
             sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
         return px, sse
+
+    # -- bitstream (the reference itself only estimates the rate) -----------------------
+    def _get_codec(self):
+        from ..entropy_coding import Codec
+        if getattr(self, "_codec", None) is None:
+            self._codec = Codec(self)
+        return self._codec
+
+    def compress(self, x) -> bytes:
+        """Images -> self-contained bitstream (rANS over the integer CDF tables of both entropy models)."""
+        return self._get_codec().compress(x)
+
+    def decompress(self, blob: bytes):
+        """Bitstream -> uint8 pixels [n, H, W, 3]; bit-identical to ``decode(encode(x))``."""
+        return self._get_codec().decompress(blob)
 
     # -- iterative inference (reference :389-413, common/itinf_lib.py:26-93) ----------------------------
     def initialize_itinf(self, image_batch):

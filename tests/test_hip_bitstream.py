@@ -1,0 +1,89 @@
+"""rANS bitstream on the GPU (-m gpu): word-exact against the pure-Python restatement of the
+stream format, encode -> decode round trips in the integer domain, rate vs the estimate, corruption detection."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rans_np
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tables_are_valid_distributions(dev):
+    from shallow_ntc_amd import entropy_coding as ec
+    tabs = ec.normal_tables()
+    assert len(tabs) == 64
+    for k, (lo, f) in enumerate(tabs):
+        assert int(f.sum()) == 65536 and f.min() >= 1 and lo == -(len(f) - 2) // 2
+    assert len(tabs[0][1]) == 2 and tabs[63][0] < -600              # sigma 0.11: {0, ESCAPE}; sigma 256: wide support
+    f = ec.quantize_pmf([0.5, 0.25, 0.25], 0.0)
+    assert int(f.sum()) == 65536 and f[3] == 1 and f[0] > f[1] == f[2] and abs(int(f[0]) - 32768) < 8
+
+
+def test_stream_words_match_python_restatement(dev):
+    from shallow_ntc_amd import entropy_coding as ec
+    rng = np.random.default_rng(0)
+    tabs = ec.normal_tables()
+    dt = ec.DeviceTables(tabs, dev)
+    n, P, c = 2, 37, 5
+    tids = rng.integers(0, 64, size=(n, P, c)).astype(np.int16)
+    sig = np.array([0.11 * np.exp(ec.SCALE_FACTOR * k) for k in range(64)])
+    vals = np.rint(rng.laplace(0, 1, size=(n, P, c)) * sig[tids] * 1.5).astype(np.int32)
+    vals[0, 3, 1] = 20000          # escapes
+    vals[1, 0, 0] = -31000
+    for group in (1, 2, 16):                # streams of 1, 2 (last group ragged: 5 channels) and all channels
+        payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt, group)
+        words = payload.cpu().numpy().view(np.uint16)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        sg = -(-c // group)
+        assert len(lens) == n * sg
+        for b in range(n):
+            for g in range(sg):
+                s = b * sg + g
+                sl = slice(g * group, min(c, (g + 1) * group))
+                ref = rans_np.encode_stream(vals[b, :, sl].ravel(), tids[b, :, sl].ravel(), tabs)
+                got = words[off[s]:off[s + 1]].tolist()
+                assert got == ref, (group, b, g)
+                assert rans_np.decode_stream(got, tids[b, :, sl].ravel(), tabs) == vals[b, :, sl].ravel().tolist()
+        back = ec.rans_decode(payload, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt, group)
+        np.testing.assert_array_equal(back.cpu().numpy(), vals)
+    payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt)
+    # corruption: flip one payload word -> decode must refuse
+    bad = payload.clone()
+    bad[5] ^= 0x0100
+    from shallow_ntc_amd import _capi
+    with pytest.raises(_capi.SntcError, match="corrupt"):
+        ec.rans_decode(bad, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt)
+
+
+def test_codec_round_trip_and_rate(dev):
+    """compress -> bytes -> decompress == decode(encode(x)) bit for bit; the coded size is within a few percent
+    of the estimated rate (integer scale table + 16-bit frequencies + escapes + per-stream headers)."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.02))
+    w = dict(model.get_weights())
+    rng = np.random.default_rng(0)
+    b = w["hyper_synthesis/layer_2/bias"].copy()
+    b[320:] = rng.uniform(-1.0, 2.5, size=320)
+    w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
+    model.set_weights(w)
+    x = torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(2, 512, 768, seed=8))).to(dev)
+    blob = model.compress(x)
+    assert blob[:4] == b"SNTC"
+    px = model.decompress(blob)
+    z_hat, sym, bits_z, bits_y = model.encode(x)
+    ref = model.decode(z_hat, sym, (512, 768))
+    assert torch.equal(px, ref)
+    est_bits = float(bits_z.sum() + bits_y.sum())
+    real_bits = 8.0 * len(blob)
+    assert 0.97 * est_bits < real_bits < 1.08 * est_bits, (real_bits, est_bits)
+    # single images decode identically from their own streams (batch invariance of the whole chain)
+    px0 = model.decompress(model.compress(x[:1].contiguous()))
+    assert torch.equal(px0, px[:1])
+    from shallow_ntc_amd import _capi
+    with pytest.raises(_capi.SntcError):
+        model.decompress(blob[:-10])
+    with pytest.raises(_capi.SntcError):
+        model.decompress(b"JUNK" + blob[4:])
