@@ -185,28 +185,29 @@ int sntc_entropy_scale_normal(const float* y, const float* hyper, int n, int64_t
 int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n, int64_t hw, int c,
                               float* y_hat, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * Bitstream: table-driven rANS, 16-bit quantised CDFs, one stream per (image, group of
- *   `group` consecutive channels), symbols position-major / channel-minor inside a stream.
- *   The reference evaluates its entropy models with compression=False (mshyper/models.py:246-251), i.e. it
- *   reports estimated rates; this is this build's own wire format, not TFC's range coder.
- *   Elements live at ((image * positions + p) * channels + c); table t = cdf[tab_off[t] .. + tab_n[t]] (tab_n[t] + 1
- *   entries ending in 65536); symbol 0 of table t is the value tab_min[t]; the last symbol is ESCAPE.
- * ------------------------------------------------------------------------------------------ */
-/* scratch: uint16 [nstreams][cap_words], nstreams = nimages * ceil(channels / group), cap_words >= 2 * positions *
- * group + 4; stream s ends up in the LAST len_words[s] words of its row. */
-int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t positions, int channels,
-                     int group, const uint32_t* cdf, const int32_t* tab_off, const int32_t* tab_n, const int32_t* tab_min,
-                     int cap_words, uint16_t* scratch, int32_t* len_words, void* stream);
-/* payload[offsets[s] .. offsets[s] + len_words[s]) = stream s (offsets: exclusive prefix sum of len_words). */
-int sntc_rans_compact(const uint16_t* scratch, int cap_words, const int32_t* len_words, const int64_t* offsets,
+/* ---------------------------------------------------------------------------------------------------------
+ * Bitstream: table-driven 64-way interleaved rANS, 16-bit quantised CDFs.  The reference has no
+ *   bitstream (compression=False at mshyper/models.py:246-251; its bpp is the estimate); these entry points make
+ *   `decode` a real codec.  One stream per (image, segment); an image's elements_per_image values (flat, in memory
+ *   order) are cut into `segments` runs of sntc_rans_cap_words()/2 - 64 elements (a multiple of 64).
+ *   Tables: cdf = uint16, concatenated, table t holds cdf[0..n) (cdf[n] = 65536 implicit; pad the array to an even
+ *   count); meta = uint32 [ntables][2] = { offset into cdf, (n << 16) | (vmin & 0xffff) }; the last symbol of every
+ *   table is ESCAPE, followed in the stream by value + 32768 as a raw 16-bit word.
+ *   Stream = [64 x (state hi, state lo)] [16-bit words in decode order]  (format: csrc/rans.hip header).
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t sntc_rans_cap_words(int64_t elems_per_image, int segments);
+/* scratch: uint16 [nimages * segments][cap_words]; stream s ends up in the LAST len_words[s] words of its row. */
+int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t elems_per_image, int segments,
+                     const uint16_t* cdf, const uint32_t* meta, int ntables, int total_entries, int64_t cap_words,
+                     uint16_t* scratch, int32_t* len_words, void* stream);
+/* gathers the streams into one payload; offsets int64 [nstreams + 1] = exclusive prefix sum of len_words */
+int sntc_rans_compact(const uint16_t* scratch, int64_t cap_words, const int32_t* len_words, const int64_t* offsets,
                       int nstreams, uint16_t* payload, void* stream);
-/* offsets has nstreams + 1 entries.  bad_streams (int32[1]) counts streams that did not end exactly at their initial
- * state / length (corruption). */
+/* bad_streams (int32[1], device) counts streams that did not end at their initial state / length: corruption */
 int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
-                     int64_t positions, int channels, int group, const uint32_t* cdf, const int32_t* tab_off, const int32_t* tab_n,
-                     const int32_t* tab_min, int32_t* values, int32_t* bad_streams, void* stream);
-/* table id of every y element: round(clamp(exp(raw), 0, 63)), raw = hyper[..., C:]  (the integer scale table). */
+                     int64_t elems_per_image, int segments, const uint16_t* cdf, const uint32_t* meta, int ntables,
+                     int total_entries, int32_t* values, int32_t* bad_streams, void* stream);
+/* table id of every y element = round(clamp(exp(raw), 0, 63)), raw = hyper[..., c:]; of every z element = channel */
 int sntc_scale_table_ids(const float* hyper, int64_t npix, int c, uint16_t* table_ids, void* stream);
 /* table id = channel (deep-factorized prior: one table per channel). */
 int sntc_channel_table_ids(int64_t npix, int c, uint16_t* table_ids, void* stream);

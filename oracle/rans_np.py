@@ -1,59 +1,84 @@
-"""Pure-Python restatement of the rANS stream format of csrc/rans.hip (TEST INFRASTRUCTURE; small cases only).
+"""Pure-Python restatement of the interleaved rANS stream format of csrc/rans.hip (TEST INFRASTRUCTURE; small cases).
 
-Not a reference algorithm: the reference has no bitstream (compression=False, mshyper/models.py:246-251).  This
-pins the product's own wire format: 32-bit state, 16-bit words, 16-bit probability precision, ESCAPE = last
-symbol followed by (value + 32768) as a uniform 16-bit symbol; stream = [state hi, state lo, words ...]."""
+Not a reference algorithm: the reference has no bitstream (compression=False, mshyper/models.py:246-251).  This pins
+the product's own wire format: 64 lanes, each a 32-bit state with 16-bit renormalisation and 16-bit probability
+precision, sharing one sequence of 16-bit words; element 64 j + l of the segment belongs to lane l at step j;
+ESCAPE = last symbol of a table, followed by (value + 32768) as a raw 16-bit word;
+stream = [lane 0 state hi, lo, lane 1 state hi, lo, ...] [words in decode order]."""
 from __future__ import annotations
 
 M = 1 << 16
+LANES = 64
 
 
-def _put(x, f, c, words):
-    if x >= (f << 16):
-        words.append(x & 0xFFFF)
-        x >>= 16
-    return ((x // f) << 16) + (x % f) + c, words
+def _cdf(f):
+    c = [0]
+    for fi in f:
+        c.append(c[-1] + int(fi))
+    return c
 
 
 def encode_stream(values, tids, tables):
-    """tables[t] = (vmin, freqs incl. ESCAPE last).  Returns the list of uint16 words in stream order."""
-    x, words = M, []
-    for v, t in zip(reversed(list(values)), reversed(list(tids))):
-        vmin, f = tables[t]
-        cdf = [0]
-        for fi in f:
-            cdf.append(cdf[-1] + int(fi))
-        sym = int(v) - vmin
-        if sym < 0 or sym >= len(f) - 1:
-            x, words = _put(x, 1, min(max(int(v), -32768), 32767) + 32768, words)
-            sym = len(f) - 1
-        x, words = _put(x, cdf[sym + 1] - cdf[sym], cdf[sym], words)
-    words.append(x & 0xFFFF)
-    words.append(x >> 16)
-    return list(reversed(words))
+    """tables[t] = (vmin, freqs incl. ESCAPE last).  Returns the list of uint16 words in stream order.
+    Works backward exactly as the kernel does, so ``rev`` collects words from the last address to the first."""
+    values, tids = [int(v) for v in values], [int(t) for t in tids]
+    n = len(values)
+    steps = -(-n // LANES)
+    x = [M] * LANES
+    rev = []
+    for j in reversed(range(steps)):
+        live = [l for l in range(LANES) if j * LANES + l < n]
+        sym = {}
+        for l in reversed(live):                      # ESCAPE payloads first: highest lane at the highest address
+            v = values[j * LANES + l]
+            vmin, f = tables[tids[j * LANES + l]]
+            s = v - vmin
+            if s < 0 or s >= len(f) - 1:
+                rev.append(x[l] & 0xFFFF)
+                x[l] = (x[l] & 0xFFFF0000) | (min(max(v, -32768), 32767) + 32768)
+                s = len(f) - 1
+            sym[l] = s
+        for l in reversed(live):
+            vmin, f = tables[tids[j * LANES + l]]
+            c = _cdf(f)
+            fr, cl = c[sym[l] + 1] - c[sym[l]], c[sym[l]]
+            if x[l] >= (fr << 16):
+                rev.append(x[l] & 0xFFFF)
+                x[l] >>= 16
+            x[l] = ((x[l] // fr) << 16) + (x[l] % fr) + cl
+    for l in reversed(range(LANES)):
+        rev.append(x[l] & 0xFFFF)
+        rev.append(x[l] >> 16)
+    return list(reversed(rev))
 
 
 def decode_stream(words, tids, tables):
-    x = (words[0] << 16) | words[1]
-    pos, out = 2, []
-    for t in tids:
-        vmin, f = tables[t]
-        cdf = [0]
-        for fi in f:
-            cdf.append(cdf[-1] + int(fi))
-        slot = x & 0xFFFF
-        sym = max(i for i in range(len(f)) if cdf[i] <= slot)
-        x = (cdf[sym + 1] - cdf[sym]) * (x >> 16) + slot - cdf[sym]
-        if x < M:
-            x = (x << 16) | words[pos]
-            pos += 1
-        v = sym + vmin
-        if sym == len(f) - 1:
-            v = (x & 0xFFFF) - 32768
-            x >>= 16
-            if x < M:
-                x = (x << 16) | words[pos]
+    tids = [int(t) for t in tids]
+    n = len(tids)
+    steps = -(-n // LANES)
+    x = [(words[2 * l] << 16) | words[2 * l + 1] for l in range(LANES)]
+    pos, out = 2 * LANES, [0] * n
+    for j in range(steps):
+        live = [l for l in range(LANES) if j * LANES + l < n]
+        esc = []
+        for l in live:                                 # phase 1: every lane decodes its symbol from its own state
+            vmin, f = tables[tids[j * LANES + l]]
+            c = _cdf(f)
+            slot = x[l] & 0xFFFF
+            s = max(i for i in range(len(f)) if c[i] <= slot)
+            x[l] = (c[s + 1] - c[s]) * (x[l] >> 16) + slot - c[s]
+            out[j * LANES + l] = s + vmin
+            if s == len(f) - 1:
+                esc.append(l)
+        for l in live:                                 # phase 2: refills in lane order
+            if x[l] < M:
+                x[l] = (x[l] << 16) | words[pos]
                 pos += 1
-        out.append(v)
-    assert x == M and pos == len(words), "stream did not terminate at its initial state"
+        for l in esc:                                  # phase 3: escaped values, then their refills in lane order
+            out[j * LANES + l] = (x[l] & 0xFFFF) - 32768
+            x[l] >>= 16
+        for l in esc:
+            x[l] = (x[l] << 16) | words[pos]
+            pos += 1
+    assert all(v == M for v in x) and pos == len(words), "stream did not terminate at its initial state"
     return out

@@ -1,67 +1,173 @@
-// rans.hip -- the bitstream behind the rate estimates: table-driven rANS with 16-bit
-// quantised CDFs, one independent stream per (image, group of G channels) so that hundreds of streams code
-// in parallel -- one thread per stream, symbols visited position-major / channel-minor.  G trades stream
-// overhead (6 bytes each: u16 length + 32-bit final state) against parallelism.
+// rans.hip -- the bitstream behind the rate estimates: table-driven, 64-way interleaved rANS.
 //
-// The reference always runs its entropy models with compression=False (mshyper/models.py:246-251) and
-// reports the *estimated* rate; this coder is this build's own wire format, not TFC's.
-// State x in [2^16, 2^32), 16-bit renormalisation, probability precision 16 bits:
-//   encode (symbols in reverse):  if x >= f << 16: emit(x & 0xffff), x >>= 16;  x = ((x / f) << 16) + x % f + c
-//   decode (forward):             s = x & 0xffff -> (symbol, f, c);  x = f (x >> 16) + s - c;  refill below 2^16
-// The last symbol of every table is ESCAPE: it is followed by the value + 32768 coded as a uniform 16-bit symbol.
+// The reference always runs its entropy models with compression=False (mshyper/models.py:246-251) and reports
+// the *estimated* rate; this coder is this build's own wire format, not TFC's.
+//
+// One stream per (image, segment); ONE WAVE codes a stream: the segment's elements (flat [P, C] order) are dealt
+// round-robin to the 64 lanes (step j, lane l <-> element 64 j + l, so table-id / value accesses are one coalesced
+// line per step), every lane owns a 32-bit rANS state and all lanes share one sequence of 16-bit words:
+//   decode step:  s = x & 0xffff -> (symbol, f, c);  x = f (x >> 16) + s - c;  lanes with x < 2^16 each take ONE
+//                 word, in lane order, from the shared read pointer (wave ballot + popcount of lower lanes);
+//                 lanes whose symbol was ESCAPE then read the value: v = (x & 0xffff) - 32768, x >>= 16, and
+//                 refill the same way (a second, usually empty, sub-step).
+//   encode step:  the exact mirror, steps in reverse, writing backward: ESCAPE lanes emit x & 0xffff and set
+//                 x = (x & ~0xffff) | (v + 32768); then lanes with x >= f << 16 emit x & 0xffff, x >>= 16;
+//                 x = ((x / f) << 16) + x % f + c.  The highest lane gets the highest address.
+//   stream     =  [64 x (state hi, state lo)] [words in decode order]; every state starts (encoder) and must end
+//                 (decoder) at 2^16, and the read pointer must end at the stream's length: a free integrity check.
+// Cost of the parallelism: 256 bytes of flushed state per stream.  Probability precision 16 bits; CDF tables are
+// uint16 (cdf[n] = 65536 implicit) and live in LDS next to a packed (offset, n, vmin) descriptor per table.
 #include <algorithm>
 #include "sntc_internal.h"
 
 namespace sntc {
 
 struct RansTables {
-  const unsigned* cdf;   // concatenated, table t: cdf[off[t] .. off[t] + n[t]]  (n[t] + 1 entries, last = 65536)
-  const int* off;
-  const int* n;          // symbols incl. ESCAPE
-  const int* vmin;       // value of symbol 0
+  const unsigned short* cdf;   // concatenated; table t: cdf[off .. off + n), cdf of symbol n (= 65536) implicit
+  const uint2* meta;           // per table: x = off, y = (n << 16) | (vmin & 0xffff); symbol n-1 is ESCAPE
+  int ntables;
+  int total;                   // entries in cdf
 };
 
-__device__ __forceinline__ void rans_put(unsigned& x, unsigned f, unsigned c, unsigned short*& wp) {
-  if ((unsigned long long)x >= ((unsigned long long)f << 16)) {
-    *--wp = (unsigned short)(x & 0xffffu);
-    x >>= 16;
+// Staging.  A wave that codes one stream has nobody to hide memory latency behind, so nothing in the coding loops
+// touches global memory for input: table ids (and values / stream words) are fetched a CHUNK of 16 steps ahead into
+// registers and dropped into LDS rings when the chunk ends; the loops read LDS only, one to two steps ahead of use.
+constexpr int kChunk = 16;                        // steps per staging chunk (1024 elements)
+constexpr int kWordRing = 4096;                   // decoder: stream words resident in LDS (2 x the most a chunk can eat)
+constexpr int kWordRegs = 2 * kChunk;             // decoder: words one lane fetches per chunk
+constexpr int kStagingBytes = 2 * kChunk * 64 * 2 + 2 * kChunk * 64 * 4;   // encoder: id + value rings; decoder: id + word rings
+static_assert(2 * kChunk * 64 * 2 + kWordRing * 2 <= kStagingBytes, "decoder rings must fit the staging area");
+constexpr int kRansLdsLimit = 150 * 1024 - kStagingBytes;
+constexpr unsigned short kNoTable = 0xffffu;      // ring entry of a lane with no element in that step
+
+template <bool LDS>
+__device__ __forceinline__ void rans_stage_tables(const RansTables& T, unsigned char* smem, const uint2*& meta,
+                                                  const unsigned short*& cdf) {
+  if (LDS) {
+    uint2* m = reinterpret_cast<uint2*>(smem);
+    unsigned short* c = reinterpret_cast<unsigned short*>(smem + (size_t)T.ntables * sizeof(uint2));
+    for (int i = threadIdx.x; i < T.ntables; i += blockDim.x) m[i] = T.meta[i];
+    const unsigned* src = reinterpret_cast<const unsigned*>(T.cdf);   // host pads the table to an even count
+    unsigned* dst = reinterpret_cast<unsigned*>(c);
+    for (int i = threadIdx.x; i < (T.total + 1) / 2; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    meta = m;
+    cdf = c;
+  } else {
+    meta = T.meta;
+    cdf = T.cdf;
   }
-  x = ((x / f) << 16) + (x % f) + c;
 }
 
-// one thread per stream (image b, channel group grp of G channels); elements at ((b * P + p) * C + c),
-// visited position-major, channel-minor inside the group
+// one wave per stream s = (image b, segment sg): elements [b E + sg Eseg, min((b + 1) E, b E + (sg + 1) Eseg))
+template <bool LDS>
 __global__ void __launch_bounds__(64) rans_encode_kernel(const int* __restrict__ values, const unsigned short* __restrict__ tid,
-                                                         int nstreams, int P, int C, int G, RansTables T, int cap,
-                                                         unsigned short* __restrict__ out, int* __restrict__ len_words) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nstreams) return;
-  const int sg = (C + G - 1) / G;
-  const int b = s / sg, c0 = (s - b * sg) * G, cn = min(G, C - c0);
-  unsigned short* end = out + (size_t)(s + 1) * cap;
-  unsigned short* wp = end;
+                                                         int segs, long long E, long long Eseg, RansTables T, long long cap,
+                                                         unsigned short* __restrict__ scratch, int* __restrict__ len_words) {
+  extern __shared__ unsigned char smem[];
+  unsigned short* tring = reinterpret_cast<unsigned short*>(smem);                   // [2][kChunk * 64]
+  int* vring = reinterpret_cast<int*>(smem + 2 * kChunk * 64 * 2);                   // [2][kChunk * 64]
+  const uint2* meta;
+  const unsigned short* cdf;
+  rans_stage_tables<LDS>(T, smem + kStagingBytes, meta, cdf);
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int b = s / segs, sg = s - b * segs;
+  const long long e0 = (long long)b * E + (long long)sg * Eseg;
+  const long long e1 = std::min((long long)(b + 1) * E, e0 + Eseg);
+  const long long steps = e1 > e0 ? (e1 - e0 + 63) / 64 : 0;
+  const long long nchunks = (steps + kChunk - 1) / kChunk;
+  unsigned short* out = scratch + (size_t)s * cap;
+  long long wp = cap;
+  const unsigned long long gt = lane == 63 ? 0ull : (~0ull << (lane + 1));
   unsigned x = 1u << 16;
-  for (int q = P * cn - 1; q >= 0; --q) {
-    const int p = q / cn;
-    const size_t e = ((size_t)b * P + p) * C + c0 + (q - p * cn);
-    const int t = tid[e];
-    const int n = T.n[t];
-    const unsigned* cdf = T.cdf + T.off[t];
-    const int v = values[e];
-    int sym = v - T.vmin[t];
-    if (sym < 0 || sym >= n - 1) {                       // escape: (reverse order) raw value first, then ESCAPE
-      const unsigned raw = (unsigned)(min(max(v, -32768), 32767) + 32768);
-      rans_put(x, 1u, raw, wp);
-      sym = n - 1;
+
+  unsigned short TR[kChunk];
+  int VR[kChunk];
+  auto fetch = [&](long long k) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+      const long long e = e0 + (k * kChunk + i) * 64 + lane;
+      const bool a = k >= 0 && e < e1;
+      TR[i] = a ? tid[e] : kNoTable;
+      VR[i] = a ? values[e] : 0;
     }
-    rans_put(x, cdf[sym + 1] - cdf[sym], cdf[sym], wp);
+  };
+  auto spill = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+      tring[buf * kChunk * 64 + i * 64 + lane] = TR[i];
+      vring[buf * kChunk * 64 + i * 64 + lane] = VR[i];
+    }
+  };
+  // everything that depends only on the symbol (descriptor, ESCAPE test, f, c) runs two steps ahead of the state
+  // arithmetic; the loop-carried chain is: escape emit, renormalise, divide
+  struct Sym { unsigned f, c, raw; bool active, esc; };
+  auto lookup = [&](int t, int v, uint2 m) -> Sym {
+    const bool active = t != kNoTable;
+    const int n = (int)(m.y >> 16), vmin = (int)(short)(m.y & 0xffffu);
+    int sym = v - vmin;
+    const bool esc = active && (sym < 0 || sym >= n - 1);
+    if (esc) sym = n - 1;
+    if (!active) sym = 0;
+    const unsigned cl = cdf[m.x + sym];
+    const unsigned ch = sym + 1 < n ? (unsigned)cdf[m.x + sym + 1] : 65536u;
+    return Sym{active ? ch - cl : 1u, cl, (unsigned)(std::min(std::max(v, -32768), 32767) + 32768), active, esc};
+  };
+  if (nchunks > 0) {
+    fetch(nchunks - 1);
+    spill((int)((nchunks - 1) & 1));
   }
-  *--wp = (unsigned short)(x & 0xffffu);
-  *--wp = (unsigned short)(x >> 16);
-  len_words[s] = (int)(end - wp);
+  for (long long k = nchunks - 1; k >= 0; --k) {
+    fetch(k - 1);
+    const int buf = (int)(k & 1);
+    const unsigned short* tb = tring + buf * kChunk * 64 + lane;
+    const int* vb = vring + buf * kChunk * 64 + lane;
+    const int cnt = (int)std::min<long long>(kChunk, steps - k * kChunk);
+    auto rd = [&](int i, int& t, int& v) {
+      const int ii = std::max(i, 0);
+      t = tb[ii * 64];
+      v = vb[ii * 64];
+      if (i < 0) t = kNoTable;
+    };
+    int t1, v1, t2, v2;
+    rd(cnt - 1, t1, v1);
+    Sym cur = lookup(t1, v1, meta[t1 == kNoTable ? 0 : t1]);
+    rd(cnt - 2, t1, v1);
+    uint2 m1 = meta[t1 == kNoTable ? 0 : t1];
+    rd(cnt - 3, t2, v2);
+    for (int i = cnt - 1; i >= 0; --i) {
+      const Sym sy = cur;
+      cur = lookup(t1, v1, m1);                             // step i - 1
+      t1 = t2;
+      v1 = v2;
+      m1 = meta[t1 == kNoTable ? 0 : t1];                   // step i - 2
+      rd(i - 3, t2, v2);
+      const unsigned long long emask = __ballot(sy.esc);
+      if (emask) {                                          // value first (reverse order), then the ESCAPE symbol
+        if (sy.esc) {
+          out[wp - 1 - __popcll(emask & gt)] = (unsigned short)(x & 0xffffu);
+          x = (x & 0xffff0000u) | sy.raw;
+        }
+        wp -= __popcll(emask);
+      }
+      const bool need = sy.active && (unsigned long long)x >= ((unsigned long long)sy.f << 16);
+      const unsigned long long mask = __ballot(need);
+      if (need) {
+        out[wp - 1 - __popcll(mask & gt)] = (unsigned short)(x & 0xffffu);
+        x >>= 16;
+      }
+      wp -= __popcll(mask);
+      if (sy.active) x = ((x / sy.f) << 16) + (x % sy.f) + sy.c;
+    }
+    spill((int)((k - 1) & 1));
+  }
+  wp -= 128;
+  out[wp + 2 * lane] = (unsigned short)(x >> 16);
+  out[wp + 2 * lane + 1] = (unsigned short)(x & 0xffffu);
+  if (lane == 0) len_words[s] = (int)(cap - wp);
 }
 
-__global__ void rans_compact_kernel(const unsigned short* __restrict__ src, int cap, const int* __restrict__ len_words,
+__global__ void rans_compact_kernel(const unsigned short* __restrict__ src, long long cap, const int* __restrict__ len_words,
                                     const long long* __restrict__ offsets, int nstreams, unsigned short* __restrict__ dst) {
   const int s = blockIdx.x;
   if (s >= nstreams) return;
@@ -71,42 +177,138 @@ __global__ void rans_compact_kernel(const unsigned short* __restrict__ src, int 
   for (int i = threadIdx.x; i < len; i += blockDim.x) to[i] = from[i];
 }
 
+template <bool LDS>
 __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* __restrict__ payload, const long long* __restrict__ offsets,
-                                                         const unsigned short* __restrict__ tid, int nstreams, int P, int C,
-                                                         int G, RansTables T, int* __restrict__ values, int* __restrict__ bad) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nstreams) return;
-  const int sg = (C + G - 1) / G;
-  const int b = s / sg, c0 = (s - b * sg) * G, cn = min(G, C - c0);
-  const unsigned short* rp = payload + offsets[s];
-  const unsigned short* rend = payload + offsets[s + 1];
-  unsigned x = ((unsigned)rp[0] << 16) | rp[1];
-  rp += 2;
-  bool ok = true;
-  for (int q = 0; q < P * cn; ++q) {
-    const int p = q / cn;
-    const size_t e = ((size_t)b * P + p) * C + c0 + (q - p * cn);
-    const int t = tid[e];
-    const int n = T.n[t];
-    const unsigned* cdf = T.cdf + T.off[t];
-    const unsigned slot = x & 0xffffu;
-    int lo = 0, hi = n;                                   // largest sym with cdf[sym] <= slot
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (cdf[mid] <= slot) lo = mid; else hi = mid;
-    }
-    const unsigned cl = cdf[lo], f = cdf[lo + 1] - cl;
-    x = f * (x >> 16) + slot - cl;
-    if (x < (1u << 16)) { ok &= rp < rend; x = (x << 16) | (rp < rend ? *rp++ : 0); }
-    int v = lo + T.vmin[t];
-    if (lo == n - 1) {                                    // ESCAPE: uniform 16-bit value follows
-      v = (int)(x & 0xffffu) - 32768;
-      x >>= 16;
-      if (x < (1u << 16)) { ok &= rp < rend; x = (x << 16) | (rp < rend ? *rp++ : 0); }
-    }
-    values[e] = v;
+                                                         const unsigned short* __restrict__ tid, int segs, long long E, long long Eseg,
+                                                         RansTables T, int* __restrict__ values, int* __restrict__ bad) {
+  extern __shared__ unsigned char smem[];
+  unsigned short* tring = reinterpret_cast<unsigned short*>(smem);                   // [2][kChunk * 64]
+  unsigned short* wring = tring + 2 * kChunk * 64;                                   // [kWordRing]
+  const uint2* meta;
+  const unsigned short* cdf;
+  rans_stage_tables<LDS>(T, smem + kStagingBytes, meta, cdf);
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int b = s / segs, sg = s - b * segs;
+  const long long e0 = (long long)b * E + (long long)sg * Eseg;
+  const long long e1 = std::min((long long)(b + 1) * E, e0 + Eseg);
+  const long long steps = e1 > e0 ? (e1 - e0 + 63) / 64 : 0;
+  const long long nchunks = (steps + kChunk - 1) / kChunk;
+  const unsigned short* w = payload + offsets[s];
+  const long long len = offsets[s + 1] - offsets[s];
+  if (len < 128) {                                           // not even the 64 states: malformed
+    if (lane == 0) atomicAdd(bad, 1);
+    return;
   }
-  if (!ok || rp != rend || x != (1u << 16)) atomicAdd(bad, 1);   // a well-formed stream ends exactly at its initial state
+  unsigned x = ((unsigned)w[2 * lane] << 16) | w[2 * lane + 1];
+  bool ok = true;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  // stream words: the ring holds [ptr, ptr + kWordRing) at the start of a chunk; a chunk eats at most kWordRing / 2
+  long long ptr = 128, filled = 128, wfrom = 128, wto = 128;
+  unsigned short WR[kWordRegs];
+  auto word_fetch = [&](long long target) {
+    wfrom = filled;
+    wto = std::min(target, len);
+#pragma unroll
+    for (int i = 0; i < kWordRegs; ++i) {
+      const long long q = wfrom + i * 64 + lane;
+      WR[i] = q < wto ? w[q] : (unsigned short)0;
+    }
+  };
+  auto word_spill = [&]() {
+#pragma unroll
+    for (int i = 0; i < kWordRegs; ++i) {
+      const long long q = wfrom + i * 64 + lane;
+      if (q < wto) wring[q & (kWordRing - 1)] = WR[i];
+    }
+    filled = std::max(filled, wto);
+  };
+  unsigned short TR[kChunk];
+  auto tid_fetch = [&](long long k) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+      const long long e = e0 + (k * kChunk + i) * 64 + lane;
+      TR[i] = (k < nchunks && e < e1) ? tid[e] : kNoTable;
+    }
+  };
+  auto tid_spill = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) tring[buf * kChunk * 64 + i * 64 + lane] = TR[i];
+  };
+  word_fetch(ptr + kWordRing / 2);
+  word_spill();
+  word_fetch(ptr + kWordRing);
+  word_spill();
+  tid_fetch(0);
+  tid_spill(0);
+
+  for (long long k = 0; k < nchunks; ++k) {
+    tid_fetch(k + 1);
+    word_fetch(ptr + kWordRing);
+    const unsigned short* tb = tring + (int)(k & 1) * kChunk * 64 + lane;
+    const int cnt = (int)std::min<long long>(kChunk, steps - k * kChunk);
+    int* vout = values + e0 + k * kChunk * 64 + lane;
+    int t1 = tb[0];
+    uint2 m1 = meta[t1 == kNoTable ? 0 : t1];
+    int t2 = cnt > 1 ? (int)tb[64] : (int)kNoTable;
+    for (int i = 0; i < cnt; ++i) {
+      const bool active = t1 != kNoTable;
+      const uint2 m = m1;
+      t1 = t2;
+      m1 = meta[t1 == kNoTable ? 0 : t1];                    // descriptor of step i + 1
+      t2 = tb[std::min(i + 2, kChunk - 1) * 64];             // table id of step i + 2
+      if (i + 2 >= cnt) t2 = kNoTable;
+      const int n = active ? (int)(m.y >> 16) : 1, vmin = (int)(short)(m.y & 0xffffu);
+      const unsigned short* c = cdf + m.x;
+      const unsigned slot = x & 0xffffu;
+      // 4-ary search for the largest sym with cdf[sym] <= slot: three independent probes per level, and the
+      // bracketing cdf values are carried along so that no read follows the search
+      int lo = 0, hi = n;
+      unsigned clo = 0u, chi = 65536u;
+      while (hi - lo > 1) {
+        const int q = (hi - lo + 3) >> 2;
+        const int p1 = lo + q, p2 = std::min(lo + 2 * q, hi - 1), p3 = std::min(lo + 3 * q, hi - 1);
+        const unsigned v1 = c[p1], v2 = c[p2], v3 = c[p3];
+        // branch-free on purpose: all three probes are consumed unconditionally, so they issue back to back
+        const int kk = (int)(slot >= v1) + (int)(slot >= v2) + (int)(slot >= v3);   // v1 <= v2 <= v3
+        const int nlo = kk == 0 ? lo : (kk == 1 ? p1 : (kk == 2 ? p2 : p3));
+        const unsigned nclo = kk == 0 ? clo : (kk == 1 ? v1 : (kk == 2 ? v2 : v3));
+        hi = kk == 0 ? p1 : (kk == 1 ? p2 : (kk == 2 ? p3 : hi));
+        chi = kk == 0 ? v1 : (kk == 1 ? v2 : (kk == 2 ? v3 : chi));
+        lo = nlo;
+        clo = nclo;
+      }
+      if (active) x = (chi - clo) * (x >> 16) + slot - clo;
+      const bool need = active && x < (1u << 16);
+      const unsigned long long mask = __ballot(need);
+      if (mask) {                                            // one word each, in lane order, from the shared pointer
+        if (need) {
+          const long long q = ptr + __popcll(mask & lt);
+          ok &= q < len;
+          x = (x << 16) | wring[q & (kWordRing - 1)];
+        }
+        ptr += __popcll(mask);
+      }
+      int v = lo + vmin;
+      const bool esc = active && lo == n - 1;
+      const unsigned long long emask = __ballot(esc);
+      if (emask) {
+        if (esc) {
+          const long long q = ptr + __popcll(emask & lt);
+          ok &= q < len;
+          v = (int)(x & 0xffffu) - 32768;
+          x = (x & 0xffff0000u) | wring[q & (kWordRing - 1)];
+        }
+        ptr += __popcll(emask);
+      }
+      if (active) vout[i * 64] = v;
+    }
+    word_spill();
+    tid_spill((int)((k + 1) & 1));
+  }
+  // a well-formed stream ends with every state back at its initial value and the pointer at the end
+  const bool good = ok && x == (1u << 16) && ptr == len;
+  if (__ballot(!good) && lane == 0) atomicAdd(bad, 1);
 }
 
 // indexes = round(clamp(exp(raw), 0, 63)) as the table id of every y element (the integer scale table TFC's
@@ -146,45 +348,71 @@ static int blocks_for(long long total) {
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-static RansTables tables(const uint32_t* cdf, const int32_t* off, const int32_t* n, const int32_t* vmin) {
-  return RansTables{cdf, off, n, vmin};
+static long long segment_elems(long long elems, int segments) {
+  const long long per = (elems + segments - 1) / segments;
+  return (per + 63) / 64 * 64;
 }
 
-extern "C" int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t positions, int channels,
-                                int group, const uint32_t* cdf, const int32_t* tab_off, const int32_t* tab_n, const int32_t* tab_min,
-                                int cap_words, uint16_t* scratch, int32_t* len_words, void* stream) {
-  if (!values || !table_ids || !cdf || !tab_off || !tab_n || !tab_min || !scratch || !len_words)
+static int table_bytes(int ntables, int total) { return ntables * (int)sizeof(uint2) + ((total + 1) / 2) * 4; }
+
+extern "C" int64_t sntc_rans_cap_words(int64_t elems_per_image, int segments) {
+  if (elems_per_image < 1 || segments < 1) return -1;
+  return 2 * segment_elems(elems_per_image, segments) + 128;
+}
+
+extern "C" int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t elems_per_image,
+                                int segments, const uint16_t* cdf, const uint32_t* meta, int ntables, int total_entries,
+                                int64_t cap_words, uint16_t* scratch, int32_t* len_words, void* stream) {
+  if (!values || !table_ids || !cdf || !meta || !scratch || !len_words)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_encode: null argument");
-  if (nimages < 1 || positions < 1 || channels < 1 || group < 1 || cap_words < 2 * positions * std::min(group, channels) + 4)
-    return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_encode: bad sizes (cap_words must be >= 2 * positions * group + 4)");
-  const int ns = nimages * ((channels + group - 1) / group);
-  hipLaunchKernelGGL(rans_encode_kernel, dim3((ns + 63) / 64), dim3(64), 0, (hipStream_t)stream, values, table_ids, ns,
-                     (int)positions, channels, group, tables(cdf, tab_off, tab_n, tab_min), cap_words, scratch, len_words);
+  if (nimages < 1 || elems_per_image < 1 || segments < 1 || ntables < 1 || total_entries < 1 ||
+      cap_words < sntc_rans_cap_words(elems_per_image, segments) || cap_words > 0x3fffffff)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_encode: bad sizes (cap_words must be >= sntc_rans_cap_words())");
+  const RansTables T{cdf, reinterpret_cast<const uint2*>(meta), ntables, total_entries};
+  const long long eseg = segment_elems(elems_per_image, segments);
+  const int ns = nimages * segments, tb = table_bytes(ntables, total_entries), lds = kStagingBytes + tb;
+  hipStream_t s = (hipStream_t)stream;
+  if (tb <= kRansLdsLimit) {
+    SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_encode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(rans_encode_kernel<true>, dim3(ns), dim3(64), lds, s, values, table_ids, segments, (long long)elems_per_image,
+                       eseg, T, (long long)cap_words, scratch, len_words);
+  } else {
+    hipLaunchKernelGGL(rans_encode_kernel<false>, dim3(ns), dim3(64), kStagingBytes, s, values, table_ids, segments, (long long)elems_per_image,
+                       eseg, T, (long long)cap_words, scratch, len_words);
+  }
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }
 
-extern "C" int sntc_rans_compact(const uint16_t* scratch, int cap_words, const int32_t* len_words, const int64_t* offsets,
+extern "C" int sntc_rans_compact(const uint16_t* scratch, int64_t cap_words, const int32_t* len_words, const int64_t* offsets,
                                  int nstreams, uint16_t* payload, void* stream) {
   if (!scratch || !len_words || !offsets || !payload || nstreams < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_compact: bad argument");
-  hipLaunchKernelGGL(rans_compact_kernel, dim3(nstreams), dim3(64), 0, (hipStream_t)stream, scratch, cap_words, len_words,
+  hipLaunchKernelGGL(rans_compact_kernel, dim3(nstreams), dim3(256), 0, (hipStream_t)stream, scratch, (long long)cap_words, len_words,
                      reinterpret_cast<const long long*>(offsets), nstreams, payload);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }
 
 extern "C" int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
-                                int64_t positions, int channels, int group, const uint32_t* cdf, const int32_t* tab_off,
-                                const int32_t* tab_n, const int32_t* tab_min, int32_t* values, int32_t* bad_streams,
-                                void* stream) {
-  if (!payload || !offsets || !table_ids || !cdf || !tab_off || !tab_n || !tab_min || !values || !bad_streams)
+                                int64_t elems_per_image, int segments, const uint16_t* cdf, const uint32_t* meta, int ntables,
+                                int total_entries, int32_t* values, int32_t* bad_streams, void* stream) {
+  if (!payload || !offsets || !table_ids || !cdf || !meta || !values || !bad_streams)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: null argument");
-  if (nimages < 1 || positions < 1 || channels < 1 || group < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: bad sizes");
-  const int ns = nimages * ((channels + group - 1) / group);
+  if (nimages < 1 || elems_per_image < 1 || segments < 1 || ntables < 1 || total_entries < 1)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: bad sizes");
+  const RansTables T{cdf, reinterpret_cast<const uint2*>(meta), ntables, total_entries};
+  const long long eseg = segment_elems(elems_per_image, segments);
+  const int ns = nimages * segments, tb = table_bytes(ntables, total_entries), lds = kStagingBytes + tb;
   hipStream_t s = (hipStream_t)stream;
   SNTC_HIP(hipMemsetAsync(bad_streams, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(rans_decode_kernel, dim3((ns + 63) / 64), dim3(64), 0, s, payload, reinterpret_cast<const long long*>(offsets),
-                     table_ids, ns, (int)positions, channels, group, tables(cdf, tab_off, tab_n, tab_min), values, bad_streams);
+  if (tb <= kRansLdsLimit) {
+    SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(rans_decode_kernel<true>, dim3(ns), dim3(64), lds, s, payload, reinterpret_cast<const long long*>(offsets),
+                       table_ids, segments, (long long)elems_per_image, eseg, T, values, bad_streams);
+  } else {
+    hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(ns), dim3(64), kStagingBytes, s, payload, reinterpret_cast<const long long*>(offsets),
+                       table_ids, segments, (long long)elems_per_image, eseg, T, values, bad_streams);
+  }
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }

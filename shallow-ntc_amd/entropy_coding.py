@@ -7,11 +7,11 @@ bpp is -sum log2 p.  This module makes ``decode`` a real codec: ``Model.compress
 Tables (host, float64, 16-bit precision: frequencies sum to 65536, every symbol >= 1, last symbol = ESCAPE):
   * y: 64 tables, one per integer scale index k = round(clamp(exp(raw), 0, 63)), sigma_k = SCALE_FN(k)
     (mshyper/models.py:28-32; rounding the index is what TFC's compress() path does), pmf(v) = Phi((v+.5)/s) - Phi((v-.5)/s)
-    on |v| <= L_k where the two tails hold < 2^-12 of the mass.
+    on |v| <= L_k = the symbols with pmf >= 2^-17; rarer values are escaped.
   * z: one table per channel from the deep-factorized prior, pmf(v) = sigmoid(L(v+.5)) - sigmoid(L(v-.5)).
 Wire format (little endian): b"SNTC" u16 version | u16 n | u32 H | u32 W | u16 C | u16 hz | u16 wz | u16 h | u16 w |
-  u16 group | u16 len_words[streams] (z) | u16 len_words[streams] (y) | z payload | y payload,
-  streams = n * ceil(C / group); a stream = [state hi, state lo, words...] of 16-bit words.
+  u16 segments_z | u16 segments_y | u32 len_words[n * segments_z] | u32 len_words[n * segments_y] | z payload | y payload;
+  a stream (one per image and segment) = 64 lane states + the interleaved 16-bit words (csrc/rans.hip).
 The decoder rebuilds mu / scale indexes with the same hyper-synthesis kernels (deterministic, batch-invariant), so
 encoder and decoder agree bit for bit.
 """
@@ -52,15 +52,19 @@ def _ndtr(x):
     return 0.5 * math.erfc(-x / math.sqrt(2.0))
 
 
-def normal_tables(tail_mass=2.0 ** -12, max_half_width=4095):
+def normal_tables(min_pmf=2.0 ** -17, max_half_width=4095):
+    """64 tables; table k spans |v| <= L_k, the symbols whose probability is worth a frequency count of its own
+    (pmf >= 2^-17, i.e. >= 1/2 count at 16-bit precision).  Rarer values go through ESCAPE (~32 bits against an
+    ideal > 17): the extra cost is bounded by 15 bits x 2^-17 per symbol."""
     tabs = []
     for k in range(NUM_SCALES):
         sigma = math.exp(math.log(SCALE_MIN) + SCALE_FACTOR * k)
+        pmf_at = lambda t: _ndtr((t + 0.5) / sigma) - _ndtr((t - 0.5) / sigma) if t <= 0 else _ndtr(-(t - 0.5) / sigma) - _ndtr(-(t + 0.5) / sigma)
         L = 0
-        while L < max_half_width and 2.0 * _ndtr(-(L + 0.5) / sigma) > tail_mass:
+        while L < max_half_width and pmf_at(L + 1) >= min_pmf:
             L += 1
         v = np.arange(-L, L + 1)
-        pmf = np.array([_ndtr((t + 0.5) / sigma) - _ndtr((t - 0.5) / sigma) for t in v])
+        pmf = np.array([pmf_at(int(t)) for t in v])
         tabs.append((-L, quantize_pmf(pmf, 2.0 * _ndtr(-(L + 0.5) / sigma))))
     return tabs
 
@@ -93,48 +97,54 @@ def factorized_tables(prior_weights, num_layers, tail_mass=2.0 ** -12, max_half_
 
 
 class DeviceTables:
-    """Concatenated CDFs + per-table offsets / sizes / minima on the device."""
+    """Concatenated uint16 CDFs (cdf[n] = 65536 implicit) + packed per-table descriptors on the device."""
 
     def __init__(self, tabs, device):
-        cdfs, off, n, vmin = [], [], [], []
+        cdfs, meta = [], []
         pos = 0
         for lo, f in tabs:
-            cdf = np.concatenate([[0], np.cumsum(f)]).astype(np.uint32)
-            off.append(pos)
-            n.append(len(f))
-            vmin.append(lo)
+            cdf = np.concatenate([[0], np.cumsum(f)[:-1]]).astype(np.uint16)     # cdf of symbols 0..n-1
+            if not -32768 <= lo <= 32767 or len(f) > 32768:
+                raise ValueError("table outside the 16-bit descriptor range")
+            meta.append((pos, (len(f) << 16) | (lo & 0xFFFF)))
             cdfs.append(cdf)
             pos += len(cdf)
+        flat = np.concatenate(cdfs)
+        if len(flat) % 2:
+            flat = np.concatenate([flat, [0]]).astype(np.uint16)                  # kernels copy 32 bits at a time
         self.host = tabs
-        self.cdf = torch.from_numpy(np.concatenate(cdfs).astype(np.int64)).to(torch.int32).to(device)   # values <= 65536
-        self.off = torch.tensor(off, dtype=torch.int32, device=device)
-        self.n = torch.tensor(n, dtype=torch.int32, device=device)
-        self.vmin = torch.tensor(vmin, dtype=torch.int32, device=device)
+        self.ntables, self.total = len(tabs), pos
+        self.cdf = torch.from_numpy(flat.view(np.int16).copy()).to(device)
+        self.meta = torch.from_numpy(np.asarray(meta, np.uint32).view(np.int32).copy()).to(device)
 
 
 def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-GROUP = 16      # channels per rANS stream: 6 bytes of overhead per stream vs. decode parallelism
+ELEMS_PER_SEGMENT = 1 << 18     # one rANS stream (= one wave of coding parallelism, 256 bytes of flushed lane states) per
+                                # this many latent elements: ~0.008 bit / element of overhead; a Kodak image = 1 z + 2 y streams
 
 
-def num_streams(n, c, group=GROUP):
-    return n * (-(-c // group))
+def _segments(elems, segments=None):
+    if segments is None:
+        segments = -(-elems // ELEMS_PER_SEGMENT)
+    return max(1, min(int(segments), -(-elems // 64)))
 
 
-def rans_encode(values, table_ids, tables: DeviceTables, group=GROUP):
-    """values int32 [n, P..., C], table_ids uint16 (int16 storage) same shape -> (payload int16-storage words,
-    len_words int64[num_streams])."""
-    n, c = values.shape[0], values.shape[-1]
-    P = values.numel() // (n * c)
-    cap = 2 * P * min(group, c) + 4
+def rans_encode(values, table_ids, tables: DeviceTables, segments=None):
+    """values int32 [n, ...], table_ids uint16 (int16 storage) same shape -> (payload int16-storage words on the
+    device, len_words int64[n * segments])."""
+    n = values.shape[0]
+    E = values.numel() // n
+    segments = _segments(E, segments)
+    cap = int(capi.load().sntc_rans_cap_words(E, segments))
     dev = values.device
-    ns = num_streams(n, c, group)
+    ns = n * segments
     scratch = torch.empty((ns, cap), dtype=torch.int16, device=dev)
     lens = torch.empty((ns,), dtype=torch.int32, device=dev)
-    capi.call("sntc_rans_encode", _p(values), _p(table_ids), n, P, c, group, _p(tables.cdf), _p(tables.off), _p(tables.n),
-              _p(tables.vmin), cap, _p(scratch), _p(lens), ops._stream())
+    capi.call("sntc_rans_encode", _p(values), _p(table_ids), n, E, segments, _p(tables.cdf), _p(tables.meta), tables.ntables,
+              tables.total, cap, _p(scratch), _p(lens), ops._stream())
     lens_h = lens.cpu().numpy().astype(np.int64)
     offsets = np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)
     payload = torch.empty((int(offsets[-1]),), dtype=torch.int16, device=dev)
@@ -143,19 +153,22 @@ def rans_encode(values, table_ids, tables: DeviceTables, group=GROUP):
     return payload, lens_h
 
 
-def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, group=GROUP):
-    """-> int32 values of ``shape`` [n, ..., C]; raises on a malformed stream."""
-    n, c = shape[0], shape[-1]
-    P = int(np.prod(shape)) // (n * c)
+def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segments=None):
+    """-> int32 values of ``shape`` [n, ...]; raises on a malformed stream."""
+    n = shape[0]
+    E = int(np.prod(shape)) // n
+    segments = _segments(E, segments)
+    if len(lens_h) != n * segments:
+        raise capi.SntcError(capi.ERR_BAD_SHAPE, "stream count does not match the image / segment counts")
     dev = payload.device
     offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)).to(dev)
     values = torch.empty(tuple(shape), dtype=torch.int32, device=dev)
     bad = torch.zeros((1,), dtype=torch.int32, device=dev)
-    capi.call("sntc_rans_decode", _p(payload), _p(offsets), _p(table_ids), n, P, c, group, _p(tables.cdf), _p(tables.off),
-              _p(tables.n), _p(tables.vmin), _p(values), _p(bad), ops._stream())
+    capi.call("sntc_rans_decode", _p(payload), _p(offsets), _p(table_ids), n, E, segments, _p(tables.cdf), _p(tables.meta),
+              tables.ntables, tables.total, _p(values), _p(bad), ops._stream())
     nbad = int(bad.item())
     if nbad:
-        raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream corrupt: {nbad} of {num_streams(n, c, group)} rANS streams did not terminate cleanly")
+        raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream corrupt: {nbad} of {n * segments} rANS streams did not terminate cleanly")
     return values
 
 
@@ -188,6 +201,8 @@ def int_to_float(x):
 class Codec:
     """compress / decompress for a mean-scale hyperprior ``Model``."""
 
+    HEAD = "<HHIIHHHHHHH"
+
     def __init__(self, model):
         self.m = model
         dev = model.device
@@ -207,28 +222,29 @@ class Codec:
             z_hat = int_to_float(zi)
             hyper = m._hyper_synthesis(z_hat)
             _, _, sym = ops.entropy_scale_normal(y, hyper, want_symbols=True)
-            zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables)
-            yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables)
+            sz, sy = _segments(zi[0].numel()), _segments(sym[0].numel())
+            zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz)
+            yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables, sy)
             zb, yb = zp.cpu().numpy().tobytes(), yp.cpu().numpy().tobytes()
-        if max(int(zl.max()), int(yl.max())) > 0xFFFF:
-            raise capi.SntcError(capi.ERR_UNSUPPORTED, "a rANS stream exceeds 65535 words; lower entropy_coding.GROUP")
-        head = MAGIC + struct.pack("<HHIIHHHHHH", VERSION, n, H, W, y.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2], GROUP)
-        return head + zl.astype("<u2").tobytes() + yl.astype("<u2").tobytes() + zb + yb
+        head = MAGIC + struct.pack(self.HEAD, VERSION, n, H, W, y.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2], sz, sy)
+        return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
 
     def decompress(self, blob: bytes):
         m = self.m
         if blob[:4] != MAGIC:
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "not an SNTC bitstream")
-        ver, n, H, W, c, hz, wz, h, w, group = struct.unpack_from("<HHIIHHHHHH", blob, 4)
+        pos = 4 + struct.calcsize(self.HEAD)
+        if len(blob) < pos:
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
+        ver, n, H, W, c, hz, wz, h, w, sz, sy = struct.unpack_from(self.HEAD, blob, 4)
         if ver != VERSION:
             raise capi.SntcError(capi.ERR_UNSUPPORTED, f"bitstream version {ver}")
-        pos = 4 + struct.calcsize("<HHIIHHHHHH")
-        ns = num_streams(n, c, group)
-        if len(blob) < pos + 4 * ns:
+        nz, ny = n * sz, n * sy
+        if len(blob) < pos + 4 * (nz + ny):
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
-        zl = np.frombuffer(blob, "<u2", ns, pos).astype(np.int64)
-        yl = np.frombuffer(blob, "<u2", ns, pos + 2 * ns).astype(np.int64)
-        pos += 4 * ns
+        zl = np.frombuffer(blob, "<u4", nz, pos).astype(np.int64)
+        yl = np.frombuffer(blob, "<u4", ny, pos + 4 * nz).astype(np.int64)
+        pos += 4 * (nz + ny)
         zw, yw = int(zl.sum()), int(yl.sum())
         if len(blob) != pos + 2 * (zw + yw):
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
@@ -236,8 +252,8 @@ class Codec:
         with torch.cuda.device(dev):
             zp = torch.from_numpy(np.frombuffer(blob, "<i2", zw, pos).copy()).to(dev)
             yp = torch.from_numpy(np.frombuffer(blob, "<i2", yw, pos + 2 * zw).copy()).to(dev)
-            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, c), dev), (n, hz, wz, c), self.z_tables, group)
+            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, c), dev), (n, hz, wz, c), self.z_tables, sz)
             hyper = m._hyper_synthesis(int_to_float(zi))
-            sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, group)
+            sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy)
             y_hat = ops.dequant_scale_normal(sym, hyper)
             return ops.to_pixels(m._synthesis(y_hat), H, W)

@@ -19,7 +19,7 @@ import torch
 
 from .. import _capi as capi
 from .. import ops
-from ..common import image_utils
+from ..common import data_lib, image_utils
 from ..common.latent_rvs_lib import LatentRVCollection, UQLatentRV
 from ..common.latent_rvs_utils import sga_schedule_at_step
 from ..common.train_lib import Metrics
@@ -209,6 +209,8 @@ class Model:
     # -- inference path (reference :212-232) -----------------------------------------------------
     def _as_device_images(self, x):
         if isinstance(x, np.ndarray):
+            if x.dtype == np.uint8:                                   # raw pixels: scale as data_lib.py:24-25 does
+                x = data_lib.normalize_image(x)
             x = ops.to_device(x, self.device)
         if x.dim() == 3:
             x = x.unsqueeze(0)

@@ -25,32 +25,35 @@ def test_stream_words_match_python_restatement(dev):
     rng = np.random.default_rng(0)
     tabs = ec.normal_tables()
     dt = ec.DeviceTables(tabs, dev)
-    n, P, c = 2, 37, 5
+    n, P, c = 2, 101, 5
     tids = rng.integers(0, 64, size=(n, P, c)).astype(np.int16)
     sig = np.array([0.11 * np.exp(ec.SCALE_FACTOR * k) for k in range(64)])
     vals = np.rint(rng.laplace(0, 1, size=(n, P, c)) * sig[tids] * 1.5).astype(np.int32)
     vals[0, 3, 1] = 20000          # escapes
     vals[1, 0, 0] = -31000
-    for group in (1, 2, 16):                # streams of 1, 2 (last group ragged: 5 channels) and all channels
-        payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt, group)
+    vals[1, 100, 4] = 32767
+    E = P * c                               # 505 elements: 8 steps of 64 lanes, the last one ragged
+    for segs in (1, 2, 3):
+        eseg = -(-(-(-E // segs)) // 64) * 64
+        payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt, segs)
         words = payload.cpu().numpy().view(np.uint16)
         off = np.concatenate([[0], np.cumsum(lens)])
-        sg = -(-c // group)
-        assert len(lens) == n * sg
+        assert len(lens) == n * segs
         for b in range(n):
-            for g in range(sg):
-                s = b * sg + g
-                sl = slice(g * group, min(c, (g + 1) * group))
-                ref = rans_np.encode_stream(vals[b, :, sl].ravel(), tids[b, :, sl].ravel(), tabs)
+            for g in range(segs):
+                s = b * segs + g
+                sl = slice(g * eseg, min(E, (g + 1) * eseg))
+                v, t = vals[b].ravel()[sl], tids[b].ravel()[sl]
+                ref = rans_np.encode_stream(v, t, tabs)
                 got = words[off[s]:off[s + 1]].tolist()
-                assert got == ref, (group, b, g)
-                assert rans_np.decode_stream(got, tids[b, :, sl].ravel(), tabs) == vals[b, :, sl].ravel().tolist()
-        back = ec.rans_decode(payload, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt, group)
+                assert got == ref, (segs, b, g)
+                assert rans_np.decode_stream(got, t, tabs) == v.tolist()
+        back = ec.rans_decode(payload, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt, segs)
         np.testing.assert_array_equal(back.cpu().numpy(), vals)
     payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt)
     # corruption: flip one payload word -> decode must refuse
     bad = payload.clone()
-    bad[5] ^= 0x0100
+    bad[300] ^= 0x0100
     from shallow_ntc_amd import _capi
     with pytest.raises(_capi.SntcError, match="corrupt"):
         ec.rans_decode(bad, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt)

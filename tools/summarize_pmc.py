@@ -21,14 +21,21 @@ for d in dirs:
         for r in csv.DictReader(open(f)):
             if "sntc" in r["Kernel_Name"]:
                 agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg_ns = {}
+stats = Path(__file__).resolve().parent.parent / "profiles" / f"{tag}_decode_only_kernel_stats.csv"
+if stats.exists():
+    for r in csv.DictReader(open(stats)):
+        avg_ns[r["Name"]] = float(r["AverageNs"])
 out = {}
 for k, v in agg.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}
     e = dict(launches=max(len(x) for x in v.values()), counters_mean_per_launch={c: round(val, 1) for c, val in m.items()})
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         e["hbm_side_bytes_per_launch"] = int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("SQ_BUSY_CYCLES"):
-        e["mfma_busy_over_sq_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"], 3)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and k in avg_ns:
+        # SIMD-cycles available in one launch = avg duration x 2.4 GHz x 256 CUs x 4 SIMDs (stats run of the same command)
+        e["avg_launch_ns_from_stats"] = round(avg_ns[k])
+        e["mfma_busy_over_simd_cycles"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg_ns[k] * 2.4 * 1024), 3)
     if m.get("SQ_WAVE_CYCLES"):
         e["wave_cycle_shares"] = {c: round(m[c] / m["SQ_WAVE_CYCLES"], 3) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c in m}
     out[k] = e
