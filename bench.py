@@ -152,11 +152,28 @@ def main():
     t_dec = timed(decode_step, args.steps, args.warmup)
     ms_per_step = 1e3 * t_dec / args.steps
     value = world * pixels_per_step * args.steps / t_dec / 1e6
-    e2e_value, table = None, None
+    e2e_value, table, regions = None, None, None
     if not args.decode_only:
         e2e_steps = max(2, args.steps // 4)
         t_e2e = timed(e2e_step, e2e_steps, 1)
         e2e_value = world * pixels_per_step * e2e_steps / t_e2e / 1e6
+        # the other regions of SURVEY.md 8d, whole job like `value`: encode alone on the metric's set, and
+        # encode+decode on the synthetic 256x256 batches the north star asks for at every GPU count
+        t_enc = timed(lambda: [model.encode(x) for _ids, x, _hw in batches], e2e_steps, 1)
+        w1_x = synthetic_batch(64, 256, 256, 4321 + rank, dev)
+
+        def w1_step():
+            z_hat, sym, _, _ = model.encode(w1_x)
+            model.decode(z_hat, sym, (256, 256), reference=w1_x)
+
+        t_w1 = timed(w1_step, e2e_steps, 1)
+        mpx = lambda px, t: round(world * px * e2e_steps / t / 1e6, 2)
+        regions = dict(
+            decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2)),
+            encode=dict(ms_per_step=round(1e3 * t_enc / e2e_steps, 3), mpixels_per_s=mpx(pixels_per_step, t_enc)),
+            encode_decode_score=dict(ms_per_step=round(1e3 * t_e2e / e2e_steps, 3), mpixels_per_s=round(e2e_value, 2)),
+            w1_encode_decode_score=dict(workload="64 x 256x256 per GPU", ms_per_step=round(1e3 * t_w1 / e2e_steps, 3),
+                                        mpixels_per_s=mpx(64 * 256 * 256, t_w1)))
         rows = []                          # per-image (bpp, psnr, mse) of the rank's set, then ONE all-gather
         for ids, x, hw in batches:
             for d, i in zip(model.evaluate_batched(x), ids):
@@ -167,11 +184,12 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, per launch ---------------
     roofline = None
-    if rank == 0:
+
+    def kernel_table(fn, reps):
         per_kernel = {}
-        for _rep in range(3):
+        for _rep in range(reps):
             ops.PROFILE = []
-            decode_eager()
+            fn()
             torch.cuda.synchronize()
             for e in ops.PROFILE:
                 vec = "true, false" if e["vec"] else "false, true"      # <TM,TN,WM,WN,VEC,PRO> as rocprof prints it
@@ -181,6 +199,10 @@ def main():
                 k["flops"] += e["flops"]
                 k["launches"] += 1
             ops.PROFILE = None
+        return per_kernel
+
+    if rank == 0:
+        per_kernel = kernel_table(decode_eager, 3)
         name, k = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None       # HBM-side bytes per launch from the committed PMC passes (separate runs)
@@ -197,6 +219,15 @@ def main():
                         precision="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                         all_kernels={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                              ms_per_step=round(v["ms"] / 3, 4)) for n, v in per_kernel.items()})
+
+        if not args.decode_only:             # the same table for the analysis side (ELIC encoder: MFMA utilisation)
+            enc = kernel_table(lambda: [model.encode(x) for _ids, x, _hw in batches], 1)
+            tot_ms, tot_fl = sum(v["ms"] for v in enc.values()), sum(v["flops"] for v in enc.values())
+            roofline["encode_kernels"] = dict(
+                conv_tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                conv_ms_per_step=round(tot_ms, 3),
+                by_kernel={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms_per_step=round(v["ms"], 3))
+                           for n, v in sorted(enc.items(), key=lambda kv: -kv[1]["ms"])})
 
     # ---- CPU baseline: the torch-CPU port of the same decode on this box's host cores ---------------
     cpu_baseline = None
@@ -239,7 +270,7 @@ def main():
                         launch="hipGraph replay (one graph per batch shape)" if args.graph else "eager",
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))"),
             encode_decode_mpixels_per_s=None if e2e_value is None else round(e2e_value, 2),
-            rd=rd, roofline=roofline, cpu_baseline=cpu_baseline,
+            regions=regions, rd=rd, roofline=roofline, cpu_baseline=cpu_baseline,
         )
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
