@@ -94,6 +94,9 @@ typedef struct sntc_conv_plan sntc_conv_plan;
 int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* weight, const float* bias,
                           void* stream, sntc_conv_plan** plan);
 void sntc_conv_plan_destroy(sntc_conv_plan* plan);
+/* Re-pack an existing plan from new device weights (and bias: present iff the plan has one); tables and tile
+ * choices are kept.  The training step calls this after every optimizer update. */
+int sntc_conv_plan_update(sntc_conv_plan* plan, const float* weight, const float* bias, void* stream);
 /* Output spatial size for an input of h x w. */
 int sntc_conv_out_shape(const sntc_conv_plan* plan, int h, int w, int* ho, int* wo);
 /* Algorithmic 2*MAC FLOPs of one forward call (dense count, as tf.profiler counts them). */
@@ -261,11 +264,68 @@ int sntc_distortion_grad(const float* x, const float* x_hat, int n, int h, int w
                          float* g_xhat, double* sse, void* stream);
 /* Backward of the activation + residual split of sntc_two_layer_tail: t is the forward input, g_h the gradient
  * w.r.t. h; g_t[npix, cp] = [d act(base) | g_h (if has_res) | zeros up to cp]. */
+/* abs_x / g_x (both [npix, ch], may both be NULL): |base| and g_h * base, the operands of the IGDN1 parameter
+ * gradients of the training step (d gamma = |x|^T (g x) summed over pixels, d beta = column sums of g x). */
 int sntc_two_layer_tail_bwd(const float* t, const float* g_h, int64_t npix, int ch, int has_res, int act_kind,
-                            const float* beta, const float* gamma, int cp, float* g_t, void* stream);
-/* Keras Adam (tf.keras.optimizers.Adam, no amsgrad) on one flat tensor; t = 1-based step. */
+                            const float* beta, const float* gamma, int cp, float* g_t, float* abs_x, float* g_x,
+                            void* stream);
+/* Keras Adam (tf.keras.optimizers.Adam, no amsgrad) on one flat tensor; t = 1-based step; the gradient is
+ * multiplied by grad_scale first (global-norm clipping, optimizer_config.global_clipnorm). */
 int sntc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                   float eps, int64_t t, void* stream);
+                   float eps, int64_t t, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step: Model.train_step, mshyper/models.py:375-383 = tape.gradient of
+ *   frame_loss_given_latent_rvs(training=True) w.r.t. every trainable variable + Adam.
+ *   Input gradients are sntc_conv_forward on adjoint plans (see the SGA note above); the pieces below are the
+ *   weight / bias gradients, the element-wise backward steps and the training-mode entropy terms.
+ * ------------------------------------------------------------------------------------------ */
+/* Weight gradient of a Keras-SAME Conv2D (kind SNTC_CONV2D, kernel [kh,kw,cin,cout]) or Conv2DTranspose
+ * (SNTC_CONV2D_TRANSPOSE, kernel [kh,kw,cout,cin]) layer, in the layer's own kernel layout:
+ *   x      [n,h,w,cin]      the layer input of the forward pass
+ *   g_out  [n,ho,wo,cout]   gradient w.r.t. the PRE-activation output (ho = ceil(h/s) or h*s)
+ *   dw     written, or accumulated into when accumulate != 0.
+ * fp32 MFMA contraction over the pixels, split over blocks, summed in a fixed order (deterministic). */
+int64_t sntc_conv_wgrad_workspace_bytes(int kind, int kh, int kw, int stride, int cin, int cout, int n, int h, int w);
+int sntc_conv_wgrad(int kind, int kh, int kw, int stride, int cin, int cout, const float* x, const float* g_out, int n,
+                    int h, int w, float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* db[c] (= or +=) sum over pixels of g[npix, c] */
+int64_t sntc_bias_grad_workspace_bytes(int64_t npix, int c);
+int sntc_bias_grad(const float* g, int64_t npix, int c, float* db, int accumulate, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+/* g_pre = g * act'(pre) written through the layer output y (relu: y > 0; leaky_relu: 1 or 0.2; sigmoid: y (1 - y)).
+ * g_pre may alias g. */
+int sntc_act_backward(const float* g, const float* y, int64_t total, int act, float* g_pre, void* stream);
+/* SimpleAttention gate unfused (common/elic.py:97-100): out = x + t * s;  g_t = g s, g_spre = g t s (1 - s). */
+int sntc_gate_forward(const float* x, const float* t, const float* s, int64_t total, float* out, void* stream);
+int sntc_gate_backward(const float* g, const float* t, const float* s, int64_t total, float* g_t, float* g_spre, void* stream);
+/* a += alpha * b  (gradient accumulation at fan-outs) */
+int sntc_axpy(float* a, const float* b, float alpha, int64_t total, void* stream);
+/* out = x + U(-.5, .5): tfc's training=True perturbation (uq method "unoise").  noise NULL -> counter-based
+ * generator keyed by (seed, step, element); else float [total] (deterministic tests). */
+int sntc_noise_add(const float* x, int64_t total, const float* noise, uint64_t seed, uint64_t step, float* out, void* stream);
+/* out[0] (double, device) = sum x^2  (global gradient norm) */
+int sntc_sumsq(const float* x, int64_t total, double* out, void* stream);
+/* Hidden layer of TwoLayer[Res]Synthesis unfused: h[npix, ch] = act(t[..., :ch]) (+ t[..., ch:2ch]);
+ * act_kind as in sntc_two_layer_tail. */
+int sntc_two_layer_hidden(const float* t, int64_t npix, int ch, int has_res, int act_kind, const float* beta,
+                          const float* gamma, float* h, void* stream);
+/* tfc.GDNParameter: eff = max(raw, bound)^2 - pedestal, and its gradient (lower_bound "identity_if_towards"). */
+int sntc_gdn_reparam_forward(const float* raw, int64_t total, float bound, float pedestal, float* eff, void* stream);
+int sntc_gdn_reparam_backward(const float* raw, const float* g_eff, int64_t total, float bound, float* g_raw, void* stream);
+/* Rate terms at a given (noisy) sample: bits[n] = -sum log2 p, d bits / d (y~ - mu), d bits / d raw (normal);
+ * d bits / d z~ (deep factorized).  Same formulas as the eval entry points with values_only = 1. */
+int sntc_noisy_normal(const float* y_tilde, const float* hyper, int n, int64_t hw, int c, float* dbits_dv,
+                      float* dbits_draw, double* bits, void* stream);
+/* grad_record (float [sntc_prior_record_floats()], may be NULL): sum over all elements of d bits / d (softplus(matrix),
+ * bias, tanh(factor)) per channel, OVERWRITTEN; turn into raw-variable gradients with sntc_prior_param_grad. */
+int sntc_noisy_factorized(const sntc_prior* prior, const float* z_tilde, int n, int64_t hw, float* dbits_dz,
+                          float* grad_record, double* bits, void* stream);
+int sntc_prior_record_floats(const sntc_prior* prior);
+/* Refresh the prior from DEVICE arrays of the raw variables (layouts of sntc_prior_create). */
+int sntc_prior_update(sntc_prior* prior, const float* matrices, const float* biases, const float* factors, void* stream);
+int sntc_prior_param_grad(const sntc_prior* prior, const float* matrices, const float* factors, const float* grad_record,
+                          float weight, float* g_matrices, float* g_biases, float* g_factors, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sntc_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "sntc_conv_plan_create": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(_P)]),
     "sntc_conv_plan_destroy": (None, [_P]),
+    "sntc_conv_plan_update": (C.c_int, [_P, _P, _P, _P]),
     "sntc_conv_out_shape": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sntc_conv_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_conv_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -81,8 +82,26 @@ SIGNATURES = {
     "sntc_sga_normal_bwd": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, C.c_int, _P, _P, _P]),
     "sntc_sga_chain": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, _P, _P]),
     "sntc_distortion_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
-    "sntc_two_layer_tail_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
-    "sntc_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _P]),
+    "sntc_two_layer_tail_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "sntc_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float, _P]),
+    "sntc_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),
+    "sntc_conv_wgrad": (C.c_int, [C.c_int] * 6 + [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int64, _P]),
+    "sntc_bias_grad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "sntc_bias_grad": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int64, _P]),
+    "sntc_act_backward": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
+    "sntc_gate_forward": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
+    "sntc_gate_backward": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P]),
+    "sntc_axpy": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
+    "sntc_noise_add": (C.c_int, [_P, C.c_int64, _P, C.c_uint64, C.c_uint64, _P, _P]),
+    "sntc_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "sntc_two_layer_hidden": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "sntc_gdn_reparam_forward": (C.c_int, [_P, C.c_int64, C.c_float, C.c_float, _P, _P]),
+    "sntc_gdn_reparam_backward": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P]),
+    "sntc_noisy_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    "sntc_noisy_factorized": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
+    "sntc_prior_record_floats": (C.c_int, [_P]),
+    "sntc_prior_update": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sntc_prior_param_grad": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -203,6 +203,26 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
   return SNTC_OK;
 }
 
+// Re-pack the weights (and bias) of an existing plan from new device arrays: the training step refreshes its forward
+// and adjoint plans after every optimizer update; geometry, tap / column tables and tile choices are unchanged.
+extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, const float* bias, void* stream) {
+  if (!p || !weight) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_update: null argument");
+  if ((bias != nullptr) != (p->bias != nullptr)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_update: bias presence differs from the plan");
+  hipStream_t s = (hipStream_t)stream;
+  const sntc_conv_desc& d = p->d;
+  for (int gi = 0; gi < p->ngroups; ++gi) {
+    auto& G = p->g[gi];
+    const size_t total = (size_t)G.Ncol * G.K;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    if (total > 0)
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, weight, G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K,
+                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0);
+    SNTC_HIP(hipGetLastError());
+  }
+  if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));
+  return SNTC_OK;
+}
+
 struct Geo {
   int Ho, Wo, Qh, Qw, sA, tstep, offy, offx, sO;
 };

@@ -8,6 +8,7 @@
 // Reference: common/latent_rvs_utils.py:8-48 (sga_round), mshyper/models.py:260-268,285-291,343,
 // 397-408 (loss terms and the variables that receive gradients), common/data_lib.py:48-52.
 #include <cmath>
+#include <algorithm>
 #include "sntc_internal.h"
 
 namespace sntc {
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256) sga_normal_bwd_kernel(const float* __rest
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i / c;
     const int ch = (int)(i - p * c);
-    const float g = g_yt[i], sp = sprime[i], dv = w * dbits_dv[i];
+    const float g = g_yt[i], sp = sprime ? sprime[i] : 1.0f, dv = w * dbits_dv[i];
     g_yloc[i] = (g + dv) * sp;
     g_hyper[p * 2 * c + ch] = g * (1.0f - sp) - dv * sp;
     g_hyper[p * 2 * c + c + ch] = w * dbits_draw[i];
@@ -251,7 +252,8 @@ __global__ void __launch_bounds__(256) distortion_grad_kernel(const float* __res
 template <int CH>
 __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__ t, const float* __restrict__ gh, int64_t npix,
                                                        int has_res, int act_kind, const float* __restrict__ beta,
-                                                       const float* __restrict__ gamma, int cp, float* __restrict__ gt) {
+                                                       const float* __restrict__ gamma, int cp, float* __restrict__ gt,
+                                                       float* __restrict__ absx, float* __restrict__ gx) {
   __shared__ float sg[CH * CH];
   __shared__ float sb[CH];
   const bool use_gdn = act_kind == 1 || act_kind == 2;
@@ -271,6 +273,13 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
       g[i] = b[0]; g[i + 1] = b[1]; g[i + 2] = b[2]; g[i + 3] = b[3];
     }
     float* dst = gt + p * cp;
+    if (absx) {                                             // operands of the IGDN1 parameter gradients (train step):
+#pragma unroll                                              //   d gamma = |x|^T (g x) over pixels, d beta = column sums of g x
+      for (int i = 0; i < CH; ++i) {
+        absx[p * CH + i] = fabsf(xv[i]);
+        gx[p * CH + i] = g[i] * xv[i];
+      }
+    }
     if (use_gdn) {
       float u[CH];   // per-j factor multiplying gamma_ij
       float nrm[CH];
@@ -309,14 +318,247 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
 
 // ---- Keras Adam (non-amsgrad): alpha = lr sqrt(1-b2^t)/(1-b1^t); p -= alpha m / (sqrt(v) + eps) ----
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps) {
+                                                   float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps,
+                                                   float gscale) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = gscale * g[i];
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
     p[i] -= alpha * mi / (sqrtf(vi) + eps);
+  }
+}
+
+
+// ---- training-mode entropy terms: the sample is y + U(-.5, .5) (uq method "unoise",
+// mshyper/models.py:253-256,277-280 with training=True); rate and partial derivatives at the given sample ----
+__device__ __forceinline__ void normal_rate_terms(float v, float raw, float* bits, float* dbits_dv, float* dbits_draw) {
+  const float e = expf(raw);
+  const float idx = fminf(fmaxf(e, 0.0f), 63.0f);
+  const float sigma = expf(kLogScaleMin + kScaleFactor * idx);
+  const float hi = (v + 0.5f) / sigma, lo = (v - 0.5f) / sigma;
+  const bool right = hi > 0.0f;
+  const float big = log_ndtr_f(right ? -lo : hi), small = log_ndtr_f(right ? -hi : lo);
+  const float logp = big + log1pf(-expf(small - big));
+  const float r_hi = expf(-0.5f * hi * hi - 0.91893853320467274f - logp);
+  const float r_lo = expf(-0.5f * lo * lo - 0.91893853320467274f - logp);
+  const float dsig_draw = (e > 0.0f && e < 63.0f) ? sigma * kScaleFactor * e : 0.0f;
+  *bits = -logp * kInvLn2;
+  *dbits_dv = -(r_hi - r_lo) / sigma * kInvLn2;
+  *dbits_draw = (r_hi * hi - r_lo * lo) / sigma * dsig_draw * kInvLn2;
+}
+
+__global__ void __launch_bounds__(256) noisy_normal_kernel(const float* __restrict__ y_tilde, const float* __restrict__ hyper,
+                                                           int64_t hw, int c, float* __restrict__ dbits_dv,
+                                                           float* __restrict__ dbits_draw, double* __restrict__ bits) {
+  const int img = blockIdx.y;
+  const int64_t per = hw * c;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c;
+    const int ch = (int)(i - p * c);
+    const int64_t gi = img * per + i;
+    const float mu = hyper[(img * hw + p) * 2 * c + ch];
+    const float raw = hyper[(img * hw + p) * 2 * c + c + ch];
+    float b, dv, dr;
+    normal_rate_terms(y_tilde[gi] - mu, raw, &b, &dv, &dr);
+    dbits_dv[gi] = dv;
+    dbits_draw[gi] = dr;
+    acc += (double)b;
+  }
+  block_sum_to(acc, bits + img);
+}
+
+// d log p / d L(v + .5), d log p / d L(v - .5) and log p of the noisy deep-factorized density at v
+__device__ __forceinline__ void df_logp_terms(float hi, float lo, float* logp, float* dhi, float* dlo) {
+  const bool right = hi > 0.0f;
+  const float big = log_sigmoid_f(right ? -lo : hi), small = log_sigmoid_f(right ? -hi : lo);
+  const float ratio = expf(small - big);
+  *logp = big + log1pf(-ratio);
+  const float inv = 1.0f / (1.0f - ratio);
+  if (!right) {                      // p = s(hi) (1 - ratio), ratio = s(lo) / s(hi)
+    *dhi = sigmoid_f(-hi) * inv;
+    *dlo = -ratio * sigmoid_f(-lo) * inv;
+  } else {                           // p = s(-lo) (1 - ratio), ratio = s(-hi) / s(-lo)
+    *dhi = ratio * sigmoid_f(hi) * inv;
+    *dlo = -sigmoid_f(lo) * inv;
+  }
+}
+
+__global__ void __launch_bounds__(256) noisy_factorized_kernel(const float* __restrict__ rec_all, DFDesc d,
+                                                               const float* __restrict__ z_tilde, int64_t hw, int c,
+                                                               float* __restrict__ dbits_dz, double* __restrict__ bits) {
+  const int img = blockIdx.y;
+  const int64_t per = hw * c;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const int64_t gi = img * per + i;
+    const float v = z_tilde[gi];
+    const float* rec = rec_all + (size_t)ch * d.stride;
+    float hi, dhi, lo, dlo, logp, ghi, glo;
+    df_logits_grad(rec, d, v + 0.5f, &hi, &dhi);
+    df_logits_grad(rec, d, v - 0.5f, &lo, &dlo);
+    df_logp_terms(hi, lo, &logp, &ghi, &glo);
+    dbits_dz[gi] = -(ghi * dhi + glo * dlo) * kInvLn2;
+    acc += (double)(-logp * kInvLn2);
+  }
+  block_sum_to(acc, bits + img);
+}
+
+// Reverse pass through the logits network for one input x and upstream gradient gL: accumulates into the
+// statically indexed gm / gb / gf (record layout: softplus(matrix), bias, tanh(factor)).
+__device__ __forceinline__ void df_logits_param_grad(const float* __restrict__ rec, const DFDesc& d, float x, float gL,
+                                                     float (&gm)[kMaxL][kMaxW * kMaxW], float (&gb)[kMaxL][kMaxW],
+                                                     float (&gf)[kMaxL][kMaxW]) {
+  float hin[kMaxL][kMaxW], th[kMaxL][kMaxW];
+  float hv[kMaxW] = {x, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kMaxL; ++k) {
+    if (k < d.nl) {
+      const int fi = d.w[k], fo = d.w[k + 1];
+      float nv[kMaxW] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < kMaxW; ++i) hin[k][i] = hv[i];
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) {
+        th[k][o] = 0.f;
+        if (o < fo) {
+          float s = rec[d.off_b[k] + o];
+#pragma unroll
+          for (int i = 0; i < kMaxW; ++i)
+            if (i < fi) s += rec[d.off_m[k] + o * fi + i] * hv[i];
+          if (k < d.nl - 1) {
+            th[k][o] = tanhf(s);
+            s += rec[d.off_f[k] + o] * th[k][o];
+          }
+          nv[o] = s;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) hv[o] = nv[o];
+    }
+  }
+  float gh[kMaxW] = {gL, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = kMaxL - 1; k >= 0; --k) {
+    if (k < d.nl) {
+      const int fi = d.w[k], fo = d.w[k + 1];
+      float gin[kMaxW] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) {
+        if (o < fo) {
+          float gs = gh[o];
+          if (k < d.nl - 1) {
+            gf[k][o] += gs * th[k][o];
+            gs *= 1.0f + rec[d.off_f[k] + o] * (1.0f - th[k][o] * th[k][o]);
+          }
+          gb[k][o] += gs;
+#pragma unroll
+          for (int i = 0; i < kMaxW; ++i)
+            if (i < fi) {
+              gm[k][o * kMaxW + i] += gs * hin[k][i];
+              gin[i] += gs * rec[d.off_m[k] + o * fi + i];
+            }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxW; ++i) gh[i] = gin[i];
+    }
+  }
+}
+
+// grad_rec[ch][.] += sum over this block's pixels of d bits / d record; thread = (channel, pixel row of 4)
+__global__ void __launch_bounds__(256) factorized_param_grad_kernel(const float* __restrict__ rec_all, DFDesc d,
+                                                                    const float* __restrict__ z_tilde, int64_t npix, int c,
+                                                                    int64_t pslab, float* __restrict__ grad_rec) {
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  if (ch >= c) return;
+  const float* rec = rec_all + (size_t)ch * d.stride;
+  float gm[kMaxL][kMaxW * kMaxW], gb[kMaxL][kMaxW], gf[kMaxL][kMaxW];
+#pragma unroll
+  for (int k = 0; k < kMaxL; ++k) {
+#pragma unroll
+    for (int e = 0; e < kMaxW * kMaxW; ++e) gm[k][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < kMaxW; ++e) { gb[k][e] = 0.f; gf[k][e] = 0.f; }
+  }
+  const int64_t p0 = blockIdx.y * pslab, p1 = p0 + pslab < npix ? p0 + pslab : npix;
+  for (int64_t p = p0 + r; p < p1; p += 4) {
+    const float v = z_tilde[p * c + ch];
+    float hi, dhi, lo, dlo, logp, ghi, glo;
+    df_logits_grad(rec, d, v + 0.5f, &hi, &dhi);
+    df_logits_grad(rec, d, v - 0.5f, &lo, &dlo);
+    df_logp_terms(hi, lo, &logp, &ghi, &glo);
+    df_logits_param_grad(rec, d, v + 0.5f, -ghi * kInvLn2, gm, gb, gf);
+    df_logits_param_grad(rec, d, v - 0.5f, -glo * kInvLn2, gm, gb, gf);
+  }
+  float* dst = grad_rec + (size_t)ch * d.stride;
+#pragma unroll
+  for (int k = 0; k < kMaxL; ++k) {
+    if (k < d.nl) {
+      const int fi = d.w[k], fo = d.w[k + 1];
+#pragma unroll
+      for (int o = 0; o < kMaxW; ++o) {
+        if (o < fo) {
+#pragma unroll
+          for (int i = 0; i < kMaxW; ++i)
+            if (i < fi) atomicAdd(dst + d.off_m[k] + o * fi + i, gm[k][o * kMaxW + i]);
+          atomicAdd(dst + d.off_b[k] + o, gb[k][o]);
+          if (k < d.nl - 1) atomicAdd(dst + d.off_f[k] + o, gf[k][o]);
+        }
+      }
+    }
+  }
+}
+
+// record <- raw variables (device arrays in the sntc_prior_create layout): softplus(matrix), bias, tanh(factor)
+__global__ void __launch_bounds__(256) prior_update_kernel(DFDesc d, int c, const float* __restrict__ mats, const float* __restrict__ bias,
+                                                           const float* __restrict__ fac, float* __restrict__ rec) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float* r = rec + (size_t)ch * d.stride;
+  size_t pm = 0, pb = 0, pf = 0;
+  for (int k = 0; k < d.nl; ++k) {
+    const int fi = d.w[k], fo = d.w[k + 1];
+    for (int e = 0; e < fo * fi; ++e) {
+      const float m = mats[pm + (size_t)ch * fo * fi + e];
+      r[d.off_m[k] + e] = m > 30.0f ? m : log1pf(expf(m));
+    }
+    for (int e = 0; e < fo; ++e) r[d.off_b[k] + e] = bias[pb + (size_t)ch * fo + e];
+    if (k < d.nl - 1)
+      for (int e = 0; e < fo; ++e) r[d.off_f[k] + e] = tanhf(fac[pf + (size_t)ch * fo + e]);
+    pm += (size_t)c * fo * fi;
+    pb += (size_t)c * fo;
+    if (k < d.nl - 1) pf += (size_t)c * fo;
+  }
+}
+
+// gradients w.r.t. the raw variables from gradients w.r.t. the record: d softplus = sigmoid, d tanh = 1 - tanh^2
+__global__ void __launch_bounds__(256) prior_param_grad_kernel(DFDesc d, int c, const float* __restrict__ mats, const float* __restrict__ fac,
+                                                               const float* __restrict__ grec, float w, float* __restrict__ gm,
+                                                               float* __restrict__ gb, float* __restrict__ gf) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float* g = grec + (size_t)ch * d.stride;
+  size_t pm = 0, pb = 0, pf = 0;
+  for (int k = 0; k < d.nl; ++k) {
+    const int fi = d.w[k], fo = d.w[k + 1];
+    for (int e = 0; e < fo * fi; ++e) {
+      const size_t at = pm + (size_t)ch * fo * fi + e;
+      gm[at] = w * g[d.off_m[k] + e] * sigmoid_f(mats[at]);
+    }
+    for (int e = 0; e < fo; ++e) gb[pb + (size_t)ch * fo + e] = w * g[d.off_b[k] + e];
+    if (k < d.nl - 1)
+      for (int e = 0; e < fo; ++e) {
+        const size_t at = pf + (size_t)ch * fo + e;
+        const float t = tanhf(fac[at]);
+        gf[at] = w * g[d.off_f[k] + e] * (1.0f - t * t);
+      }
+    pm += (size_t)c * fo * fi;
+    pb += (size_t)c * fo;
+    if (k < d.nl - 1) pf += (size_t)c * fo;
   }
 }
 
@@ -345,7 +587,7 @@ extern "C" int sntc_sga_normal_fwd(const float* y_loc, const float* hyper, int n
 
 extern "C" int sntc_sga_normal_bwd(const float* g_ytilde, const float* sprime, const float* dbits_dv, const float* dbits_draw,
                                    float weight, int64_t npix, int c, float* g_yloc, float* g_hyper, void* stream) {
-  if (!g_ytilde || !sprime || !dbits_dv || !dbits_draw || !g_yloc || !g_hyper)
+  if (!g_ytilde || !dbits_dv || !dbits_draw || !g_yloc || !g_hyper)          // sprime == NULL: additive noise, d sample / d loc = 1
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_normal_bwd: null argument");
   hipLaunchKernelGGL(sga_normal_bwd_kernel, dim3(grid_for(npix * c)), dim3(256), 0, (hipStream_t)stream, g_ytilde, sprime,
                      dbits_dv, dbits_draw, weight, npix, c, g_yloc, g_hyper);
@@ -393,34 +635,90 @@ extern "C" int sntc_distortion_grad(const float* x, const float* x_hat, int n, i
 
 template <int CH>
 static int launch_tail_bwd(const float* t, const float* gh, int64_t npix, int has_res, int act_kind, const float* beta,
-                           const float* gamma, int cp, float* gt, hipStream_t s) {
+                           const float* gamma, int cp, float* gt, float* absx, float* gx, hipStream_t s) {
   hipLaunchKernelGGL((tail_bwd_kernel<CH>), dim3(grid_for(npix)), dim3(256), 0, s, t, gh, npix, has_res, act_kind, beta, gamma,
-                     cp, gt);
+                     cp, gt, absx, gx);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }
 
 extern "C" int sntc_two_layer_tail_bwd(const float* t, const float* g_h, int64_t npix, int ch, int has_res, int act_kind,
-                                       const float* beta, const float* gamma, int cp, float* g_t, void* stream) {
+                                       const float* beta, const float* gamma, int cp, float* g_t, float* abs_x, float* g_x,
+                                       void* stream) {
   if (!t || !g_h || !g_t || npix < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: null argument");
   if (cp < ch * (has_res ? 2 : 1)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: padded channel count too small");
   if ((act_kind == 1 || act_kind == 2) && (!beta || !gamma))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: GDN parameters missing");
+  if ((abs_x == nullptr) != (g_x == nullptr)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_bwd: abs_x and g_x go together");
   hipStream_t s = (hipStream_t)stream;
   switch (ch) {
-    case 12: return launch_tail_bwd<12>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, s);
-    case 24: return launch_tail_bwd<24>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, s);
-    case 48: return launch_tail_bwd<48>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, s);
+    case 12: return launch_tail_bwd<12>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, abs_x, g_x, s);
+    case 24: return launch_tail_bwd<24>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, abs_x, g_x, s);
+    case 48: return launch_tail_bwd<48>(t, g_h, npix, has_res, act_kind, beta, gamma, cp, g_t, abs_x, g_x, s);
     default: return fail(SNTC_ERR_UNSUPPORTED, "sntc_two_layer_tail_bwd: hidden channels must be 12, 24 or 48");
   }
 }
 
 extern "C" int sntc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
-                              float beta2, float eps, int64_t t, void* stream) {
+                              float beta2, float eps, int64_t t, float grad_scale, void* stream) {
   if (!param || !grad || !m || !v || n < 1 || t < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_adam_step: bad argument");
   const double alpha = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, (float)alpha,
-                     beta1, beta2, eps);
+                     beta1, beta2, eps, grad_scale);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+// ---- training-mode entropy entry points ----
+extern "C" int sntc_noisy_normal(const float* y_tilde, const float* hyper, int n, int64_t hw, int c, float* dbits_dv,
+                                 float* dbits_draw, double* bits, void* stream) {
+  if (!y_tilde || !hyper || !dbits_dv || !dbits_draw || !bits) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_normal: null argument");
+  if (n < 1 || hw < 1 || c < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_normal: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  hipLaunchKernelGGL(noisy_normal_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, y_tilde, hyper, hw, c, dbits_dv, dbits_draw, bits);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_prior_record_floats(const sntc_prior* prior) { return prior ? prior->channels * prior->d.stride : -1; }
+
+extern "C" int sntc_noisy_factorized(const sntc_prior* prior, const float* z_tilde, int n, int64_t hw, float* dbits_dz,
+                                     float* grad_record, double* bits, void* stream) {
+  if (!prior || !z_tilde || !dbits_dz || !bits) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_factorized: null argument");
+  if (n < 1 || hw < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_factorized: bad sizes");
+  const int c = prior->channels;
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  hipLaunchKernelGGL(noisy_factorized_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, prior->rec, prior->d, z_tilde, hw, c,
+                     dbits_dz, bits);
+  SNTC_HIP(hipGetLastError());
+  if (grad_record) {                         // sum over ALL elements of d bits / d record (caller applies the loss weight)
+    SNTC_HIP(hipMemsetAsync(grad_record, 0, sizeof(float) * (size_t)c * prior->d.stride, s));
+    const int64_t npix = (int64_t)n * hw;
+    const int64_t slabs = std::min<int64_t>(64, (npix + 63) / 64);
+    const int64_t pslab = (npix + slabs - 1) / slabs;
+    hipLaunchKernelGGL(factorized_param_grad_kernel, dim3((c + 63) / 64, (unsigned)slabs), dim3(256), 0, s, prior->rec, prior->d,
+                       z_tilde, npix, c, pslab, grad_record);
+    SNTC_HIP(hipGetLastError());
+  }
+  return SNTC_OK;
+}
+
+extern "C" int sntc_prior_update(sntc_prior* prior, const float* matrices, const float* biases, const float* factors, void* stream) {
+  if (!prior || !matrices || !biases || (prior->d.nl > 1 && !factors)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_prior_update: null argument");
+  hipLaunchKernelGGL(prior_update_kernel, dim3((prior->channels + 255) / 256), dim3(256), 0, (hipStream_t)stream, prior->d,
+                     prior->channels, matrices, biases, factors, prior->rec);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_prior_param_grad(const sntc_prior* prior, const float* matrices, const float* factors, const float* grad_record,
+                                     float weight, float* g_matrices, float* g_biases, float* g_factors, void* stream) {
+  if (!prior || !matrices || !grad_record || !g_matrices || !g_biases || (prior->d.nl > 1 && (!factors || !g_factors)))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_prior_param_grad: null argument");
+  hipLaunchKernelGGL(prior_param_grad_kernel, dim3((prior->channels + 255) / 256), dim3(256), 0, (hipStream_t)stream, prior->d,
+                     prior->channels, matrices, factors, grad_record, weight, g_matrices, g_biases, g_factors);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }

@@ -74,6 +74,10 @@ class ConvPlan:
                 pass
             self._h = None
 
+    def update(self, weight, bias=None):
+        """Re-pack from new device weights (training step); the arrays are read asynchronously on the current stream."""
+        capi.call("sntc_conv_plan_update", self._h, _ptr(weight), _ptr(bias), _stream())
+
     def out_hw(self, h, w):
         ho, wo = C.c_int(), C.c_int()
         capi.call("sntc_conv_out_shape", self._h, h, w, C.byref(ho), C.byref(wo))
@@ -321,20 +325,112 @@ def distortion_grad(x, x_hat, scale):
     return g, sse
 
 
-def two_layer_tail_bwd(t, g_h, ch, has_res, act_kind, beta, gamma, cp):
+def two_layer_tail_bwd(t, g_h, ch, has_res, act_kind, beta, gamma, cp, param_operands=False):
+    """-> g_t, or (g_t, |base|, g_h * base) when ``param_operands`` (the IGDN1 parameter-gradient operands)."""
     _check_nhwc(t, ch * (2 if has_res else 1))
     _check_nhwc(g_h, ch)
     n, hh, wh, _ = t.shape
     g_t = torch.empty((n, hh, wh, cp), dtype=torch.float32, device=t.device)
+    ax = torch.empty((n, hh, wh, ch), dtype=torch.float32, device=t.device) if param_operands else None
+    gx = torch.empty_like(ax) if param_operands else None
     capi.call("sntc_two_layer_tail_bwd", _ptr(t), _ptr(g_h), n * hh * wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma),
-              cp, _ptr(g_t), _stream())
-    return g_t
+              cp, _ptr(g_t), _ptr(ax), _ptr(gx), _stream())
+    return (g_t, ax, gx) if param_operands else g_t
 
 
-def adam_step(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-7):
+def adam_step(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
     """In-place Keras Adam update of ``param`` (and its moments m, v); t is the 1-based step."""
     capi.call("sntc_adam_step", _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), float(lr), float(beta1),
-              float(beta2), float(eps), int(t), _stream())
+              float(beta2), float(eps), int(t), float(grad_scale), _stream())
+
+
+# ------------------------------------------------------------------------------------------
+# Training step pieces (SURVEY.md 8 f4)
+# ------------------------------------------------------------------------------------------
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """One growing scratch buffer per device for the split-K slabs of the gradient kernels."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(int(nbytes), 1 << 20),), dtype=torch.uint8, device=device)
+        _WS[device] = buf
+    return buf
+
+
+def conv_wgrad(kind, k, stride, cin, cout, x, g_out, dw, accumulate=False):
+    """dw (the layer's kernel layout, flat or shaped) = or += d loss / d kernel; g_out is the pre-activation gradient."""
+    _check_nhwc(x, cin)
+    _check_nhwc(g_out, cout)
+    n, h, w, _ = x.shape
+    kid = KINDS[kind]
+    need = capi.load().sntc_conv_wgrad_workspace_bytes(kid, k, k, stride, cin, cout, n, h, w)
+    if need < 0:
+        raise capi.SntcError(capi.ERR_UNSUPPORTED, capi.last_error())
+    ws = _workspace(need, x.device)
+    capi.call("sntc_conv_wgrad", kid, k, k, stride, cin, cout, _ptr(x), _ptr(g_out), n, h, w, _ptr(dw), int(accumulate), _ptr(ws),
+              ws.numel(), _stream())
+
+
+def bias_grad(g, db, accumulate=False):
+    c = g.shape[-1]
+    npix = g.numel() // c
+    need = capi.load().sntc_bias_grad_workspace_bytes(npix, c)
+    ws = _workspace(need, g.device)
+    capi.call("sntc_bias_grad", _ptr(g), npix, c, _ptr(db), int(accumulate), _ptr(ws), ws.numel(), _stream())
+
+
+def act_backward(g, y, act, out=None):
+    out = torch.empty_like(g) if out is None else out
+    capi.call("sntc_act_backward", _ptr(g), _ptr(y), g.numel(), ACTS[act], _ptr(out), _stream())
+    return out
+
+
+def gate_forward(x, t, s):
+    out = torch.empty_like(x)
+    capi.call("sntc_gate_forward", _ptr(x), _ptr(t), _ptr(s), x.numel(), _ptr(out), _stream())
+    return out
+
+
+def gate_backward(g, t, s):
+    g_t, g_s = torch.empty_like(g), torch.empty_like(g)
+    capi.call("sntc_gate_backward", _ptr(g), _ptr(t), _ptr(s), g.numel(), _ptr(g_t), _ptr(g_s), _stream())
+    return g_t, g_s
+
+
+def axpy(a, b, alpha=1.0):
+    capi.call("sntc_axpy", _ptr(a), _ptr(b), float(alpha), a.numel(), _stream())
+    return a
+
+
+def noise_add(x, noise=None, seed=0, step=0):
+    out = torch.empty_like(x)
+    capi.call("sntc_noise_add", _ptr(x), x.numel(), _ptr(noise), int(seed), int(step), _ptr(out), _stream())
+    return out
+
+
+def sumsq(x):
+    out = torch.empty((1,), dtype=torch.float64, device=x.device)
+    capi.call("sntc_sumsq", _ptr(x), x.numel(), _ptr(out), _stream())
+    return out
+
+
+def two_layer_hidden(t, ch, has_res, act_kind, beta, gamma):
+    n, hh, wh, _ = t.shape
+    h = torch.empty((n, hh, wh, ch), dtype=torch.float32, device=t.device)
+    capi.call("sntc_two_layer_hidden", _ptr(t), n * hh * wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma), _ptr(h), _stream())
+    return h
+
+
+def noisy_normal(y_tilde, hyper):
+    """-> (bits[n] float64, d bits / d (y~ - mu), d bits / d raw)."""
+    n, h, w, c = y_tilde.shape
+    dv, dr = torch.empty_like(y_tilde), torch.empty_like(y_tilde)
+    bits = torch.empty((n,), dtype=torch.float64, device=y_tilde.device)
+    capi.call("sntc_noisy_normal", _ptr(y_tilde), _ptr(hyper), n, h * w, c, _ptr(dv), _ptr(dr), _ptr(bits), _stream())
+    return bits, dv, dr
 
 
 # ------------------------------------------------------------------------------------------

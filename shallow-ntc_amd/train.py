@@ -1,0 +1,487 @@
+"""Training step: ``Model.train_step`` of the reference (mshyper/models.py:375-383) =
+tape.gradient of ``end_to_end_frame_loss(training=True)`` w.r.t. every trainable variable + Keras Adam with
+``global_clipnorm`` and the CompressionSchedule learning rate (common/schedule.py:155-176).
+
+There is no autograd here: the backward pass is written out layer by layer.
+  * forward            the same gather-GEMM plans as inference (bias / activation / residual fused), activations kept;
+  * input gradients    adjoint plans: the adjoint of Conv2D is Conv2DTranspose on the SAME kernel array and vice versa;
+  * weight gradients   sntc_conv_wgrad (fp32 MFMA contraction over pixels), bias gradients sntc_bias_grad;
+  * entropy terms      uniform-noise samples (uq method 'unoise'), analytic d bits / d (sample, mean, raw scale, prior);
+  * optimizer          every variable lives in ONE flat float32 buffer (parameters, gradients, Adam moments), laid
+                       out in backward order, so the data-parallel all-reduce (RCCL) runs on a few large contiguous
+                       buckets that are launched as soon as their last gradient is written, overlapping the rest of
+                       the backward pass; Adam is one kernel over the whole buffer.
+Trainable here: Conv2D / Conv2DTranspose stacks, ELIC residual / attention blocks, the two-layer syntheses with
+IGDN1 (reparameterised beta / gamma as in tfc.GDNParameter), the deep-factorized prior -- i.e. the reference's
+two_layer_syn / two_layer_syn2 / jpegl training configs.  GDN-based analysis transforms and SignalConv2D (RDFT
+kernels) are not.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from . import ops
+from .common._graph import GDN, Conv, ResidualBlock, Seq, SimpleAttention
+from .common.transforms import _TwoLayerBase
+
+GDN_OFFSET = 2.0 ** -18           # tfc.GDNParameter: reparam_offset; pedestal = offset^2
+GDN_BETA_MIN = 1e-6               # tfc.GDN beta_min; gamma's minimum is 0
+
+
+class FlatStore:
+    """All trainable variables in one flat device buffer (+ gradient and Adam moments of the same layout)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._arrays = OrderedDict()
+        self.offsets = OrderedDict()
+        self.marks = OrderedDict()         # bucket name -> end offset (backward order)
+
+    def add(self, name, array):
+        if name in self._arrays:
+            raise KeyError(f"duplicate variable {name}")
+        self._arrays[name] = np.ascontiguousarray(array, dtype=np.float32)
+
+    def mark(self, bucket):
+        self.marks[bucket] = len(self._arrays)       # turned into an end offset by finalize()
+
+    def finalize(self):
+        total, host, ends = 0, [], []
+        for name, a in self._arrays.items():
+            self.offsets[name] = (total, a.shape)
+            total += a.size
+            pad = (-total) % 4                       # keep every variable 16-byte aligned
+            host.append(a.ravel())
+            if pad:
+                host.append(np.zeros(pad, np.float32))
+                total += pad
+            ends.append(total)
+        self.total = total
+        self.marks = OrderedDict((b, ends[cnt - 1] if cnt else 0) for b, cnt in self.marks.items())
+        flat = np.concatenate(host) if host else np.zeros(0, np.float32)
+        with torch.cuda.device(self.device):
+            self.param = ops.to_device(flat, self.device)
+            self.grad = torch.zeros_like(self.param)
+            self.m = torch.zeros_like(self.param)
+            self.v = torch.zeros_like(self.param)
+        self._arrays = None
+        return self
+
+    def _view(self, buf, name):
+        off, shape = self.offsets[name]
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def p(self, name):
+        return self._view(self.param, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def export(self, buf=None):
+        host = (self.param if buf is None else buf).cpu().numpy()
+        return OrderedDict((k, host[o:o + int(np.prod(s))].reshape(s).copy()) for k, (o, s) in self.offsets.items())
+
+
+class TConv:
+    """One trainable convolution: forward plan, adjoint plan, weight / bias gradients."""
+
+    def __init__(self, store, name, kind, k, s, cin, cout, act, bias, add_res=False):
+        if kind not in ("conv", "convT"):
+            raise NotImplementedError(f"{name}: {kind} layers (tfc.SignalConv2D, RDFT-reparameterised) are not trainable here")
+        self.name, self.kind, self.k, self.s, self.cin, self.cout, self.act = name, kind, k, s, cin, cout, act
+        self.W, self.gW = store.p(f"{name}/kernel"), store.g(f"{name}/kernel")
+        self.b = store.p(f"{name}/bias") if bias else None
+        self.gb = store.g(f"{name}/bias") if bias else None
+        self.fwd_plan = ops.ConvPlan(kind, self.W, self.b, s, act, capi.PRO_NONE, capi.EPI_ADD if add_res else capi.EPI_STORE)
+        # kernel [kh,kw,Cin,Cout] of a Conv2D == kernel [kh,kw,Cout',Cin'] of its adjoint Conv2DTranspose (and vice versa)
+        self.adj_plan = ops.ConvPlan("convT" if kind == "conv" else "conv", self.W, None, s, None)
+
+    def refresh(self):
+        self.fwd_plan.update(self.W, self.b)
+        self.adj_plan.update(self.W, None)
+
+    def fwd(self, x, res=None):
+        y = self.fwd_plan(x, res)
+        return y, (x, y)
+
+    def bwd(self, ctx, g, need_dx=True, act_folded=False):
+        x, y = ctx
+        if self.act is not None and not act_folded:
+            g = ops.act_backward(g, y, self.act)
+        ops.conv_wgrad(self.kind, self.k, self.s, self.cin, self.cout, x, g, self.gW)
+        if self.gb is not None:
+            ops.bias_grad(g, self.gb)
+        return self.adj_plan(g) if need_dx else None
+
+    def convs(self):
+        return [self]
+
+
+class TSeq:
+    def __init__(self, items):
+        self.items = items
+
+    def fwd(self, x):
+        ctxs = []
+        for it in self.items:
+            x, c = it.fwd(x)
+            ctxs.append(c)
+        return x, ctxs
+
+    def bwd(self, ctxs, g, need_dx=True):
+        for i in range(len(self.items) - 1, -1, -1):
+            g = self.items[i].bwd(ctxs[i], g, need_dx or i > 0)
+        return g
+
+    def convs(self):
+        return [c for it in self.items for c in it.convs()]
+
+
+class TResidualBlock:
+    """x + conv1x1(relu(conv3x3(relu(conv1x1(x)))))  (elic.py:41-68); the skip rides on the last conv's epilogue."""
+
+    def __init__(self, c0, c1, c2):
+        self.c = (c0, c1, c2)
+
+    def fwd(self, x):
+        h0, k0 = self.c[0].fwd(x)
+        h1, k1 = self.c[1].fwd(h0)
+        y, k2 = self.c[2].fwd(h1, res=x)
+        return y, (k0, k1, k2)
+
+    def bwd(self, ctx, g, need_dx=True):
+        d = self.c[2].bwd(ctx[2], g)
+        d = self.c[1].bwd(ctx[1], d)
+        d = self.c[0].bwd(ctx[0], d)
+        return ops.axpy(d, g)                      # + the skip path
+
+    def convs(self):
+        return list(self.c)
+
+
+class TAttention:
+    """x + trunk(x) * sigmoid(conv1x1(branch(x)))  (elic.py:71-100), gate unfused so that the sigmoid output is kept."""
+
+    def __init__(self, trunk, branch, gate):
+        self.trunk, self.branch, self.gate = TSeq(trunk), TSeq(branch), gate
+
+    def fwd(self, x):
+        t, kt = self.trunk.fwd(x)
+        b, kb = self.branch.fwd(x)
+        s, kg = self.gate.fwd(b)
+        return ops.gate_forward(x, t, s), (kt, kb, kg, t, s)
+
+    def bwd(self, ctx, g, need_dx=True):
+        kt, kb, kg, t, s = ctx
+        g_t, g_spre = ops.gate_backward(g, t, s)
+        d_b = self.gate.bwd(kg, g_spre, act_folded=True)
+        dx = self.trunk.bwd(kt, g_t)
+        ops.axpy(dx, self.branch.bwd(kb, d_b))
+        return ops.axpy(dx, g)
+
+    def convs(self):
+        return self.trunk.convs() + self.branch.convs() + [self.gate]
+
+
+class TTwoLayer:
+    """TwoLayer[Res]Synthesis (transforms.py:298-361) unfused for training: one stride-8 transposed conv producing
+    [base | res], the hidden layer (IGDN1 + add), the 5x5/2 output layer."""
+
+    def __init__(self, store, pre, t: _TwoLayerBase, cin):
+        self.t, self.pre = t, pre
+        c2 = t._ch * (2 if t._has_res else 1)
+        self.up = TConv(store, f"{pre}/up", "convT", t._k[0], t._s[0], cin, c2, None, True)
+        self.out = TConv(store, f"{pre}/{t._names[2]}", "convT", t._k[1], t._s[1], t._ch, t._out_ch, None, True)
+        self.gdn = t._act_kind == 1
+        if t._act_kind == 2:
+            raise NotImplementedError("a forward GDN1 hidden activation is not trainable here (the reference configs use igdn)")
+        if self.gdn:
+            self.beta_raw, self.g_beta_raw = store.p(f"{pre}/act/beta_raw"), store.g(f"{pre}/act/beta_raw")
+            self.gamma_raw, self.g_gamma_raw = store.p(f"{pre}/act/gamma_raw"), store.g(f"{pre}/act/gamma_raw")
+            self.beta, self.gamma = torch.empty_like(self.beta_raw), torch.empty_like(self.gamma_raw)
+            self.g_beta, self.g_gamma = torch.empty_like(self.beta_raw), torch.empty_like(self.gamma_raw)
+            self.pedestal = GDN_OFFSET ** 2
+            self.beta_bound = math.sqrt(GDN_BETA_MIN + self.pedestal)
+            self.gamma_bound = GDN_OFFSET
+        else:
+            self.beta = self.gamma = None
+
+    def refresh(self):
+        if self.gdn:
+            capi.call("sntc_gdn_reparam_forward", ops._ptr(self.beta_raw), self.beta_raw.numel(), self.beta_bound, self.pedestal,
+                      ops._ptr(self.beta), ops._stream())
+            capi.call("sntc_gdn_reparam_forward", ops._ptr(self.gamma_raw), self.gamma_raw.numel(), self.gamma_bound, self.pedestal,
+                      ops._ptr(self.gamma), ops._stream())
+
+    def fwd(self, x):
+        t = self.t
+        mid, k_up = self.up.fwd(x)
+        h = ops.two_layer_hidden(mid, t._ch, t._has_res, t._act_kind, self.beta, self.gamma)
+        out, k_out = self.out.fwd(h)
+        return out, (k_up, k_out, mid)
+
+    def bwd(self, ctx, g, need_dx=True):
+        t = self.t
+        k_up, k_out, mid = ctx
+        g_h = self.out.bwd(k_out, g)
+        c2 = t._ch * (2 if t._has_res else 1)
+        if self.gdn:
+            g_t, ax, gx = ops.two_layer_tail_bwd(mid, g_h, t._ch, t._has_res, t._act_kind, self.beta, self.gamma, c2, param_operands=True)
+            # d gamma[i, j] = sum_p |x_i| (g x)_j: a 1x1 "convolution" weight gradient; d beta = column sums of g x
+            ops.conv_wgrad("conv", 1, 1, t._ch, t._ch, ax, gx, self.g_gamma)
+            ops.bias_grad(gx, self.g_beta)
+            capi.call("sntc_gdn_reparam_backward", ops._ptr(self.beta_raw), ops._ptr(self.g_beta), self.g_beta.numel(), self.beta_bound,
+                      ops._ptr(self.g_beta_raw), ops._stream())
+            capi.call("sntc_gdn_reparam_backward", ops._ptr(self.gamma_raw), ops._ptr(self.g_gamma), self.g_gamma.numel(),
+                      self.gamma_bound, ops._ptr(self.g_gamma_raw), ops._stream())
+        else:
+            g_t = ops.two_layer_tail_bwd(mid, g_h, t._ch, t._has_res, t._act_kind, None, None, c2)
+        return self.up.bwd(k_up, g_t, need_dx)
+
+    def convs(self):
+        return [self.up, self.out]
+
+
+def gdn_raw(effective, minimum):
+    pedestal = GDN_OFFSET ** 2
+    return np.sqrt(np.maximum(np.asarray(effective, np.float64) + pedestal, pedestal)).astype(np.float32)
+
+
+def gdn_effective(raw, minimum):
+    pedestal = GDN_OFFSET ** 2
+    return (np.maximum(np.asarray(raw, np.float64), math.sqrt(minimum + pedestal)) ** 2 - pedestal).astype(np.float32)
+
+
+class Trainer:
+    """Owns the training state of a mean-scale hyperprior ``Model`` and runs ``train_step``."""
+
+    BUCKETS = ("synthesis", "prior", "hyper_synthesis", "hyper_analysis", "analysis")   # backward order
+
+    def __init__(self, model, seed=0):
+        if model.factorized:
+            raise NotImplementedError("the training step is implemented for the mean-scale hyperprior model")
+        uq = model._latent_config["uq"].get("method", "unoise")
+        if uq != "unoise":
+            raise NotImplementedError(f"training with uq method {uq!r} (the shipped training configs use 'unoise')")
+        self.m = model
+        self.device = model.device
+        self.seed = seed
+        self.store = FlatStore(self.device)
+        w = model.get_weights()
+        tr = model._transforms()
+        b, hb = model._bottleneck_size, model._hyper_bottleneck_size
+        cins = dict(analysis=3, synthesis=b, hyper_analysis=b, hyper_synthesis=hb)
+        self._two_layer = isinstance(tr["synthesis"], _TwoLayerBase)
+        # ---- variable inventory, in backward order (see module docstring) ----
+        for bucket in self.BUCKETS:
+            if bucket == "prior":
+                nl = len(model._prior_num_filters) + 1
+                for kind, cnt in (("matrix", nl), ("bias", nl), ("factor", nl - 1)):      # per kind, layer order: the C-ABI layout
+                    for k in range(cnt):
+                        self.store.add(f"prior/{kind}_{k}", w[f"prior/{kind}_{k}"])
+            elif bucket == "synthesis" and self._two_layer:
+                self._add_two_layer(tr["synthesis"], w)
+            else:
+                names = [k for k in w if k.startswith(bucket + "/")]
+                for k in reversed(names):
+                    self.store.add(k, w[k])
+            self.store.mark(bucket)
+        self.store.finalize()
+        with torch.cuda.device(self.device):
+            self.analysis = self._build(tr["analysis"]._graph, "analysis", 3)[0]
+            self.hyper_analysis = self._build(tr["hyper_analysis"]._graph, "hyper_analysis", b)[0]
+            self.hyper_synthesis = self._build(tr["hyper_synthesis"]._graph, "hyper_synthesis", hb)[0]
+            if self._two_layer:
+                self.synthesis = TTwoLayer(self.store, "synthesis", tr["synthesis"], b)
+            else:
+                self.synthesis = self._build(tr["synthesis"]._graph, "synthesis", b)[0]
+            self._prior = model._get_prior()
+            if model._prior_channels() % 4:
+                raise NotImplementedError("the flat prior layout needs a hyper-latent channel count divisible by 4")
+            self._prior_names = dict(m=self.store.offsets["prior/matrix_0"][0], b=self.store.offsets["prior/bias_0"][0],
+                                     f=self.store.offsets.get("prior/factor_0", (0, ()))[0])
+            self._grad_rec = torch.empty((capi.load().sntc_prior_record_floats(self._prior._h),), dtype=torch.float32, device=self.device)
+            self._refresh()
+        self.step_count = 0
+        self._handles = []
+
+    # ---- construction -----------------------------------------------------------------------------
+    def _add_two_layer(self, t, w):
+        n1, nr, n2 = t._names
+        k1, b1 = w[f"synthesis/{n1}/kernel"], w[f"synthesis/{n1}/bias"]
+        if nr:
+            k1 = np.concatenate([k1, w[f"synthesis/{nr}/kernel"]], axis=2)
+            b1 = np.concatenate([b1, w[f"synthesis/{nr}/bias"]])
+        self.store.add(f"synthesis/{n2}/kernel", w[f"synthesis/{n2}/kernel"])
+        self.store.add(f"synthesis/{n2}/bias", w[f"synthesis/{n2}/bias"])
+        if t._act_kind == 1:
+            self.store.add("synthesis/act/beta_raw", gdn_raw(w["synthesis/act/beta"], GDN_BETA_MIN))
+            self.store.add("synthesis/act/gamma_raw", gdn_raw(w["synthesis/act/gamma"], 0.0))
+        self.store.add("synthesis/up/kernel", k1)
+        self.store.add("synthesis/up/bias", b1)
+
+    def _conv(self, pre, node, cin, add_res=False):
+        return TConv(self.store, f"{pre}/{node.name}", node.kind, node.k, node.s, cin, node.cout, node.act, node.bias, add_res)
+
+    def _build(self, node, pre, cin):
+        if isinstance(node, Conv):
+            return self._conv(pre, node, cin), node.cout
+        if isinstance(node, Seq):
+            items = []
+            for l in node.layers:
+                it, cin = self._build(l, pre, cin)
+                items.append(it)
+            return TSeq(items), cin
+        if isinstance(node, ResidualBlock):
+            a, bb, c = node._mk(cin)
+            return TResidualBlock(self._conv(pre, a, cin), self._conv(pre, bb, cin // 2), self._conv(pre, c, cin // 2, add_res=True)), cin
+        if isinstance(node, SimpleAttention):
+            trunk, branch, gate = node._mk(cin)
+            g = Conv(gate.name, "conv", cin, 1, 1, "sigmoid")               # plain epilogue: the gate is applied by gate_forward
+            return TAttention([self._build(r, pre, cin)[0] for r in trunk], [self._build(r, pre, cin)[0] for r in branch],
+                              self._conv(pre, g, cin)), cin
+        if isinstance(node, GDN):
+            raise NotImplementedError("GDN layers inside analysis / synthesis stacks are not trainable here")
+        raise NotImplementedError(type(node).__name__)
+
+    def _all_convs(self):
+        return self.analysis.convs() + self.hyper_analysis.convs() + self.hyper_synthesis.convs() + self.synthesis.convs()
+
+    def _refresh(self):
+        """Parameters changed: re-pack every plan, recompute the effective GDN parameters and the prior record."""
+        for c in self._all_convs():
+            c.refresh()
+        if self._two_layer:
+            self.synthesis.refresh()
+        p = self.store.param
+        o = self._prior_names
+        capi.call("sntc_prior_update", self._prior._h, ops._ptr(p[o["m"]:]), ops._ptr(p[o["b"]:]), ops._ptr(p[o["f"]:]), ops._stream())
+
+    # ---- one step -----------------------------------------------------------------------------------
+    def loss_and_grads(self, x, rd_lambda, noise_z=None, noise_y=None, on_bucket=None):
+        """Forward + backward; leaves d loss / d variable in ``store.grad`` and returns the loss terms.
+        ``on_bucket(name)`` is called as soon as all gradients of a bucket are written (backward order)."""
+        m = self.m
+        n, h, w, c = x.shape
+        f = m.downsample_factor
+        if h % f or w % f:
+            raise ValueError(f"training patches must be multiples of {f} (the reference trains on 256 x 256 crops)")
+        notify = on_bucket or (lambda name: None)
+        w_bpp = 1.0 / (n * h * w)                                      # bpp = mean_B(bits) / (H W)        (:302-307)
+        scale = rd_lambda * 2.0 * 255.0 * 255.0 / (n * h * w * c)     # d(lambda mean (255 d)^2) / d x_hat  (:313-317,343)
+        step = self.step_count
+        y, k_a = self.analysis.fwd(x)                                                              # :218-222
+        z, k_ha = self.hyper_analysis.fwd(y)
+        z_t = ops.noise_add(z, noise_z, self.seed, 2 * step)                                       # :253-256 (training=True)
+        dbz = torch.empty_like(z_t)
+        bits_z = torch.empty((n,), dtype=torch.float64, device=x.device)
+        capi.call("sntc_noisy_factorized", self._prior._h, ops._ptr(z_t), n, z_t.shape[1] * z_t.shape[2], ops._ptr(dbz),
+                  ops._ptr(self._grad_rec), ops._ptr(bits_z), ops._stream())
+        hyper, k_hs = self.hyper_synthesis.fwd(z_t)                                                # :273
+        y_t = ops.noise_add(y, noise_y, self.seed, 2 * step + 1)                                   # :277-280
+        bits_y, dv, dr = ops.noisy_normal(y_t, hyper)
+        recon, k_s = self.synthesis.fwd(y_t)                                                       # :297
+        g_x, sse = ops.distortion_grad(x, recon, scale)
+        # ---- backward ----
+        g_yt = self.synthesis.bwd(k_s, g_x)
+        notify("synthesis")
+        st, o = self.store, self._prior_names
+        capi.call("sntc_prior_param_grad", self._prior._h, ops._ptr(st.param[o["m"]:]), ops._ptr(st.param[o["f"]:]),
+                  ops._ptr(self._grad_rec), w_bpp, ops._ptr(st.grad[o["m"]:]), ops._ptr(st.grad[o["b"]:]), ops._ptr(st.grad[o["f"]:]),
+                  ops._stream())
+        notify("prior")
+        g_y, g_hyper = ops.sga_normal_bwd(g_yt, None, dv, dr, w_bpp)
+        g_z = self.hyper_synthesis.bwd(k_hs, g_hyper)
+        notify("hyper_synthesis")
+        ops.axpy(g_z, dbz, w_bpp)
+        ops.axpy(g_y, self.hyper_analysis.bwd(k_ha, g_z))
+        notify("hyper_analysis")
+        self.analysis.bwd(k_a, g_y, need_dx=False)
+        notify("analysis")
+        return dict(bits_z=bits_z, bits_y=bits_y, sse=sse, recon=recon, y=y, z=z)
+
+    def _bucket_slices(self):
+        out, lo = OrderedDict(), 0
+        for name, hi in self.store.marks.items():
+            out[name] = (lo, hi)
+            lo = hi
+        return out
+
+    def train_step(self, x):
+        """One optimizer step on the batch ``x`` (NHWC float32 in [-0.5, 0.5], device tensor or ndarray)."""
+        m = self.m
+        x = m._as_device_images(x)
+        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        slices = self._bucket_slices()
+        handles = []
+
+        def on_bucket(name):                       # data-parallel: average the bucket across ranks while backward continues
+            if world > 1:
+                lo, hi = slices[name]
+                if hi > lo:
+                    handles.append(torch.distributed.all_reduce(self.store.grad[lo:hi], async_op=True))
+
+        with torch.cuda.device(self.device):
+            rd_lambda = m._scheduled_rd_lambda
+            lr = m._scheduled_lr
+            out = self.loss_and_grads(x, rd_lambda, on_bucket=on_bucket)
+            for hd in handles:
+                hd.wait()
+            inv_world = 1.0 / world
+            clip = m._optimizer_config.get("global_clipnorm")
+            gscale = inv_world
+            norm = None
+            if clip is not None:
+                norm = math.sqrt(float(ops.sumsq(self.store.grad).item())) * inv_world
+                if norm > clip:
+                    gscale *= clip / norm
+            cfg = m._optimizer_config
+            ops.adam_step(self.store.param, self.store.grad, self.store.m, self.store.v, lr, self.step_count + 1,
+                          cfg.get("beta_1", 0.9), cfg.get("beta_2", 0.999), cfg.get("epsilon", 1e-7), grad_scale=gscale)
+            self._refresh()
+            host = torch.stack([out["bits_z"], out["bits_y"], out["sse"]]).cpu().numpy()
+        self.step_count += 1
+        m._step = self.step_count
+        n, h, w, c = x.shape
+        bpp = float(host[0].mean() / (h * w) + host[1].mean() / (h * w))
+        mse_i = host[2] / (h * w * c)
+        mse = float(mse_i.mean())
+        psnr = float(np.mean(-10.0 * (np.log(mse_i) - 2.0 * math.log(255.0)) / math.log(10.0)))
+        loss = bpp + rd_lambda * mse
+        if not math.isfinite(loss):
+            raise capi.NonFiniteError(capi.ERR_NON_FINITE, "rd_loss is not finite")
+        return dict(rd_loss=loss, bpp=bpp, mse=mse, psnr=psnr, scheduled_lr=lr, sched_rd_lambda=rd_lambda, grad_norm=norm)
+
+    # ---- weights out ---------------------------------------------------------------------------------
+    def export_weights(self):
+        """Current variables in ``Model.get_weights()`` naming (effective GDN parameters, separate base / res kernels)."""
+        raw = self.store.export()
+        out = OrderedDict()
+        t = self.m._synthesis
+        for k, v in raw.items():
+            if self._two_layer and k == "synthesis/up/kernel":
+                n1, nr, _ = t._names
+                out[f"synthesis/{n1}/kernel"] = v[:, :, :t._ch].copy()
+                if nr:
+                    out[f"synthesis/{nr}/kernel"] = v[:, :, t._ch:].copy()
+            elif self._two_layer and k == "synthesis/up/bias":
+                n1, nr, _ = t._names
+                out[f"synthesis/{n1}/bias"] = v[:t._ch].copy()
+                if nr:
+                    out[f"synthesis/{nr}/bias"] = v[t._ch:].copy()
+            elif k == "synthesis/act/beta_raw":
+                out["synthesis/act/beta"] = gdn_effective(v, GDN_BETA_MIN)
+            elif k == "synthesis/act/gamma_raw":
+                out["synthesis/act/gamma"] = gdn_effective(v, 0.0)
+            else:
+                out[k] = v
+        return out
+
+    def sync_model(self):
+        """Load the trained variables into the inference ``Model`` (validation / checkpoint)."""
+        self.m.set_weights(self.export_weights())

@@ -1,0 +1,187 @@
+"""Training step on the GPU against float64 PyTorch autograd of the oracle loss (oracle/train_ref.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as graft
+
+graft.load_package()
+pytestmark = pytest.mark.gpu
+
+from oracle import train_ref  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+WGRAD_CASES = [  # kind, k, s, cin, cout, n, h, w
+    ("conv", 5, 2, 3, 64, 2, 32, 48),        # first analysis layer: 3 input channels (scalar gather path)
+    ("conv", 3, 1, 32, 32, 2, 16, 24),
+    ("conv", 1, 1, 96, 48, 1, 20, 12),
+    ("conv", 5, 2, 64, 96, 2, 16, 16),
+    ("conv", 5, 2, 40, 40, 1, 8, 8),
+    ("convT", 5, 2, 32, 48, 2, 6, 10),
+    ("convT", 3, 1, 48, 64, 1, 12, 8),
+    ("convT", 13, 8, 32, 24, 2, 4, 6),       # two-layer synthesis up-conv: 169 taps, 24 channels on the gathered side
+    ("convT", 5, 2, 12, 3, 1, 16, 24),       # output layer: 3 channels on the gathered side
+    ("convT", 18, 16, 32, 3, 1, 3, 4),       # JPEG-like
+]
+
+
+@pytest.mark.parametrize("kind,k,s,cin,cout,n,h,w", WGRAD_CASES)
+def test_conv_wgrad_and_bias_grad(kind, k, s, cin, cout, n, h, w, dev):
+    """dW, db of sum(conv(x) * g) from sntc_conv_wgrad / sntc_bias_grad == autograd of the float64 restatement."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(k * 100 + s * 10 + cin)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wshape = (k, k, cin, cout) if kind == "conv" else (k, k, cout, cin)
+    wt = torch.tensor(rng.standard_normal(wshape) * 0.1, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    xt = train_ref.as_input(x)
+    y = train_ref.conv2d(xt, wt, bt, s) if kind == "conv" else train_ref.conv2d_transpose(xt, wt, bt, s)
+    g = rng.standard_normal((n, y.shape[2], y.shape[3], cout)).astype(np.float32)
+    (y * train_ref.as_input(g)).sum().backward()
+    dw = torch.full(wshape, 7.0, dtype=torch.float32, device=dev)              # must be overwritten
+    db = torch.empty((cout,), dtype=torch.float32, device=dev)
+    xd, gd = torch.from_numpy(x).to(dev), torch.from_numpy(g).to(dev)
+    ops.conv_wgrad(kind, k, s, cin, cout, xd, gd, dw)
+    ops.bias_grad(gd, db)
+    assert _rel(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5
+    assert _rel(db.cpu().numpy(), bt.grad.numpy()) < 2e-5
+    ops.conv_wgrad(kind, k, s, cin, cout, xd, gd, dw, accumulate=True)           # accumulate: exactly twice
+    assert _rel(dw.cpu().numpy(), 2 * wt.grad.numpy()) < 2e-5
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(kind, k, s, cin, cout, xd, gd, dw2)                           # deterministic: bit-identical on a re-run
+    ops.conv_wgrad(kind, k, s, cin, cout, xd, gd, dw)
+    assert torch.equal(dw, dw2)
+
+
+def test_elementwise_training_kernels(dev):
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal((2, 5, 7, 8)).astype(np.float32)
+    y = rng.standard_normal((2, 5, 7, 8)).astype(np.float32)
+    gd, yd = torch.from_numpy(g).to(dev), torch.from_numpy(y).to(dev)
+    np.testing.assert_array_equal(ops.act_backward(gd, yd, "relu").cpu().numpy(), g * (y > 0))
+    np.testing.assert_array_equal(ops.act_backward(gd, yd, "leaky_relu").cpu().numpy(), g * np.where(y > 0, 1.0, 0.2).astype(np.float32))
+    sg = 1.0 / (1.0 + np.exp(-y))
+    np.testing.assert_allclose(ops.act_backward(gd, torch.from_numpy(sg).to(dev), "sigmoid").cpu().numpy(), g * sg * (1 - sg), rtol=1e-6)
+    t = rng.standard_normal(g.shape).astype(np.float32)
+    td, sd = torch.from_numpy(t).to(dev), torch.from_numpy(sg).to(dev)
+    np.testing.assert_allclose(ops.gate_forward(yd, td, sd).cpu().numpy(), y + t * sg, rtol=1e-6, atol=1e-7)
+    g_t, g_s = ops.gate_backward(gd, td, sd)
+    np.testing.assert_allclose(g_t.cpu().numpy(), g * sg, rtol=1e-6)
+    np.testing.assert_allclose(g_s.cpu().numpy(), g * t * sg * (1 - sg), rtol=1e-5, atol=1e-7)
+    a = gd.clone()
+    ops.axpy(a, yd, 0.5)
+    np.testing.assert_allclose(a.cpu().numpy(), g + 0.5 * y, rtol=1e-6)
+    assert abs(float(ops.sumsq(gd).item()) - float((g.astype(np.float64) ** 2).sum())) < 1e-6 * g.size
+    u = ops.noise_add(torch.zeros((4096,), device=dev), None, seed=5, step=9).cpu().numpy()
+    assert -0.5 < u.min() and u.max() < 0.5 and abs(u.mean()) < 0.02 and abs(u.var() - 1 / 12) < 0.005
+    u2 = ops.noise_add(torch.zeros((4096,), device=dev), None, seed=5, step=9).cpu().numpy()
+    u3 = ops.noise_add(torch.zeros((4096,), device=dev), None, seed=5, step=10).cpu().numpy()
+    assert np.array_equal(u, u2) and not np.array_equal(u, u3)
+
+
+def _small_model(dev, synthesis):
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)), synthesis=synthesis)
+    model = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=1000,
+                  optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
+    w = dict(model.get_weights())
+    rng = np.random.default_rng(11)
+    for k, v in w.items():                       # biases / gate inputs away from zero so every path carries gradient
+        if k.endswith("/bias"):
+            w[k] = (0.05 * rng.standard_normal(v.shape)).astype(np.float32)
+    for k in ("prior/factor_0", "prior/factor_1"):
+        if k in w:
+            w[k] = (0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    model.set_weights(w)
+    return model, cfg
+
+
+SYNTHESES = [
+    dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn", res_type="conv"),
+    dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16),
+]
+
+
+@pytest.mark.parametrize("synthesis", SYNTHESES, ids=["two_layer_res", "jpeg_like"])
+def test_loss_and_gradients_match_autograd(synthesis, dev):
+    """Every d loss / d variable of the HIP backward pass against float64 autograd of the oracle training loss under the
+    same uniform noise: ELIC analysis (residual blocks, attention gates), hyper transforms, entropy models incl. the
+    deep-factorized prior variables, two-layer synthesis incl. the reparameterised IGDN variables."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.train import GDN_BETA_MIN, Trainer, gdn_raw
+    model, cfg = _small_model(dev, synthesis)
+    tr = Trainer(model, seed=1)
+    n, h, w = 2, 64, 128
+    x = data_lib.normalize_image(data_lib.synthetic_images(n, h, w, seed=5))
+    rng = np.random.default_rng(7)
+    nz = rng.uniform(-0.5, 0.5, size=(n, h // 64, w // 64, 32)).astype(np.float32)
+    ny = rng.uniform(-0.5, 0.5, size=(n, h // 16, w // 16, 32)).astype(np.float32)
+    lam = 0.02
+    xd = torch.from_numpy(x).to(dev)
+    out = tr.loss_and_grads(xd, lam, torch.from_numpy(nz).to(dev), torch.from_numpy(ny).to(dev))
+    got = tr.store.export(tr.store.grad)
+    params = dict(model.get_weights())
+    raw_names = ()
+    if "synthesis/act/beta" in params:
+        params["synthesis/act/beta"] = (gdn_raw(params["synthesis/act/beta"], GDN_BETA_MIN), GDN_BETA_MIN)
+        params["synthesis/act/gamma"] = (gdn_raw(params["synthesis/act/gamma"], 0.0), 0.0)
+        raw_names = ("synthesis/act/beta", "synthesis/act/gamma")
+    ref = train_ref.loss_and_grads(cfg, params, x, nz, ny, lam, gdn_raw_names=raw_names)
+    bits_z, bits_y = out["bits_z"].cpu().numpy(), out["bits_y"].cpu().numpy()
+    assert _rel(bits_z, ref["bits_z"]) < 2e-5 and _rel(bits_y, ref["bits_y"]) < 2e-5
+    assert _rel(out["recon"].cpu().numpy(), ref["recon"]) < 5e-5
+    mse = float((out["sse"].cpu().numpy() / (h * w * 3)).mean())
+    assert abs(mse - ref["mse"]) < 2e-5 * ref["mse"]
+    rg = dict(ref["grads"])
+    if "synthesis/base_conv/kernel" in rg:                                       # the store keeps [base | res] as one kernel
+        rg["synthesis/up/kernel"] = np.concatenate([rg.pop("synthesis/base_conv/kernel"), rg.pop("synthesis/res/kernel")], axis=2)
+        rg["synthesis/up/bias"] = np.concatenate([rg.pop("synthesis/base_conv/bias"), rg.pop("synthesis/res/bias")])
+        rg["synthesis/act/beta_raw"] = rg.pop("synthesis/act/beta")
+        rg["synthesis/act/gamma_raw"] = rg.pop("synthesis/act/gamma")
+    assert set(rg) == set(got)
+    worst = max(((_rel(got[k], rg[k]), k) for k in rg), key=lambda t: t[0])
+    for k in rg:
+        assert np.abs(rg[k]).max() > 0, f"{k}: reference gradient is identically zero (test would be vacuous)"
+    assert worst[0] < 3e-4, worst
+
+
+def test_train_step_updates_and_export(dev):
+    """One full step = clip by global norm + Keras Adam on every variable (checked against the oracle arithmetic), plans
+    re-packed: the second step's loss equals a fresh model built from the exported weights; the loss goes down."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.train import Trainer
+    model, cfg = _small_model(dev, SYNTHESES[0])
+    tr = Trainer(model, seed=3)
+    x = data_lib.normalize_image(data_lib.synthetic_images(2, 64, 64, seed=9))
+    before = tr.store.export()
+    m0 = tr.train_step(x)
+    g = tr.store.export(tr.store.grad)
+    after = tr.store.export()
+    scale, norm = train_ref.clip_scale(list(g.values()), 1.0)
+    assert abs(norm - m0["grad_norm"]) < 1e-4 * norm
+    for k in before:
+        want, _, _ = train_ref.adam_update(before[k].astype(np.float64), scale * g[k].astype(np.float64), 0.0, 0.0, 1e-3, 1)
+        assert np.abs(after[k] - want).max() < 2e-6, k
+    losses = [m0["rd_loss"]] + [tr.train_step(x)["rd_loss"] for _ in range(12)]
+    assert losses[-1] < losses[0], losses
+    assert model._step == 13 and math.isfinite(losses[-1])
+    # exported weights reproduce the trainer's forward in the inference model
+    tr.sync_model()
+    xd = torch.from_numpy(x).to(dev)
+    lat = model.infer_latent_rvs(xd)
+    y_tr, _ = tr.analysis.fwd(xd)
+    assert _rel(lat.uq[1].loc.cpu().numpy(), y_tr.cpu().numpy()) < 1e-5
