@@ -10,7 +10,7 @@
 // is huge); each block writes its partial tile to a workspace slab and a second kernel sums the slabs in a fixed
 // order (deterministic), optionally accumulating into dW.
 //
-// Block = 4 waves (2 x 2), wave tile 64 x (32 TN), MFMA v_mfma_f32_32x32x2_f32 (exact f32).  The operands arrive
+// Block = 4 waves covering 128 x (32..192) outputs, MFMA v_mfma_f32_32x32x2_f32 (exact f32).  The operands arrive
 // pixel-major ([pixel][channel], NHWC rows), which is exactly [k][m] / [k][n]: the LDS tiles keep that layout and
 // every MFMA operand is one ds_read_b32 per lane (lanes 0-31: 32 consecutive channels of pixel k, lanes 32-63 of
 // pixel k + 1) -- conflict-free without padding.  Global loads are 16 B per lane along channels, zero outside the
@@ -26,7 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct WGArgs {
   const float* S;      // [n, Hs, Ws, Cs]
   const float* D;      // [n, Hd, Wd, Cd]
-  float* slab;         // [ksplit][M][N] partial sums
+  float* slab;         // [ksplit][M][N] partial sums (ksplit > 1) or dW itself (ksplit == 1)
+  int accumulate;      // ksplit == 1 only: add to the existing dW
   int n, Hs, Ws, Cs, Hd, Wd, Cd;
   int kh, kw, stride, pt, pl;
   int M, N;            // taps*Cs, Cd
@@ -38,13 +39,17 @@ struct WGArgs {
 constexpr int kBK = 16;     // pixels per LDS stage
 constexpr int kBM = 128;
 
-template <int TN, bool VECS>
+// WN waves across N (1 or 2), each TN MFMA tiles wide; the other 4 / WN waves stack along M with TM tiles each so
+// that the block always covers 128 rows: BN = 32 WN TN in {32, 64, 96, 128, 160, 192} fits N = 96 / 160 / 192 / 320 /
+// 480 exactly (no MFMA work on padding columns).
+template <int WN, int TN, bool VECS>
 __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
-  constexpr int BN = 64 * TN;
+  constexpr int WM = 4 / WN, TM = kBM / (32 * WM);
+  constexpr int BN = 32 * WN * TN;
   __shared__ float As[2][kBK][kBM];
   __shared__ float Bs[2][kBK][BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int bid = blockIdx.x;
   const int tm = bid % a.ntm;
   bid /= a.ntm;
@@ -53,7 +58,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
   const int m0 = tm * kBM, n0 = tn * BN;
   const long long p0 = (long long)ks * a.pslab, p1 = std::min(a.P, p0 + a.pslab);
 
-  // ---- loader roles: A tile = 16 rows x 32 float4 -> 2 per thread; B tile = 16 rows x (BN/4) float4
+  // ---- loader roles: A tile = 16 rows x 32 float4 -> 2 per thread; B tile = 16 rows x (BN / 4) float4
   const int ac4 = tid & 31, ar0 = tid >> 5;                 // rows ar0, ar0 + 8
   const int am = m0 + 4 * ac4;
   int aky[4], akx[4], acs[4];
@@ -68,11 +73,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
     akx[e] = tap % a.kw - a.pl;
   }
   constexpr int BC4 = BN / 4;                               // float4 columns of the B tile
-  constexpr int BROWS = 256 / BC4;                          // rows covered per pass (16 for TN=1, 8 for TN=2)
-  constexpr int BPASS = kBK / BROWS;
-  const int bc4 = tid % BC4, br0 = tid / BC4;
-  const int bn = n0 + 4 * bc4;
-  const bool bok = bn < a.N;                                // N % 4 == 0 (checked on the host)
+  constexpr int BTOT = kBK * BC4;                           // float4 per stage
+  constexpr int BPASS = (BTOT + 255) / 256;
 
   f32x4 ra[2], rb[BPASS];
   auto gload = [&](long long pb) {
@@ -102,9 +104,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
-      const long long p = pb + br0 + BROWS * q;
+      const int idx = tid + 256 * q;
+      const int row = idx / BC4, c4 = idx - row * BC4;
+      const long long p = pb + row;
+      const int bn = n0 + 4 * c4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p < p1 && bok) v = *reinterpret_cast<const f32x4*>(a.D + (size_t)p * a.Cd + bn);
+      if (idx < BTOT && p < p1 && bn < a.N) v = *reinterpret_cast<const f32x4*>(a.D + (size_t)p * a.Cd + bn);   // N % 4 == 0
       rb[q] = v;
     }
   };
@@ -112,19 +117,23 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(&As[buf][ar0 + 8 * q][4 * ac4]) = ra[q];
 #pragma unroll
-    for (int q = 0; q < BPASS; ++q) *reinterpret_cast<f32x4*>(&Bs[buf][br0 + BROWS * q][4 * bc4]) = rb[q];
+    for (int q = 0; q < BPASS; ++q) {
+      const int idx = tid + 256 * q;
+      const int row = idx / BC4, c4 = idx - row * BC4;
+      if (idx < BTOT) *reinterpret_cast<f32x4*>(&Bs[buf][row][4 * c4]) = rb[q];
+    }
   };
 
-  f32x16 acc[2][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int kl = lane >> 5, cl = lane & 31;
-  const int arow = wm * 64 + cl, bcol = wn * 32 * TN + cl;
+  const int arow = wm * 32 * TM + cl, bcol = wn * 32 * TN + cl;
   int buf = 0;
   if (p0 < p1) {
     gload(p0);
@@ -136,13 +145,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
     if (more) gload(pb + kBK);
 #pragma unroll
     for (int kk = 0; kk < kBK / 2; ++kk) {
-      float fa[2], fb[TN];
+      float fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = As[buf][2 * kk + kl][arow + 32 * i];
+      for (int i = 0; i < TM; ++i) fa[i] = As[buf][2 * kk + kl][arow + 32 * i];
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][2 * kk + kl][bcol + 32 * j];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
@@ -153,40 +162,80 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
 
   float* out = a.slab + (size_t)ks * a.M * a.N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * 32 * TN + 32 * j + cl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + 32 * i + (r >> 2) * 8 + kl * 4 + (r & 3);
-        if (row < a.M && col < a.N) out[(size_t)row * a.N + col] = acc[i][j][r];
+        const int row = m0 + wm * 32 * TM + 32 * i + (r >> 2) * 8 + kl * 4 + (r & 3);
+        if (row < a.M && col < a.N) {
+          float* o = out + (size_t)row * a.N + col;
+          *o = (a.ksplit == 1 && a.accumulate) ? *o + acc[i][j][r] : acc[i][j][r];
+        }
       }
     }
 }
 
-// dW[e] (= or +=) sum over slabs, fixed order
+// dW[e] (= or +=) sum over slabs in a FIXED association order (deterministic): a block owns 64 elements, its four
+// waves take the slabs k = wave, wave + 4, ... (four loads in flight each), combined through LDS
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, long long total, int ksplit,
                                                            float* __restrict__ dw, int accumulate) {
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    float s = accumulate ? dw[e] : 0.f;
-    for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * total + e];
-    dw[e] = s;
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long e = blockIdx.x * 64LL + l;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < total) {
+    int k = grp;
+    for (; k + 12 < ksplit; k += 16) {
+      s0 += slab[(size_t)k * total + e];
+      s1 += slab[(size_t)(k + 4) * total + e];
+      s2 += slab[(size_t)(k + 8) * total + e];
+      s3 += slab[(size_t)(k + 12) * total + e];
+    }
+    for (; k < ksplit; k += 4) s0 += slab[(size_t)k * total + e];
+  }
+  red[grp][l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && e < total) {
+    const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    dw[e] = accumulate ? dw[e] + s : s;
   }
 }
 
-// db[c] (= or +=) sum over pixels of g[p][c]: one block per 64-channel strip x pixel slab, then ordered reduce
+// db[c] (= or +=) sum over pixels of g[p][c].  HBM-bound: a block owns 64 channels x one pixel slab, a thread one
+// float4 of channels and every 16th pixel (4 loads in flight), LDS-reduced to one partial row per slab; the partial rows
+// are summed in a fixed order by wgrad_reduce_kernel.
+template <bool VEC>
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, long long P, int C, long long pslab,
                                                      float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  __shared__ f32x4 red[16][16];
+  const int q = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * q;
   const long long p0 = blockIdx.y * pslab, p1 = std::min(P, p0 + pslab);
-  float s = 0.f;
-  if (c < C)
-    for (long long p = p0 + r; p < p1; p += 4) s += g[(size_t)p * C + c];
-  red[r][threadIdx.x & 63] = s;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  auto ld = [&](long long p) -> f32x4 {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p < p1 && c < C) {
+      if (VEC) v = *reinterpret_cast<const f32x4*>(g + (size_t)p * C + c);
+      else
+        for (int e = 0; e < 4; ++e)
+          if (c + e < C) v[e] = g[(size_t)p * C + c + e];
+    }
+    return v;
+  };
+  for (long long p = p0 + r; p < p1; p += 64) {
+    const f32x4 a0 = ld(p), a1 = ld(p + 16), a2 = ld(p + 32), a3 = ld(p + 48);
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  red[r][q] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (r == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (r == 0) {
+    f32x4 t = red[0][q];
+    for (int i = 1; i < 16; ++i) t += red[i][q];
+    for (int e = 0; e < 4; ++e)
+      if (c + e < C) part[(size_t)blockIdx.y * C + c + e] = t[e];
+  }
 }
 
 }  // namespace sntc
@@ -215,18 +264,31 @@ int wg_geometry(int kind, int kh, int kw, int stride, int cin, int cout, int h, 
   return SNTC_OK;
 }
 
-void wg_split(const WGGeo& g, int kh, int kw, int n, int* tn_out, int* ntm, int* ntn, int* ksplit, long long* pslab) {
+// column-tile width: the candidate with the least padded columns (ties: the wider one, more reuse of the A tile)
+int wg_pick_bn(int N) {
+  static const int cand[6] = {32, 64, 96, 128, 160, 192};
+  int best = 32;
+  long long best_pad = 1LL << 60;
+  for (int c : cand) {
+    const long long padded = (long long)((N + c - 1) / c) * c;
+    if (padded <= best_pad) { best_pad = padded; best = c; }
+  }
+  return best;
+}
+
+void wg_split(const WGGeo& g, int kh, int kw, int n, int* bn_out, int* ntm, int* ntn, int* ksplit, long long* pslab) {
   const int M = kh * kw * g.Cs, N = g.Cd;
-  const int TN = N <= 64 ? 1 : 2;
-  const int bn = 64 * TN;
-  *tn_out = TN;
+  const int bn = wg_pick_bn(N);
+  *bn_out = bn;
   *ntm = (M + kBM - 1) / kBM;
   *ntn = (N + bn - 1) / bn;
   const long long P = (long long)n * g.Hd * g.Wd;
   const long long tiles = (long long)*ntm * *ntn;
   const long long chunks = (P + kBK - 1) / kBK;
   long long ks = std::max<long long>(1, (1536 + tiles - 1) / tiles);       // ~6 blocks per CU in flight
-  ks = std::min(ks, std::max<long long>(1, chunks / 4));                    // at least 4 stages per block
+  // every slab costs a write + a read of the whole [M, N] output: keep >= 24 stages (384 pixels) of MFMA work per
+  // slab so that this traffic stays a fraction of the contraction (pixel-poor, weight-heavy hyper layers: no split)
+  ks = std::min(ks, std::max<long long>(1, chunks / 24));
   ks = std::min<long long>(ks, 256);
   const long long per = ((chunks + ks - 1) / ks) * kBK;
   *pslab = per;
@@ -241,7 +303,7 @@ extern "C" int64_t sntc_conv_wgrad_workspace_bytes(int kind, int kh, int kw, int
   int tn, ntm, ntn, ks;
   long long pslab;
   wg_split(g, kh, kw, n, &tn, &ntm, &ntn, &ks, &pslab);
-  return (int64_t)4 * ks * kh * kw * g.Cs * g.Cd;
+  return ks > 1 ? (int64_t)4 * ks * kh * kw * g.Cs * g.Cd : 0;
 }
 
 extern "C" int sntc_conv_wgrad(int kind, int kh, int kw, int stride, int cin, int cout, const float* x, const float* g_out,
@@ -261,46 +323,62 @@ extern "C" int sntc_conv_wgrad(int kind, int kh, int kw, int stride, int cin, in
   a.P = (long long)n * g.Hd * g.Wd;
   int tn;
   wg_split(g, kh, kw, n, &tn, &a.ntm, &a.ntn, &a.ksplit, &a.pslab);
-  const int64_t need = (int64_t)4 * a.ksplit * a.M * a.N;
-  if (!workspace || workspace_bytes < need) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_wgrad: workspace smaller than sntc_conv_wgrad_workspace_bytes()");
+  const int64_t need = a.ksplit > 1 ? (int64_t)4 * a.ksplit * a.M * a.N : 0;
+  if (need > 0 && (!workspace || workspace_bytes < need))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_wgrad: workspace smaller than sntc_conv_wgrad_workspace_bytes()");
   if ((size_t)n * g.Hs * g.Ws * g.Cs >= (1ull << 31) || (size_t)a.P * g.Cd >= (1ull << 31))
     return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_wgrad: tensors of 2^31 elements or more: split the batch");
-  a.slab = static_cast<float*>(workspace);
+  a.slab = a.ksplit > 1 ? static_cast<float*>(workspace) : dw;      // one slab: the kernel writes dW itself
+  a.accumulate = accumulate;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((long long)a.ntm * a.ntn * a.ksplit));
   const bool vec = g.Cs % 4 == 0;
-  if (tn == 1) {
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<1, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<2, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<2, false>), grid, dim3(256), 0, s, a);
+#define SNTC_WG_LAUNCH(WN, TN)                                                                        \
+  do {                                                                                                \
+    if (vec) hipLaunchKernelGGL((wgrad_kernel<WN, TN, true>), grid, dim3(256), 0, s, a);               \
+    else hipLaunchKernelGGL((wgrad_kernel<WN, TN, false>), grid, dim3(256), 0, s, a);                  \
+  } while (0)
+  switch (tn) {                       // tn holds the column-tile width chosen by wg_split
+    case 32: SNTC_WG_LAUNCH(1, 1); break;
+    case 64: SNTC_WG_LAUNCH(2, 1); break;
+    case 96: SNTC_WG_LAUNCH(1, 3); break;
+    case 128: SNTC_WG_LAUNCH(2, 2); break;
+    case 160: SNTC_WG_LAUNCH(1, 5); break;
+    default: SNTC_WG_LAUNCH(2, 3); break;
   }
+#undef SNTC_WG_LAUNCH
   SNTC_HIP(hipGetLastError());
-  const long long total = (long long)a.M * a.N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, s, a.slab, total,
-                     a.ksplit, dw, accumulate);
-  SNTC_HIP(hipGetLastError());
+  if (a.ksplit > 1) {
+    const long long total = (long long)a.M * a.N;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.slab, total,
+                       a.ksplit, dw, accumulate);
+    SNTC_HIP(hipGetLastError());
+  }
   return SNTC_OK;
+}
+
+static int64_t bias_slabs(int64_t npix, int c) {
+  const int64_t strips = (c + 63) / 64;
+  return std::max<int64_t>(1, std::min<int64_t>((2048 + strips - 1) / strips, (npix + 255) / 256));
 }
 
 extern "C" int64_t sntc_bias_grad_workspace_bytes(int64_t npix, int c) {
   if (npix < 1 || c < 1) return -1;
-  const int64_t slabs = std::min<int64_t>(256, (npix + 1023) / 1024);
-  return 4 * slabs * c;
+  return 4 * bias_slabs(npix, c) * c;
 }
 
 extern "C" int sntc_bias_grad(const float* g, int64_t npix, int c, float* db, int accumulate, void* workspace,
                               int64_t workspace_bytes, void* stream) {
   if (!g || !db || npix < 1 || c < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_bias_grad: bad argument");
-  const int64_t slabs = std::min<int64_t>(256, (npix + 1023) / 1024);
+  const int64_t slabs = bias_slabs(npix, c);
   if (!workspace || workspace_bytes < 4 * slabs * c) return fail(SNTC_ERR_BAD_SHAPE, "sntc_bias_grad: workspace smaller than sntc_bias_grad_workspace_bytes()");
   const long long pslab = (npix + slabs - 1) / slabs;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (unsigned)slabs), dim3(256), 0, s, g, (long long)npix, c, pslab,
-                     static_cast<float*>(workspace));
+  const dim3 grid((c + 63) / 64, (unsigned)slabs);
+  if (c % 4 == 0) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, s, g, (long long)npix, c, pslab, static_cast<float*>(workspace));
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, s, g, (long long)npix, c, pslab, static_cast<float*>(workspace));
   SNTC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((c + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), (long long)c,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((c + 63) / 64), dim3(256), 0, s, static_cast<const float*>(workspace), (long long)c,
                      (int)slabs, db, accumulate);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;

@@ -1,8 +1,12 @@
-"""Multi-GPU driver: independent images shard over ranks; the only exchange is one all-gather of
-per-image (bpp, psnr, mse, bits) rows at the end (RCCL over xGMI when the backend is "nccl").
+"""Multi-GPU driver: independent images shard over ranks; the only exchange of the eval path is one all-gather
+of per-image (bpp, psnr, mse, bits) rows at the end (RCCL over xGMI when the backend is "nccl").
 
 The reference has no distribution at all (one GPU per Slurm array task, slurm_template.py:8-11);
 images are independent (mshyper/models.py:425-433), so there is no data-path collective.
+
+The training step is data-parallel: every rank holds a full replica, takes its own slice of the
+batch, and the gradients are averaged with a handful of large all-reduces (``BucketReducer``) that are launched
+while the backward pass is still producing the earlier layers' gradients.
 """
 from __future__ import annotations
 
@@ -75,3 +79,35 @@ def gather_rows(local_rows, indices, num_items, device="cpu"):
         ok = ~np.isnan(g[:, 0])
         out[g[ok, 0].astype(int)] = g[ok, 1:]
     return out
+
+
+class BucketReducer:
+    """Bucketed, overlapped all-reduce of ONE flat gradient buffer.
+
+    ``slices``: ordered {bucket name: (lo, hi)} over the flat buffer, in the order the backward pass completes them.
+    ``launch(name)`` starts the (asynchronous) sum of that slice across ranks as soon as its last gradient is written
+    -- on RCCL the collective runs on its own stream, so it overlaps the rest of the backward pass; xGMI is point to
+    point, so a few large buckets (tens of MB) keep every ring link busy instead of paying the latency per tensor.
+    ``finish()`` waits for all of them and returns the factor (1 / world) that turns the sums into means -- the caller
+    folds it into its optimizer kernel instead of spending another pass over the buffer."""
+
+    def __init__(self, flat, slices):
+        self.flat, self.slices = flat, dict(slices)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._handles = []
+        self._launched = []
+
+    def launch(self, name):
+        lo, hi = self.slices[name]
+        self._launched.append(name)
+        if self.world > 1 and hi > lo:
+            self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        missing = [n for n in self.slices if n not in self._launched]
+        if missing:
+            raise RuntimeError(f"gradient buckets never launched: {missing}")
+        for h in self._handles:
+            h.wait()
+        self._handles, self._launched = [], []
+        return 1.0 / self.world

@@ -354,6 +354,20 @@ class Model:
         """Bitstream -> uint8 pixels [n, H, W, 3]; bit-identical to ``decode(encode(x))``."""
         return self._get_codec().decompress(blob)
 
+    # -- training (reference :375-383) -----------------------------------------------------------------------
+    def train_step(self, image_batch):
+        """One optimizer step on ``image_batch`` (tape.gradient of end_to_end_frame_loss(training=True) + Adam,
+        reference :375-383); returns Metrics with the reference's scalar keys.  The training state (flat parameter /
+        gradient / moment buffers, adjoint plans) lives in ``shallow_ntc_amd.train.Trainer`` and is created on first
+        use; ``self.trainer.sync_model()`` loads the trained variables back into the inference path."""
+        if getattr(self, "trainer", None) is None:
+            from ..train import Trainer
+            self.trainer = Trainer(self, seed=self._seed)
+        d = self.trainer.train_step(image_batch)
+        metrics = Metrics.make()
+        metrics.record_scalars({k: d[k] for k in ("rd_loss", "bpp", "mse", "psnr", "scheduled_lr", "sched_rd_lambda")})
+        return metrics
+
     # -- iterative inference (reference :389-413, common/itinf_lib.py:26-93) ----------------------------
     def initialize_itinf(self, image_batch):
         """latent_rvs = trainable copy of the encoder's latents; fresh Adam state (:389-395)."""

@@ -412,27 +412,18 @@ class Trainer:
             lo = hi
         return out
 
-    def train_step(self, x):
-        """One optimizer step on the batch ``x`` (NHWC float32 in [-0.5, 0.5], device tensor or ndarray)."""
+    def train_step(self, x, noise_z=None, noise_y=None):
+        """One optimizer step on this rank's batch ``x`` (NHWC float32 in [-0.5, 0.5], device tensor or ndarray).
+        Under torch.distributed every rank passes its own slice of the global batch; gradients are averaged."""
+        from .distributed import BucketReducer
         m = self.m
         x = m._as_device_images(x)
-        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        slices = self._bucket_slices()
-        handles = []
-
-        def on_bucket(name):                       # data-parallel: average the bucket across ranks while backward continues
-            if world > 1:
-                lo, hi = slices[name]
-                if hi > lo:
-                    handles.append(torch.distributed.all_reduce(self.store.grad[lo:hi], async_op=True))
-
         with torch.cuda.device(self.device):
             rd_lambda = m._scheduled_rd_lambda
             lr = m._scheduled_lr
-            out = self.loss_and_grads(x, rd_lambda, on_bucket=on_bucket)
-            for hd in handles:
-                hd.wait()
-            inv_world = 1.0 / world
+            reducer = BucketReducer(self.store.grad, self._bucket_slices())
+            out = self.loss_and_grads(x, rd_lambda, noise_z, noise_y, on_bucket=reducer.launch)
+            inv_world = reducer.finish()
             clip = m._optimizer_config.get("global_clipnorm")
             gscale = inv_world
             norm = None

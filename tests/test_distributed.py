@@ -64,3 +64,53 @@ def test_single_process_paths():
     t = D.gather_rows(np.array([[1.0, 2.0]]), [1], 3)
     assert np.isnan(t[0]).all() and (t[1] == [1.0, 2.0]).all()
     assert D.max_over_ranks(3.5) == 3.5
+
+
+def _reducer_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import __graft_entry__ as graft
+    graft.load_package()
+    from shallow_ntc_amd import distributed as D
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init(backend="gloo")
+    flat = torch.arange(40, dtype=torch.float32) * (rank + 1)          # rank r holds (r + 1) * [0..39]
+    slices = dict(synthesis=(0, 12), prior=(12, 12), hyper=(12, 28), analysis=(28, 40))   # one empty bucket
+    red = D.BucketReducer(flat, slices)
+    for name in slices:                                                   # backward order
+        red.launch(name)
+    scale = red.finish()
+    q.put((rank, (flat * scale).numpy(), scale))
+    red2 = D.BucketReducer(flat, slices)
+    red2.launch("synthesis")
+    try:
+        red2.finish()
+        q.put((rank, "no error", None))
+    except RuntimeError as e:
+        q.put((rank, str(e), None))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_gradient_all_reduce():
+    """The training step's exchange: every bucket of the flat gradient buffer is summed across ranks, the returned
+    factor turns sums into means, and forgetting a bucket is an error rather than a silently stale gradient."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(40, dtype=np.float32) * 1.5                       # mean of 1x and 2x
+    for rank, val, scale in outs:
+        if scale is not None:
+            assert scale == 0.5
+            np.testing.assert_array_equal(val, want)
+        else:
+            assert "never launched" in val

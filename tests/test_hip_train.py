@@ -185,3 +185,59 @@ def test_train_step_updates_and_export(dev):
     lat = model.infer_latent_rvs(xd)
     y_tr, _ = tr.analysis.fwd(xd)
     assert _rel(lat.uq[1].loc.cpu().numpy(), y_tr.cpu().numpy()) < 1e-5
+
+
+def _ddp_worker(rank, world, port, x, nz, ny, q):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SNTC_DIST_BACKEND="gloo")
+    import torch
+    import __graft_entry__ as graft
+    graft.load_package()
+    from shallow_ntc_amd import distributed as D
+    from shallow_ntc_amd.train import Trainer
+    D.init()
+    dev = torch.device("cuda:0")
+    model, _ = _small_model(dev, SYNTHESES[0])
+    tr = Trainer(model, seed=3)
+    sl = slice(rank * (x.shape[0] // world), (rank + 1) * (x.shape[0] // world))
+    t = lambda a: torch.from_numpy(a[sl]).to(dev)
+    m = tr.train_step(t(x), t(nz), t(ny))
+    if rank == 0:
+        q.put((tr.store.export(), m["grad_norm"]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_step_equals_full_batch_step(dev):
+    """Two ranks (sharing this GPU, gloo transport), each with half of the batch and the bucketed gradient all-reduce,
+    end one step with the same variables as one process stepping on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.train import Trainer
+    n, h, w = 4, 64, 64
+    x = data_lib.normalize_image(data_lib.synthetic_images(n, h, w, seed=21))
+    rng = np.random.default_rng(2)
+    nz = rng.uniform(-0.5, 0.5, size=(n, 1, 1, 32)).astype(np.float32)
+    ny = rng.uniform(-0.5, 0.5, size=(n, 4, 4, 32)).astype(np.float32)
+    model, _ = _small_model(dev, SYNTHESES[0])
+    tr = Trainer(model, seed=3)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    m1 = tr.train_step(t(x), t(nz), t(ny))
+    want = tr.store.export()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, x, nz, ny, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, norm = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert abs(norm - m1["grad_norm"]) < 1e-4 * m1["grad_norm"]
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() < 5e-6, k
