@@ -168,12 +168,25 @@ def main():
 
         t_w1 = timed(w1_step, e2e_steps, 1)
         mpx = lambda px, t: round(world * px * e2e_steps / t / 1e6, 2)
+        # training step at the reference's training shape (two_layer_syn.py:13-15: batch 8 x 256 x 256 per
+        # replica); data-parallel: with N > 1 the bucketed gradient all-reduce over RCCL is inside the timed region
+        from shallow_ntc_amd.train import Trainer
+        train_cfg = configs.two_layer_syn(rd_lambda=0.08)
+        train_cfg["optimizer_config"] = dict(learning_rate=1e-4, global_clipnorm=1.0)
+        train_model = Model(device=dev, **train_cfg)
+        trainer = Trainer(train_model, seed=rank)
+        train_x = synthetic_batch(8, 256, 256, 777 + rank, dev)
+        t_train = timed(lambda: trainer.train_step(train_x), e2e_steps, 2)
+        del trainer, train_model
         regions = dict(
             decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2)),
             encode=dict(ms_per_step=round(1e3 * t_enc / e2e_steps, 3), mpixels_per_s=mpx(pixels_per_step, t_enc)),
             encode_decode_score=dict(ms_per_step=round(1e3 * t_e2e / e2e_steps, 3), mpixels_per_s=round(e2e_value, 2)),
             w1_encode_decode_score=dict(workload="64 x 256x256 per GPU", ms_per_step=round(1e3 * t_w1 / e2e_steps, 3),
-                                        mpixels_per_s=mpx(64 * 256 * 256, t_w1)))
+                                        mpixels_per_s=mpx(64 * 256 * 256, t_w1)),
+            train_step=dict(workload="8 x 256x256 per GPU, unoise, Adam + global_clipnorm, gradient all-reduce when N > 1",
+                            ms_per_step=round(1e3 * t_train / e2e_steps, 3),
+                            images_per_s=round(world * 8 * e2e_steps / t_train, 1), mpixels_per_s=mpx(8 * 256 * 256, t_train)))
         rows = []                          # per-image (bpp, psnr, mse) of the rank's set, then ONE all-gather
         for ids, x, hw in batches:
             for d, i in zip(model.evaluate_batched(x), ids):

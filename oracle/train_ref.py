@@ -142,7 +142,7 @@ def gdn_raw(effective, minimum):
 
 
 # ---- the training loss -----------------------------------------------------------------------------
-def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num_filters=(3, 3), gdn_raw_names=()):
+def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num_filters=(3, 3), gdn_raw_names=(), uq="unoise"):
     """params: {name: ndarray} (Model.get_weights() naming; entries listed in ``gdn_raw_names`` hold the RAW
     reparameterised GDN variable as ``(array, minimum)``).  x NHWC in [-0.5, 0.5]; noise_* NHWC in (-.5, .5).
     -> dict(loss, bpp, mse, bits_z[n], bits_y[n], recon NHWC, grads {name: ndarray})."""
@@ -178,11 +178,14 @@ def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num
     factors = [eff[f"prior/factor_{k}"] for k in range(nl - 1)]
     z_t = z + as_input(noise_z)
     bits_z = noisy_deep_factorized_bits(z_t.permute(0, 2, 3, 1), mats, biases, factors).sum(dim=(1, 2, 3))
-    hyper = hyper_synthesis(T.sub_params(eff, "hyper_synthesis/"), z_t, be=_SELF)
+    # 'mixedq' (mshyper/models.py:257-259,281-283): the decoder side sees tfc's straight-through rounding
+    z_dec = z + (torch.round(z) - z).detach() if uq == "mixedq" else z_t
+    hyper = hyper_synthesis(T.sub_params(eff, "hyper_synthesis/"), z_dec, be=_SELF)
     mu, raw = hyper[:, :b], hyper[:, b:]
     y_t = y + as_input(noise_y)
     bits_y = noisy_normal_bits(y_t - mu, raw).sum(dim=(1, 2, 3))
-    recon = synthesis(T.sub_params(eff, "synthesis/"), y_t, be=_SELF)
+    y_dec = (y - mu) + (torch.round(y - mu) - (y - mu)).detach() + mu if uq == "mixedq" else y_t
+    recon = synthesis(T.sub_params(eff, "synthesis/"), y_dec, be=_SELF)
     bpp = bits_z.mean() / (h * w) + bits_y.mean() / (h * w)
     mse = ((255.0 * (xt - recon)) ** 2).mean(dim=(1, 2, 3)).mean()
     loss = bpp + rd_lambda * mse

@@ -266,8 +266,9 @@ class Trainer:
         if model.factorized:
             raise NotImplementedError("the training step is implemented for the mean-scale hyperprior model")
         uq = model._latent_config["uq"].get("method", "unoise")
-        if uq != "unoise":
-            raise NotImplementedError(f"training with uq method {uq!r} (the shipped training configs use 'unoise')")
+        if uq not in ("unoise", "mixedq"):
+            raise NotImplementedError(f"training with uq method {uq!r} (the shipped training configs use 'unoise' and 'mixedq')")
+        self.uq = uq
         self.m = model
         self.device = model.device
         self.seed = seed
@@ -382,10 +383,20 @@ class Trainer:
         bits_z = torch.empty((n,), dtype=torch.float64, device=x.device)
         capi.call("sntc_noisy_factorized", self._prior._h, ops._ptr(z_t), n, z_t.shape[1] * z_t.shape[2], ops._ptr(dbz),
                   ops._ptr(self._grad_rec), ops._ptr(bits_z), ops._stream())
-        hyper, k_hs = self.hyper_synthesis.fwd(z_t)                                                # :273
+        # 'unoise': the noisy sample also feeds the decoder side; 'mixedq' (:257-259,281-283): rates at the noisy values,
+        # decoder side sees the hard-rounded values through a straight-through estimator -- the backward pass is the
+        # same in both cases (d sample / d loc = 1, d sample / d mu = 0)
+        mixed = self.uq == "mixedq"
+        if mixed:
+            from .entropy_coding import int_to_float, round_to_int
+            z_dec = int_to_float(round_to_int(z))
+        else:
+            z_dec = z_t
+        hyper, k_hs = self.hyper_synthesis.fwd(z_dec)                                              # :273
         y_t = ops.noise_add(y, noise_y, self.seed, 2 * step + 1)                                   # :277-280
         bits_y, dv, dr = ops.noisy_normal(y_t, hyper)
-        recon, k_s = self.synthesis.fwd(y_t)                                                       # :297
+        y_dec = ops.entropy_scale_normal(y, hyper, False)[0] if mixed else y_t                     # round(y - mu) + mu
+        recon, k_s = self.synthesis.fwd(y_dec)                                                     # :297
         g_x, sse = ops.distortion_grad(x, recon, scale)
         # ---- backward ----
         g_yt = self.synthesis.bwd(k_s, g_x)

@@ -93,16 +93,17 @@ def test_elementwise_training_kernels(dev):
     assert np.array_equal(u, u2) and not np.array_equal(u, u3)
 
 
-def _small_model(dev, synthesis):
+def _small_model(dev, synthesis, analysis=None, uq="unoise"):
     from shallow_ntc_amd.mshyper.models import Model
-    cfg = dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)), synthesis=synthesis)
-    model = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=1000,
+    cfg = dict(analysis=analysis or dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)), synthesis=synthesis)
+    model = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=1000, latent_config=dict(uq=dict(method=uq)),
                   optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
     w = dict(model.get_weights())
     rng = np.random.default_rng(11)
     for k, v in w.items():                       # biases / gate inputs away from zero so every path carries gradient
         if k.endswith("/bias"):
             w[k] = (0.05 * rng.standard_normal(v.shape)).astype(np.float32)
+    w["hyper_analysis/layer_2/bias"] = (1.5 * rng.standard_normal(w["hyper_analysis/layer_2/bias"].shape)).astype(np.float32)  # z away from 0
     for k in ("prior/factor_0", "prior/factor_1"):
         if k in w:
             w[k] = (0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
@@ -113,17 +114,21 @@ def _small_model(dev, synthesis):
 SYNTHESES = [
     dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn", res_type="conv"),
     dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16),
+    dict(cls="TwoLayerSynthesis", channels=(24, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn"),
 ]
+CNN = dict(cls="CNNAnalysis", channels_base=32, output_channels=32)      # two_layer_syn2.py: CNN analysis, leaky_relu, mixedq
 
 
-@pytest.mark.parametrize("synthesis", SYNTHESES, ids=["two_layer_res", "jpeg_like"])
-def test_loss_and_gradients_match_autograd(synthesis, dev):
+@pytest.mark.parametrize("synthesis,analysis,uq", [(SYNTHESES[0], None, "unoise"), (SYNTHESES[1], None, "unoise"),
+                                                   (SYNTHESES[2], CNN, "mixedq")],
+                         ids=["two_layer_res", "jpeg_like", "cnn_two_layer_mixedq"])
+def test_loss_and_gradients_match_autograd(synthesis, analysis, uq, dev):
     """Every d loss / d variable of the HIP backward pass against float64 autograd of the oracle training loss under the
     same uniform noise: ELIC analysis (residual blocks, attention gates), hyper transforms, entropy models incl. the
     deep-factorized prior variables, two-layer synthesis incl. the reparameterised IGDN variables."""
     from shallow_ntc_amd.common import data_lib
     from shallow_ntc_amd.train import GDN_BETA_MIN, Trainer, gdn_raw
-    model, cfg = _small_model(dev, synthesis)
+    model, cfg = _small_model(dev, synthesis, analysis, uq)
     tr = Trainer(model, seed=1)
     n, h, w = 2, 64, 128
     x = data_lib.normalize_image(data_lib.synthetic_images(n, h, w, seed=5))
@@ -140,7 +145,7 @@ def test_loss_and_gradients_match_autograd(synthesis, dev):
         params["synthesis/act/beta"] = (gdn_raw(params["synthesis/act/beta"], GDN_BETA_MIN), GDN_BETA_MIN)
         params["synthesis/act/gamma"] = (gdn_raw(params["synthesis/act/gamma"], 0.0), 0.0)
         raw_names = ("synthesis/act/beta", "synthesis/act/gamma")
-    ref = train_ref.loss_and_grads(cfg, params, x, nz, ny, lam, gdn_raw_names=raw_names)
+    ref = train_ref.loss_and_grads(cfg, params, x, nz, ny, lam, gdn_raw_names=raw_names, uq=uq)
     bits_z, bits_y = out["bits_z"].cpu().numpy(), out["bits_y"].cpu().numpy()
     assert _rel(bits_z, ref["bits_z"]) < 2e-5 and _rel(bits_y, ref["bits_y"]) < 2e-5
     assert _rel(out["recon"].cpu().numpy(), ref["recon"]) < 5e-5
@@ -150,6 +155,9 @@ def test_loss_and_gradients_match_autograd(synthesis, dev):
     if "synthesis/base_conv/kernel" in rg:                                       # the store keeps [base | res] as one kernel
         rg["synthesis/up/kernel"] = np.concatenate([rg.pop("synthesis/base_conv/kernel"), rg.pop("synthesis/res/kernel")], axis=2)
         rg["synthesis/up/bias"] = np.concatenate([rg.pop("synthesis/base_conv/bias"), rg.pop("synthesis/res/bias")])
+    elif "synthesis/conv1/kernel" in rg:
+        rg["synthesis/up/kernel"], rg["synthesis/up/bias"] = rg.pop("synthesis/conv1/kernel"), rg.pop("synthesis/conv1/bias")
+    if "synthesis/act/beta" in rg:
         rg["synthesis/act/beta_raw"] = rg.pop("synthesis/act/beta")
         rg["synthesis/act/gamma_raw"] = rg.pop("synthesis/act/gamma")
     assert set(rg) == set(got)
