@@ -67,8 +67,20 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
   const int lb0 = blockIdx.x - G.blk0;
   const int split = lb0 % a.ksplit;          // K range of this block (deterministic split-K)
   const int lb = lb0 / a.ksplit;
-  const int mt = lb % a.ntm;
-  const int nt = lb / a.ntm;
+  // XCD-aware tile order: blocks b and b + 8 share an XCD (and its 4 MB L2).  Inside one XCD's sequence the column
+  // tile runs fastest, so the ~64 blocks resident on an XCD cover a few row strips x all column tiles: an
+  // activation strip is fetched into ONE L2 instead of eight, and the weight tiles are shared by the co-resident strips.
+  int mt, nt;
+  const int full = a.ntm & ~7;
+  if (lb < full * G.ntn) {
+    const int l = lb >> 3;
+    mt = (l / G.ntn) * 8 + (lb & 7);
+    nt = l % G.ntn;
+  } else {                                   // ragged tail: fewer than 8 row strips left
+    const int r = lb - full * G.ntn, rem = a.ntm - full;
+    mt = full + r % rem;
+    nt = r / rem;
+  }
   const int m0 = mt * BM;
   const int n0 = nt * BN;
 
