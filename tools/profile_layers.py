@@ -22,7 +22,7 @@ ap.add_argument("--batch", type=int, default=18)
 ap.add_argument("--hw", type=int, nargs=2, default=[512, 768])
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--config", default="two_layer_syn")
-ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--decode-only", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -42,13 +42,14 @@ def run(fn, label):
         t0.record(); fn(); t1.record()
         torch.cuda.synchronize()
         for i, e in enumerate(ops.PROFILE):
-            a = acc.setdefault(i, dict(e, ms=0.0))
-            a["ms"] += e["e0"].elapsed_time(e["e1"]) / args.reps
+            a = acc.setdefault(i, dict(e, samples=[]))
+            a["samples"].append(e["e0"].elapsed_time(e["e1"]))
         total = t0.elapsed_time(t1)
         ops.PROFILE = None
     print(f"== {label}: {total:.3f} ms wall, {n * h * w / total / 1e3:.1f} Mpx/s")
     tot_ms = tot_fl = 0
     for i, a in acc.items():
+        a["ms"] = float(np.median(a["samples"]))          # median: a rep now and then carries a one-off stall
         tf = a["flops"] / a["ms"] / 1e9
         tot_ms += a["ms"]; tot_fl += a["flops"]
         print(f"{i:3d} {a['kind']:7s} k{a['k']} s{a['s']} {a['cin']:4d}->{a['cout']:4d} in {a['n']}x{a['h']}x{a['w']:<4d} v{a['variant']} "
