@@ -94,6 +94,7 @@ class Model:
         self._quality_metrics = quality_metrics     # MS-SSIM at eval (reference :321-331); LPIPS is not vendored
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self._step = 0
+        self._timing = {}
         self._prior = None
         self._init_transforms(transform_config)
 
@@ -216,26 +217,41 @@ class Model:
             x = x.unsqueeze(0)
         return x.contiguous()
 
+    def _timed(self, name, fn, *args):
+        """``profile=True`` (reference :142-149, common/profile_utils.py:62-77): per-transform wall time as Metrics scalars
+        ``<name>_time`` in seconds -- here GPU time between two HIP events on the launch stream (the reference's
+        perf_counter around a tf.function is documented as inaccurate, README.md:44-45)."""
+        if not self._profile:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args)
+        e1.record()
+        e1.synchronize()
+        self._timing[f"{name}_time"] = e0.elapsed_time(e1) * 1e-3
+        return out
+
     def infer_latent_rvs(self, x):
         x = self._as_device_images(x)
+        self._timing = {}
         with torch.cuda.device(self.device):
             xp = image_utils.pad_images(x, self.downsample_factor)
-            y = self._analysis(xp)
-            z = self._hyper_analysis(y)
+            y = self._timed("analysis", self._analysis, xp)
+            z = self._timed("hyper_analysis", self._hyper_analysis, y)
         return LatentRVCollection(uq=(UQLatentRV(z), UQLatentRV(y)))
 
     # -- generative path + losses (reference :234-359, training=False branch) ------------------------
     def _rate_and_reconstruction(self, latent_rvs, want_symbols=False):
         z, y = latent_rvs.uq[0].loc, latent_rvs.uq[1].loc
         z_hat, bits_z = self._get_prior()(z)                          # :254-259 (offset 0)
-        hyper = self._hyper_synthesis(z_hat)                          # :273; split + exp fused below
+        hyper = self._timed("hyper_synthesis", self._hyper_synthesis, z_hat)    # :273; split + exp fused below
         y_hat, bits_y, sym = ops.entropy_scale_normal(y, hyper, want_symbols)   # :274-279
-        recon = self._synthesis(y_hat)                                # :297
+        recon = self._timed("synthesis", self._synthesis, y_hat)                # :297
         return dict(z_hat=z_hat, y_hat=y_hat, symbols=sym, hyper=hyper, bits_z=bits_z, bits_y=bits_y, recon=recon)
 
     def frame_loss_given_latent_rvs(self, image_batch, latent_rvs, training):
         if training:
-            raise NotImplementedError("training=True (noise / SGA sampling) runs through itinf_train_step")
+            raise NotImplementedError("training=True runs through train_step (noise proxies) / itinf_train_step (SGA)")
         x = self._as_device_images(image_batch)
         with torch.cuda.device(self.device):
             r = self._rate_and_reconstruction(latent_rvs)
@@ -281,6 +297,8 @@ class Model:
             metrics.record_scalars(dict(msssim=float(ms), msssim_db=float(db)))
         metrics.record_scalars(dict(rd_loss=float(rd_loss), bpp=float(bpp), mse=float(mse), psnr=float(psnr),
                                     scheduled_lr=self._scheduled_lr))
+        if self._profile:                                                               # :350-351
+            metrics.record_scalars(dict(getattr(self, "_timing", {})))
         return float(rd_loss), metrics
 
     def end_to_end_frame_loss(self, image_batch, training):

@@ -199,3 +199,19 @@ def test_eval_workdir_from_checkpoint(tmp_path, dev):
     for r, wnt in zip(rows, want):
         for k in ("bpp", "psnr", "mse", "msssim"):
             assert abs(r[k] - wnt[k]) <= 1e-6 * max(1.0, abs(wnt[k])), k
+
+
+def test_profile_mode_reports_transform_times(dev):
+    """Model(profile=True) adds the reference's *_time scalars (mshyper/models.py:219-224,269-271,293-295,350-351)."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)),
+               synthesis=dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16))
+    model = Model(device=dev, transform_config=cfg, profile=True, quality_metrics=False)
+    x = data_lib.normalize_image(data_lib.synthetic_images(1, 64, 64, seed=2))
+    s = model.validation_step(x).scalars_float
+    for k in ("analysis_time", "hyper_analysis_time", "hyper_synthesis_time", "synthesis_time"):
+        assert 0.0 < s[k] < 1.0, (k, s[k])
+    plain = Model(device=dev, transform_config=cfg, quality_metrics=False).validation_step(x).scalars_float
+    assert not any(k.endswith("_time") for k in plain)
+    assert plain["bpp"] == s["bpp"] and plain["psnr"] == s["psnr"]

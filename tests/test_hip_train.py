@@ -249,3 +249,31 @@ def test_data_parallel_step_equals_full_batch_step(dev):
     assert abs(norm - m1["grad_norm"]) < 1e-4 * m1["grad_norm"]
     for k in want:
         assert np.abs(got[k] - want[k]).max() < 5e-6, k
+
+
+def test_train_eval_compress_round_trip(dev):
+    """The rows of SURVEY.md 8 working together: a small model is trained for some steps (f4), its variables go back
+    into the inference model, which evaluates (a17/a18), and compresses / decompresses a real bitstream (f2) whose
+    size tracks the estimated rate; training lowers the rate-distortion loss the evaluation reports."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)),
+               synthesis=dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn"))
+    model = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=400,
+                  optimizer_config=dict(learning_rate=2e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
+    x = data_lib.normalize_image(data_lib.synthetic_images(4, 128, 128, seed=31))
+    before = np.mean([m.scalars_float["rd_loss"] for m in model.evaluate(x)])
+    for _ in range(60):
+        m = model.train_step(x)
+    assert set(("rd_loss", "bpp", "mse", "psnr", "scheduled_lr", "sched_rd_lambda")) <= set(m.scalars_float)
+    model.trainer.sync_model()
+    rows = model.evaluate_batched(x)
+    after = np.mean([r["rd_loss"] for r in rows])
+    assert after < 0.7 * before, (before, after)
+    blob = model.compress(x)
+    px = model.decompress(blob)
+    z_hat, sym, bits_z, bits_y = model.encode(x)
+    assert torch.equal(px, model.decode(z_hat, sym, (128, 128)))
+    est = float(bits_z.sum() + bits_y.sum())
+    overhead = 8 * (4 * 2 * 256 + 64)                        # 2 streams x 256 B per image + header / length fields
+    assert 0.97 * est < 8 * len(blob) < 1.06 * est + overhead, (8 * len(blob), est)
