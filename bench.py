@@ -63,6 +63,10 @@ def main():
                     help="only launch decode kernels (the command profiles/ is recorded with): skips the "
                          "encode+decode loop, the (bpp, PSNR) evaluation and the CPU baseline")
     ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=0,
+                    help="decode the batches of the set on this many HIP streams at once (0 = one per batch shape): the tail of "
+                         "one batch's kernels is filled by the other's blocks; 1 = serial on the current stream")
+    ap.add_argument("--chunk", type=int, default=0, help="split every batch shape into sub-batches of at most this many images (0 = no split)")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
                          "the host already runs ahead of the GPU)")
@@ -98,10 +102,12 @@ def main():
         shapes = KODAK_SHAPES[:args.images] if args.images <= 24 else [KODAK_SHAPES[i % 24] for i in range(args.images)]
     groups = {}
     for i, s in enumerate(shapes):
-        groups.setdefault(s, []).append(i)
+        key = s if args.chunk <= 0 else (s, sum(1 for j in range(i) if shapes[j] == s) // args.chunk)
+        groups.setdefault(key, []).append(i)
     batches = []   # (image ids, x)
-    for (h, wd), ids in groups.items():
-        batches.append((ids, synthetic_batch(len(ids), h, wd, 1234 + 97 * rank + h, dev), (h, wd)))
+    for key, ids in groups.items():
+        h, wd = key if args.chunk <= 0 else key[0]
+        batches.append((ids, synthetic_batch(len(ids), h, wd, 1234 + 97 * rank + h + 7 * ids[0], dev), (h, wd)))
     pixels_per_step = sum(h * wd for h, wd in shapes)
 
     # ---- codes resident in HBM: synthetic latents of the encoder's output shapes (SURVEY.md 8d:
@@ -120,8 +126,24 @@ def main():
     def decode_eager():
         return [model.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
 
+    nstreams = len(codes) if args.streams == 0 else args.streams
+    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
+
+    def decode_streams():
+        """Independent batches on independent streams (joined back into the current stream before returning)."""
+        cur = torch.cuda.current_stream()
+        outs = []
+        for i, (z_hat, sym, hw, _x) in enumerate(codes):
+            st = side[i % nstreams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(model.decode(z_hat, sym, hw))
+        for st in side:
+            cur.wait_stream(st)
+        return outs
+
     if not args.graph:
-        decode_step = decode_eager
+        decode_step = decode_streams if nstreams > 1 and len(codes) > 1 else decode_eager
     else:                                  # one captured HIP graph per batch shape, replayed every step
         from shallow_ntc_amd.graphs import DecodeGraph
         graphs = [DecodeGraph(model, z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
@@ -280,7 +302,8 @@ def main():
                                     f"Kodak-24-shaped synthetic set per GPU ({len(shapes)} images: 512x768 / 768x512), ") +
                                  "random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
                         timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels",
-                        launch="hipGraph replay (one graph per batch shape)" if args.graph else "eager",
+                        launch="hipGraph replay (one graph per batch shape)" if args.graph else
+                        (f"eager, {min(nstreams, len(codes))} concurrent streams (one per batch)" if nstreams > 1 and len(codes) > 1 else "eager"),
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))"),
             encode_decode_mpixels_per_s=None if e2e_value is None else round(e2e_value, 2),
             regions=regions, rd=rd, roofline=roofline, cpu_baseline=cpu_baseline,
