@@ -272,6 +272,7 @@ class Trainer:
         self.m = model
         self.device = model.device
         self.seed = seed
+        self.use_graph = True
         self.store = FlatStore(self.device)
         w = model.get_weights()
         tr = model._transforms()
@@ -354,7 +355,23 @@ class Trainer:
         return self.analysis.convs() + self.hyper_analysis.convs() + self.hyper_synthesis.convs() + self.synthesis.convs()
 
     def _refresh(self):
-        """Parameters changed: re-pack every plan, recompute the effective GDN parameters and the prior record."""
+        """Parameters changed: re-pack every plan, recompute the effective GDN parameters and the prior record.
+        ~170 plans x (pack kernels + bias copy) is ~400 tiny launches: after the first (eager) pass the sequence is
+        replayed as one captured HIP graph -- all pointers are views of the flat store, nothing allocates."""
+        graph = getattr(self, "_refresh_graph", None)
+        if graph is not None:
+            graph.replay()
+            return
+        self._refresh_eager()
+        if getattr(self, "_refresh_warm", 0) >= 1 and self.use_graph:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._refresh_eager()
+            self._refresh_graph = g
+        self._refresh_warm = getattr(self, "_refresh_warm", 0) + 1
+
+    def _refresh_eager(self):
         for c in self._all_convs():
             c.refresh()
         if self._two_layer:
