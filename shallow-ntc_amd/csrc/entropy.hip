@@ -11,27 +11,11 @@
 //   logistic-sigmoid cumulative "right of the median" is simply upper > 0, and sf(x) = cdf(-x).
 #include <cmath>
 #include <vector>
-#include "sntc_internal.h"
+#include "device_math.h"
 
 namespace sntc {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-constexpr float kLogScaleMin = -2.2072749131897207f;    // ln 0.11        (mshyper/models.py:29)
-constexpr float kScaleFactor = 0.12305479932808384f;    // (ln 256 - ln 0.11)/63   (:31)
-constexpr float kInvLn2 = 1.4426950408889634f;
-
-// log Phi(x), float32: direct for x > -10, asymptotic series below (as TFP's float32 log_ndtr).
-__device__ __forceinline__ float log_ndtr_f(float x) {
-  const float t = x * 0.70710678118654752f;
-  if (x > 0.0f) return log1pf(-0.5f * erfcf(t));
-  if (x > -10.0f) return logf(0.5f * erfcf(-t));
-  const float x2 = x * x;
-  const float ix2 = 1.0f / x2;
-  const float series = 1.0f - ix2 * (1.0f - 3.0f * ix2 * (1.0f - 5.0f * ix2));
-  return -0.5f * x2 - logf(-x) - 0.91893853320467274f + logf(series);
-}
 
 __device__ __forceinline__ float log_diff_exp(float big, float small) {
   return big + log1pf(-expf(small - big));
@@ -45,22 +29,6 @@ __device__ __forceinline__ float normal_bits(float v, float sigma) {
   const float a = right ? -lo : hi;
   const float b = right ? -hi : lo;
   return -log_diff_exp(log_ndtr_f(a), log_ndtr_f(b)) * kInvLn2;
-}
-
-__device__ __forceinline__ double block_sum_to(double v, double* dst) {
-  __shared__ double part[8];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) part[wave] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0;
-    for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
-    atomicAdd(dst, s);
-  }
-  __syncthreads();
-  return v;
 }
 
 // grid (blocks_per_image, n).  4 channels per thread; c % 4 == 0.
@@ -146,8 +114,6 @@ __device__ __forceinline__ float df_logits(const float* __restrict__ rec, const 
   }
   return hcur[0];
 }
-
-__device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 
 __global__ void __launch_bounds__(256) factorized_kernel(const float* __restrict__ rec_all, DFDesc d, const float* __restrict__ z,
                                                          int64_t hw, int c, float* __restrict__ z_hat,

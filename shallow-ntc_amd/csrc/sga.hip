@@ -9,28 +9,16 @@
 // 397-408 (loss terms and the variables that receive gradients), common/data_lib.py:48-52.
 #include <cmath>
 #include <algorithm>
-#include "sntc_internal.h"
+#include "device_math.h"
 
 namespace sntc {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kLogScaleMin = -2.2072749131897207f;
-constexpr float kScaleFactor = 0.12305479932808384f;
-constexpr float kInvLn2 = 1.4426950408889634f;
 constexpr float kSgaEps = 1e-5f;           // latent_rvs_utils.py:9 epsilon
 
 // ---- counter-based uniform -> Gumbel (statistical parity with tfp's RelaxedOneHotCategorical) ----
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __device__ __forceinline__ float gumbel_from(unsigned long long seed, unsigned long long step, unsigned long long idx, int k) {
-  const unsigned long long r = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + 2 * idx + k);
-  const float u = ((float)(r >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
-  return -logf(-logf(u));
+  return -logf(-logf(uniform01(splitmix64(stream_key(seed, step) + 2 * idx + k))));
 }
 
 // out = w0 floor(mu) + w1 ceil(mu), w = softmax((logits + g) / tau); also d out / d mu.
@@ -47,27 +35,6 @@ __device__ __forceinline__ void sga_sample(float mu, float tau, float g0, float 
   const float dl0 = a_free ? -1.0f / (tau * (1.0f - a * a)) : 0.0f;
   const float dl1 = b_free ? 1.0f / (tau * (1.0f - b * b)) : 0.0f;
   *dout = (ce - fl) * w1 * (1.0f - w1) * (dl1 - dl0) / tau;
-}
-
-__device__ __forceinline__ float log_ndtr_f(float x) {
-  const float t = x * 0.70710678118654752f;
-  if (x > 0.0f) return log1pf(-0.5f * erfcf(t));
-  if (x > -10.0f) return logf(0.5f * erfcf(-t));
-  const float x2 = x * x, ix2 = 1.0f / x2;
-  return -0.5f * x2 - logf(-x) - 0.91893853320467274f + logf(1.0f - ix2 * (1.0f - 3.0f * ix2 * (1.0f - 5.0f * ix2)));
-}
-
-__device__ __forceinline__ void block_sum_to(double v, double* dst) {
-  __shared__ double part[8];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0;
-    for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += part[i];
-    atomicAdd(dst, s);
-  }
 }
 
 // ---- normal (y) : forward sample + rate + partial derivatives ----
@@ -168,8 +135,6 @@ __device__ __forceinline__ void df_logits_grad(const float* __restrict__ rec, co
   *dL = hd[0];
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 
 __global__ void __launch_bounds__(256) sga_factorized_fwd_kernel(const float* __restrict__ rec_all, DFDesc d,
                                                                  const float* __restrict__ z_loc, int64_t hw, int c, float tau,

@@ -3,18 +3,9 @@
 // contractions of the backward pass are sntc_conv_forward (input gradients, adjoint plans) and sntc_conv_wgrad.
 #include <algorithm>
 #include <cmath>
-#include "sntc_internal.h"
+#include "device_math.h"
 
 namespace sntc {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned long long tr_splitmix64(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 
 #define SNTC_GRID_STRIDE(i, total) \
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
@@ -59,8 +50,7 @@ __global__ void __launch_bounds__(256) noise_add_kernel(const float* __restrict_
     float u;
     if (noise) u = noise[i];
     else {
-      const unsigned long long r = tr_splitmix64(tr_splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (unsigned long long)i);
-      u = ((float)(r >> 40) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;
+      u = uniform01(splitmix64(stream_key(seed, step) + (unsigned long long)i)) - 0.5f;
     }
     out[i] = x[i] + u;
   }

@@ -17,9 +17,11 @@ def pytest_configure(config):
 
 
 def _have_gpu():
+    """device_count() does not initialise the GPU: tests/test_distributed.py spawns worker processes, which must never
+    happen from a process that has touched the GPU (the pool refuses such an exec)."""
     try:
         import torch
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 
