@@ -264,9 +264,13 @@ class Model:
 
     def _msssim(self, x, recon):
         """Per-image (MS-)SSIM of the uint8-quantised images (reference :321-331), or None."""
-        if not self._quality_metrics or min(x.shape[1], x.shape[2]) < 11:
-            return None
         h, w = x.shape[1], x.shape[2]
+        if not self._quality_metrics or min(h, w) < 11:
+            return None
+        if (h >= 160 or w >= 160) and min(h, w) < 11 * 16:
+            # the reference switches to ssim_multiscale once either side reaches 160 (:325-329), which TensorFlow itself
+            # rejects when the fifth scale is smaller than the 11 x 11 window; report no MS-SSIM instead of failing the step
+            return None
         return ops.image_quality(ops.pixels_float(x, h, w), ops.pixels_float(recon, h, w), 255.0)
 
     def _finish_metrics(self, x_shape, bits_z, bits_y, sse, msssim=None):

@@ -215,3 +215,10 @@ def test_profile_mode_reports_transform_times(dev):
     plain = Model(device=dev, transform_config=cfg, quality_metrics=False).validation_step(x).scalars_float
     assert not any(k.endswith("_time") for k in plain)
     assert plain["bpp"] == s["bpp"] and plain["psnr"] == s["psnr"]
+
+
+def test_smoke_entry_point_runs(dev):
+    """__graft_entry__.smoke() is what the driver runs first on the GPU box: keep it under test (128 x 192 image: the
+    MS-SSIM pyramid does not fit, the metric is skipped rather than raised)."""
+    import __graft_entry__ as graft
+    graft.smoke()
