@@ -55,6 +55,7 @@ struct GGArgs {
   int ntm;
   int ksplit;          // >= 1: number of K ranges (blocks per tile)
   float* slab;         // split-K partial sums (workspace) or nullptr
+  int dbg;             // diagnostic switches (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers
   int ngroups;
   GGGroup g[kMaxGroups];
 };
