@@ -116,6 +116,36 @@ def small_model_fixture():
     np.savez_compressed(OUT / "model_two_layer_small.npz", **d)
 
 
+def bitstream_fixture():
+    """A frozen rANS stream of this build's wire format (oracle/rans_np.py): 505 values over all 64 scale tables incl.
+    escapes -> the exact uint16 words, for 1 and 3 segments."""
+    from . import rans_np
+    rng = np.random.default_rng(0)
+    tabs = rans_np.normal_tables()
+    n, E = 2, 505
+    tids = rng.integers(0, 64, size=(n, E)).astype(np.int16)
+    sig = np.array([0.11 * np.exp((np.log(256.0) - np.log(0.11)) / 63.0 * k) for k in range(64)])
+    vals = np.rint(rng.laplace(0, 1, size=(n, E)) * sig[tids] * 1.5).astype(np.int32)
+    vals[0, 16] = 20000
+    vals[1, 0] = -31000
+    vals[1, 504] = 32767
+    d = dict(values=vals, table_ids=tids, table_sizes=np.array([len(f) for _, f in tabs], np.int32),
+             table_min=np.array([lo for lo, _ in tabs], np.int32), table_freqs=np.concatenate([np.asarray(f, np.int32) for _, f in tabs]))
+    for segs in (1, 3):
+        eseg = -(-(-(-E // segs)) // 64) * 64
+        words, lens = [], []
+        for b in range(n):
+            for g in range(segs):
+                sl = slice(g * eseg, min(E, (g + 1) * eseg))
+                w = rans_np.encode_stream(vals[b, sl], tids[b, sl], tabs)
+                assert rans_np.decode_stream(w, tids[b, sl], tabs) == vals[b, sl].tolist()
+                words += w
+                lens.append(len(w))
+        d[f"words_s{segs}"] = np.asarray(words, np.uint16)
+        d[f"lens_s{segs}"] = np.asarray(lens, np.int64)
+    np.savez_compressed(OUT / "bitstream.npz", **d)
+
+
 def published_rows():
     """DATA copied from the reference's published results (not source): a few per-image rows and the
     parameter / FLOP tables, used as known-answer tests of the metric definitions and the layer inventory."""
@@ -134,6 +164,7 @@ if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     ops_fixture()
     small_model_fixture()
+    bitstream_fixture()
     if REF.exists():
         published_rows()
     for f in sorted(OUT.iterdir()):

@@ -7,8 +7,47 @@ ESCAPE = last symbol of a table, followed by (value + 32768) as a raw 16-bit wor
 stream = [lane 0 state hi, lo, lane 1 state hi, lo, ...] [words in decode order]."""
 from __future__ import annotations
 
+import math
+
 M = 1 << 16
 LANES = 64
+NUM_SCALES, SCALE_MIN, SCALE_MAX = 64, 0.11, 256.0       # mshyper/models.py:28-32
+
+
+def _ndtr(x):
+    return 0.5 * math.erfc(-x / math.sqrt(2.0))
+
+
+def quantize_pmf(pmf, escape_mass):
+    """Frequencies at 16-bit precision: 1 + floor(p (65536 - n)) each, the remainder to the most probable symbol;
+    the last entry is ESCAPE."""
+    p = [max(float(v), 0.0) for v in pmf] + [max(float(escape_mass), 0.0)]
+    tot = sum(p)
+    p = [v / tot for v in p]
+    n = len(p)
+    f = [1 + int(math.floor(v * (M - n))) for v in p]
+    f[max(range(n), key=lambda i: p[i])] += M - sum(f)
+    assert min(f) >= 1 and sum(f) == M
+    return f
+
+
+def normal_tables(min_pmf=2.0 ** -17, max_half_width=4095):
+    """One table per integer scale index k: sigma_k = SCALE_FN(k), symbols |v| <= L_k with pmf >= 2^-17, then ESCAPE."""
+    factor = (math.log(SCALE_MAX) - math.log(SCALE_MIN)) / (NUM_SCALES - 1.0)
+    tabs = []
+    for k in range(NUM_SCALES):
+        sigma = math.exp(math.log(SCALE_MIN) + factor * k)
+
+        def pmf_at(t):
+            if t <= 0:
+                return _ndtr((t + 0.5) / sigma) - _ndtr((t - 0.5) / sigma)
+            return _ndtr(-(t - 0.5) / sigma) - _ndtr(-(t + 0.5) / sigma)
+
+        L = 0
+        while L < max_half_width and pmf_at(L + 1) >= min_pmf:
+            L += 1
+        tabs.append((-L, quantize_pmf([pmf_at(t) for t in range(-L, L + 1)], 2.0 * _ndtr(-(L + 0.5) / sigma))))
+    return tabs
 
 
 def _cdf(f):

@@ -177,3 +177,30 @@ def test_sga_schedule_and_rounding_limits():
     np.testing.assert_allclose(out, [0.0, 2.0, -0.0, 3.0], atol=1e-6)
     out = O.sga_round(mu, 0.5, g, offset=np.full(mu.shape, 0.25))
     assert np.all(out >= np.floor(mu - 0.25) + 0.25 - 1e-12) and np.all(out <= np.ceil(mu - 0.25) + 0.25 + 1e-12)
+
+
+def test_bitstream_golden_and_tables():
+    """tests/golden/bitstream.npz freezes the wire format: the pure-Python coder reproduces its words and decodes them,
+    and the product's host-side table construction (numpy, no GPU needed) is the same table set as the oracle's."""
+    from pathlib import Path
+    from oracle import rans_np
+    g = np.load(Path(__file__).parent / "golden" / "bitstream.npz")
+    tabs = rans_np.normal_tables()
+    assert [len(f) for _, f in tabs] == g["table_sizes"].tolist() and [lo for lo, _ in tabs] == g["table_min"].tolist()
+    assert np.concatenate([np.asarray(f) for _, f in tabs]).tolist() == g["table_freqs"].tolist()
+    vals, tids = g["values"], g["table_ids"]
+    E = vals.shape[1]
+    for segs in (1, 3):
+        eseg = -(-(-(-E // segs)) // 64) * 64
+        words, off = g[f"words_s{segs}"].tolist(), 0
+        for i, ln in enumerate(g[f"lens_s{segs}"].tolist()):
+            b, s = divmod(i, segs)
+            sl = slice(s * eseg, min(E, (s + 1) * eseg))
+            assert rans_np.encode_stream(vals[b, sl], tids[b, sl], tabs) == words[off:off + ln]
+            assert rans_np.decode_stream(words[off:off + ln], tids[b, sl], tabs) == vals[b, sl].tolist()
+            off += ln
+    import __graft_entry__ as graft
+    graft.load_package()
+    from shallow_ntc_amd import entropy_coding as ec
+    prod = ec.normal_tables()
+    assert [(lo, list(map(int, f))) for lo, f in prod] == [(lo, list(f)) for lo, f in tabs]
