@@ -154,10 +154,28 @@ def main():
         def decode_step():
             return [g() for g in graphs]
 
+    def on_streams(fn_per_batch):
+        """Run fn(batch) for every batch of the set, independent batches on independent streams."""
+        if not side or len(batches) < 2:
+            return [fn_per_batch(b) for b in batches]
+        cur = torch.cuda.current_stream()
+        outs = []
+        for i, b in enumerate(batches):
+            st = side[i % nstreams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(fn_per_batch(b))
+        for st in side:
+            cur.wait_stream(st)
+        return outs
+
+    def e2e_one(batch):
+        ids, x, hw = batch
+        z_hat, sym, _, _ = model.encode(x)
+        return model.decode(z_hat, sym, hw, reference=x)
+
     def e2e_step():
-        for ids, x, hw in batches:
-            z_hat, sym, _, _ = model.encode(x)
-            model.decode(z_hat, sym, hw, reference=x)
+        return on_streams(e2e_one)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -181,7 +199,7 @@ def main():
         e2e_value = world * pixels_per_step * e2e_steps / t_e2e / 1e6
         # the other regions of SURVEY.md 8d, whole job like `value`: encode alone on the metric's set, and
         # encode+decode on the synthetic 256x256 batches the north star asks for at every GPU count
-        t_enc = timed(lambda: [model.encode(x) for _ids, x, _hw in batches], e2e_steps, 1)
+        t_enc = timed(lambda: on_streams(lambda b: model.encode(b[1])), e2e_steps, 1)
         w1_x = synthetic_batch(64, 256, 256, 4321 + rank, dev)
 
         def w1_step():
