@@ -294,7 +294,12 @@ static int pick_variant(const sntc_conv_plan* p, int64_t M) {
     // fewer than ~3 workgroups per CU leaves nothing to overlap a block's barriers / epilogue with
     // (measured: 240 blocks 68 TFLOP/s vs 640 blocks 87 TFLOP/s on the same layer)
     if (nb < 768) cost *= 1.0 + 0.5 * (double)(768 - nb) / 768.0;
-    if (v == 8) cost *= 1.15;   // 64x64: half the MFMAs per staged byte
+    int kmax = 0;
+    for (int gi = 0; gi < p->ngroups; ++gi) kmax = std::max(kmax, p->g[gi].K);
+    // 64x64: half the MFMAs per staged byte -- except on short contractions (1x1 convolutions, K <= 192), where the
+    // tile's prologue / epilogue dominates and four small blocks per CU overlap them best (measured on 96->192 and
+    // 192->192: 65 / 78 TFLOP/s against 61 / 62 with the 128-row tiles)
+    if (v == 8) cost *= kmax <= 192 ? 0.90 : 1.15;
     if (v == 1) cost *= 1.10;
     if (v == 7) cost *= 1.08;   // 92 KB of LDS: one block per CU
     if (cost < best) { best = cost; bestv = v; }
