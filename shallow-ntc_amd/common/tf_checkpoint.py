@@ -532,3 +532,123 @@ def load_reference_checkpoint(prefix, transform_config):
     m.sequential_convs(g.child(model, "_hyper_synthesis"), "hyper_synthesis/", ["layer_0", "layer_1", "layer_2"])
     m.deep_factorized(g.child(model, "_prior"))
     return m.out
+
+
+# ------------------------------------------------------------------------------------------ writing
+class _GraphWriter:
+    """Builds the TrackableObjectGraph + tensor dict of ``tf.train.Checkpoint(model=model)`` for the reference's
+    classes -- the inverse of ``CheckpointMapper`` (same attribute names, same checkpoint keys)."""
+
+    def __init__(self, weights):
+        self.w = weights
+        self.nodes = [({}, {})]
+        self.tensors = OrderedDict()
+
+    def add(self, parent, name):
+        self.nodes.append(({}, {}))
+        self.nodes[parent][0][name] = len(self.nodes) - 1
+        return len(self.nodes) - 1
+
+    def var(self, parent, name, path, value):
+        n = self.add(parent, name)
+        key = f"{path}/{name}{VAR_SUFFIX}"
+        self.nodes[n][1]["VARIABLE_VALUE"] = key
+        self.tensors[key] = np.asarray(value)
+        return n
+
+    def conv(self, parent, name, path, ours):
+        n = self.add(parent, name)
+        self.var(n, "kernel", f"{path}/{name}", self.w[ours + "/kernel"])
+        if ours + "/bias" in self.w:
+            self.var(n, "bias", f"{path}/{name}", self.w[ours + "/bias"])
+        return n
+
+    def residual_block(self, parent, name, path, ours):
+        blk = self.add(self.add(parent, name), "_block")
+        for i in range(3):
+            self.conv(blk, f"layer_with_weights-{i}", f"{path}/{name}/_block", f"{ours}/conv{i}")
+
+    def elic_analysis(self, parent):
+        seq = self.add(parent, "_transform")
+        path = "model/_analysis/_transform"
+        items = {k.split("/")[1] for k in self.w if k.startswith("analysis/")}
+        nconv = sum(1 for i in items if i.startswith("conv"))
+        nrb = sum(1 for i in items if i.startswith("rb"))
+        per = nrb // (nconv - 1)                               # residual blocks after every conv but the last (elic.py:147-163)
+        rbs = iter([f"rb{i}" for i in range(nrb)])
+        take = lambda: [next(rbs) for _ in range(per)]
+        names = (["conv0", *take()] if nconv == 4 else [])
+        c = nconv - 3
+        names += [f"conv{c}", *take(), "attn0", f"conv{c + 1}", *take(), f"conv{c + 2}", "attn1"]
+        if set(names) != items:
+            raise KeyError(f"analysis variables do not form an ElicAnalysis: {sorted(items)}")
+        for i, item in enumerate(names):
+            lw, ours = f"layer_with_weights-{i}", f"analysis/{item}"
+            if item.startswith("conv"):
+                self.conv(seq, lw, path, ours)
+            elif item.startswith("rb"):
+                self.residual_block(seq, lw, path, ours)
+            else:
+                att = self.add(seq, lw)
+                trunk, branch = self.add(att, "_trunk"), self.add(att, "_attention_branch")
+                for j in range(3):
+                    self.residual_block(trunk, f"layer_with_weights-{j}", f"{path}/{lw}/_trunk", f"{ours}/trunk/rb{j}")
+                    self.residual_block(branch, f"layer_with_weights-{j}", f"{path}/{lw}/_attention_branch", f"{ours}/branch/rb{j}")
+                self.conv(branch, "layer_with_weights-3", f"{path}/{lw}/_attention_branch", f"{ours}/branch/conv")
+
+    def sequential(self, parent, path, ours_prefix, count):
+        for i in range(count):
+            self.conv(parent, f"layer_with_weights-{i}", path, f"{ours_prefix}layer_{i}")
+
+    def gdn1(self, parent, path, ours):
+        act = self.add(parent, "activation")
+        for pname, leaf in (("beta_parameter", "beta"), ("gamma_parameter", "gamma")):
+            p = self.add(act, pname)
+            self.var(p, "variable", f"{path}/activation/{pname}", gdn_parameter_variable(self.w[f"{ours}/{leaf}"]))
+
+
+def save_reference_checkpoint(prefix, weights, transform_config, step=0):
+    """Write ``weights`` (``Model.get_weights()`` naming) as the TensorBundle + object graph the reference's training
+    loop produces (common/train_lib.py:123-126), so that the reference's ``eval.py`` (or ``load_reference_checkpoint``
+    here) restores it.  Variables only: the Keras optimizer slots of the reference checkpoint are not written."""
+    b = _GraphWriter(weights)
+    model = b.add(0, "model")
+    ana = b.add(model, "_analysis")
+    a_cls = transform_config["analysis"]["cls"]
+    if a_cls == "ElicAnalysis":
+        b.elic_analysis(ana)
+    elif a_cls == "CNNAnalysis":
+        b.sequential(ana, "model/_analysis", "analysis/", 4)
+    else:
+        raise NotImplementedError(f"checkpoint export for analysis {a_cls}")
+    syn = b.add(model, "_synthesis")
+    s_cls = transform_config["synthesis"]["cls"]
+    if s_cls == "TwoLayerResSynthesis":
+        for n in ("base_conv", "res", "out_conv"):
+            b.conv(syn, n, "model/_synthesis", f"synthesis/{n}")
+        if "synthesis/act/beta" in weights:
+            b.gdn1(syn, "model/_synthesis", "synthesis/act")
+    elif s_cls == "TwoLayerSynthesis":
+        c1 = b.conv(syn, "conv1", "model/_synthesis", "synthesis/conv1")
+        b.conv(syn, "conv2", "model/_synthesis", "synthesis/conv2")
+        if "synthesis/act/beta" in weights:
+            b.gdn1(c1, "model/_synthesis/conv1", "synthesis/act")
+    elif s_cls == "JPEGLikeSynthesis":
+        b.conv(syn, "conv", "model/_synthesis", "synthesis/conv")
+    else:
+        raise NotImplementedError(f"checkpoint export for synthesis {s_cls}")
+    for tname in ("_hyper_analysis", "_hyper_synthesis"):
+        b.sequential(b.add(model, tname), f"model/{tname}", f"{tname[1:]}/", 3)
+    base = b.add(b.add(model, "_prior"), "_base")
+    for kind, ours in (("_matrices", "matrix"), ("_biases", "bias"), ("_factors", "factor")):
+        lst = b.add(base, kind)
+        i = 0
+        while f"prior/{ours}_{i}" in weights:
+            v = np.asarray(weights[f"prior/{ours}_{i}"])
+            b.var(lst, str(i), f"model/_prior/_base/{kind}", v if ours == "matrix" else v[..., None])
+            i += 1
+    tensors = OrderedDict(b.tensors)
+    tensors[OBJECT_GRAPH_KEY] = ObjectGraph.serialize(b.nodes)
+    tensors["save_counter" + VAR_SUFFIX] = np.array(int(step), np.int64)
+    write_bundle(prefix, tensors)
+    return prefix

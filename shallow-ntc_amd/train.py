@@ -499,8 +499,25 @@ class Trainer:
                 out["synthesis/act/gamma"] = gdn_effective(v, 0.0)
             else:
                 out[k] = v
-        return out
+        order = list(self.m.get_weights())                     # Model.get_weights() order (the store is in backward order)
+        return OrderedDict((k, out[k]) for k in order)
 
     def sync_model(self):
         """Load the trained variables into the inference ``Model`` (validation / checkpoint)."""
         self.m.set_weights(self.export_weights())
+
+    def save_checkpoint(self, workdir, model_config=None):
+        """``workdir/train/checkpoints/ckpt-<step>`` in the reference's TensorBundle layout (+ ``config.json``), i.e. what
+        ``common/eval_lib.py:load_latest_ckpt`` -- here and in the reference -- restores (train_lib.py:123-126,248-250,326-336).
+        Variables only; the Adam moments stay in this process."""
+        import json
+        from pathlib import Path
+        from .common import eval_lib, tf_checkpoint
+        ckdir = Path(workdir) / eval_lib.TRAIN_COLLECTION / eval_lib.CHECKPOINTS_DIR_NAME
+        ckdir.mkdir(parents=True, exist_ok=True)
+        cfg = dict(model_config) if model_config is not None else dict(
+            scheduled_num_steps=self.m._scheduled_num_steps, rd_lambda=self.m._rd_lambda, transform_config=self.m._transform_config,
+            optimizer_config=self.m._optimizer_config, latent_config=self.m._latent_config)
+        (Path(workdir) / "config.json").write_text(json.dumps(dict(model_config=cfg), indent=1, default=lambda o: list(o)))
+        return tf_checkpoint.save_reference_checkpoint(ckdir / f"ckpt-{self.step_count}", self.export_weights(),
+                                                       self.m._transform_config, self.step_count)

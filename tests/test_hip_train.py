@@ -230,7 +230,7 @@ def test_data_parallel_gradient_is_the_mean_of_shard_gradients(dev):
         lo = b
 
 
-def test_train_eval_compress_round_trip(dev):
+def test_train_eval_compress_round_trip(dev, tmp_path):
     """The rows of SURVEY.md 8 working together: a small model is trained for some steps (f4), its variables go back
     into the inference model, which evaluates (a17/a18), and compresses / decompresses a real bitstream (f2) whose
     size tracks the estimated rate; training lowers the rate-distortion loss the evaluation reports."""
@@ -249,6 +249,13 @@ def test_train_eval_compress_round_trip(dev):
     rows = model.evaluate_batched(x)
     after = np.mean([r["rd_loss"] for r in rows])
     assert after < 0.7 * before, (before, after)
+    # checkpoint in the reference's TensorBundle layout -> eval_lib.load_latest_ckpt -> identical evaluation
+    from shallow_ntc_amd.common import eval_lib
+    model.trainer.save_checkpoint(tmp_path)
+    restored = eval_lib.load_latest_ckpt(tmp_path, device=dev)
+    assert restored._step == 60
+    rows2 = restored.evaluate_batched(x)
+    assert [r["bpp"] for r in rows2] == [r["bpp"] for r in rows] and [r["psnr"] for r in rows2] == [r["psnr"] for r in rows]
     blob = model.compress(x)
     px = model.decompress(blob)
     z_hat, sym, bits_z, bits_y = model.encode(x)

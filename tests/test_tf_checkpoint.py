@@ -182,3 +182,28 @@ def test_reference_model_mapping(tmp_path):
         ck.load_reference_checkpoint(prefix, dict(tc, synthesis=dict(cls="JPEGLikeSynthesis")))
     with pytest.raises(NotImplementedError):
         ck.load_reference_checkpoint(prefix, dict(tc, analysis=dict(cls="MBT2018Analysis")))
+
+
+@pytest.mark.parametrize("analysis,synthesis", [
+    (dict(cls="ElicAnalysis", channels=(8, 8, 8, 16)), dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn")),
+    (dict(cls="CNNAnalysis", channels_base=8, output_channels=16), dict(cls="TwoLayerSynthesis", channels=(24, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn")),
+    (dict(cls="ElicAnalysis", channels=(8, 8, 8, 16)), dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16)),
+])
+def test_writer_is_the_inverse_of_the_reader(tmp_path, analysis, synthesis):
+    """save_reference_checkpoint -> load_reference_checkpoint returns every variable (the GDN parameters through tfc's
+    reparameterisation and back); the writer produces the same keys as the hand-built reference-shaped bundle above."""
+    from oracle import model_np
+    cfg = dict(analysis=analysis, synthesis=synthesis)
+    m = model_np.Model(cfg)
+    w = m.init_params(5)
+    prefix = ck.save_reference_checkpoint(tmp_path / "ckpt-7", w, cfg, step=7)
+    back = ck.load_reference_checkpoint(prefix, cfg)
+    assert set(back) == set(w)
+    for k in w:
+        np.testing.assert_allclose(back[k], w[k], rtol=0, atol=2e-7 if "/act/" in k else 0, err_msg=k)
+    assert int(ck.read_bundle(prefix)["save_counter" + ck.VAR_SUFFIX]) == 7
+    if synthesis["cls"] == "TwoLayerResSynthesis":
+        (tmp_path / "hand").mkdir()
+        hand = ck.read_bundle(_reference_like_checkpoint(tmp_path / "hand", w))
+        ours = ck.read_bundle(prefix)
+        assert {k for k in hand if k.endswith(ck.VAR_SUFFIX)} == {k for k in ours if k.endswith(ck.VAR_SUFFIX)}
