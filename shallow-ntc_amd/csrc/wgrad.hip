@@ -76,6 +76,18 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
   constexpr int BTOT = kBK * BC4;                           // float4 per stage
   constexpr int BPASS = (BTOT + 255) / 256;
 
+  // the two pixel rows this thread gathers per stage, as (image, i, j): decoded once, then advanced by kBK pixels
+  // per stage (no per-stage division)
+  int pi[2], pj[2], pimg[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const long long p = p0 + ar0 + 8 * q;
+    const long long hw = (long long)a.Hd * a.Wd;
+    pimg[q] = (int)(p / hw);
+    const int rem = (int)(p - (long long)pimg[q] * hw);
+    pi[q] = rem / a.Wd;
+    pj[q] = rem - pi[q] * a.Wd;
+  }
   f32x4 ra[2], rb[BPASS];
   auto gload = [&](long long pb) {
 #pragma unroll
@@ -83,10 +95,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
       const long long p = pb + ar0 + 8 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (p < p1) {
-        const long long hw = (long long)a.Hd * a.Wd;
-        const int img = (int)(p / hw);
-        const int rem = (int)(p - img * hw);
-        const int i = rem / a.Wd, j = rem - i * a.Wd;
+        const int img = pimg[q], i = pi[q], j = pj[q];
         if (VECS) {
           const int sy = i * a.stride + aky[0], sx = j * a.stride + akx[0];
           if (aok[0] && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
@@ -101,6 +110,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
         }
       }
       ra[q] = v;
+      pj[q] += kBK;                                         // next stage: kBK pixels further
+      while (pj[q] >= a.Wd) {
+        pj[q] -= a.Wd;
+        if (++pi[q] == a.Hd) { pi[q] = 0; ++pimg[q]; }
+      }
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
