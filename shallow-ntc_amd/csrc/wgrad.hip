@@ -36,7 +36,8 @@ struct WGArgs {
   int ntm, ntn, ksplit;
 };
 
-constexpr int kBK = 16;     // pixels per LDS stage
+constexpr int kBK = 16;     // pixels per LDS stage (32 measured slower: fewer, fatter K slabs and half the blocks per CU)
+constexpr int kAPass = kBK / 8;   // A-tile rows per thread per stage (256 threads = 8 rows x 32 float4)
 constexpr int kBM = 128;
 
 // WN waves across N (1 or 2), each TN MFMA tiles wide; the other 4 / WN waves stack along M with TM tiles each so
@@ -78,9 +79,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
 
   // the two pixel rows this thread gathers per stage, as (image, i, j): decoded once, then advanced by kBK pixels
   // per stage (no per-stage division)
-  int pi[2], pj[2], pimg[2];
+  int pi[kAPass], pj[kAPass], pimg[kAPass];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < kAPass; ++q) {
     const long long p = p0 + ar0 + 8 * q;
     const long long hw = (long long)a.Hd * a.Wd;
     pimg[q] = (int)(p / hw);
@@ -88,10 +89,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
     pi[q] = rem / a.Wd;
     pj[q] = rem - pi[q] * a.Wd;
   }
-  f32x4 ra[2], rb[BPASS];
+  f32x4 ra[kAPass], rb[BPASS];
   auto gload = [&](long long pb) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kAPass; ++q) {
       const long long p = pb + ar0 + 8 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (p < p1) {
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(&As[buf][ar0 + 8 * q][4 * ac4]) = ra[q];
+    for (int q = 0; q < kAPass; ++q) *reinterpret_cast<f32x4*>(&As[buf][ar0 + 8 * q][4 * ac4]) = ra[q];
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       const int idx = tid + 256 * q;
