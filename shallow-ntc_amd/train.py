@@ -90,7 +90,7 @@ class FlatStore:
 class TConv:
     """One trainable convolution: forward plan, adjoint plan, weight / bias gradients."""
 
-    def __init__(self, store, name, kind, k, s, cin, cout, act, bias, add_res=False):
+    def __init__(self, store, name, kind, k, s, cin, cout, act, bias, add_res=False, adj_epilogue=capi.EPI_STORE):
         if kind not in ("conv", "convT"):
             raise NotImplementedError(f"{name}: {kind} layers (tfc.SignalConv2D, RDFT-reparameterised) are not trainable here")
         self.name, self.kind, self.k, self.s, self.cin, self.cout, self.act = name, kind, k, s, cin, cout, act
@@ -99,7 +99,11 @@ class TConv:
         self.gb = store.g(f"{name}/bias") if bias else None
         self.fwd_plan = ops.ConvPlan(kind, self.W, self.b, s, act, capi.PRO_NONE, capi.EPI_ADD if add_res else capi.EPI_STORE)
         # kernel [kh,kw,Cin,Cout] of a Conv2D == kernel [kh,kw,Cout',Cin'] of its adjoint Conv2DTranspose (and vice versa)
-        self.adj_plan = ops.ConvPlan("convT" if kind == "conv" else "conv", self.W, None, s, None)
+        # adj_epilogue: what the input-gradient launch does on the way out --
+        #   EPI_MASK_RELU  multiply by 1[x > 0], x = this layer's input: the producer's relu backward rides along
+        #   EPI_ADD        add a second gradient (the skip path of a ResidualBlock)
+        self.adj_epilogue = adj_epilogue
+        self.adj_plan = ops.ConvPlan("convT" if kind == "conv" else "conv", self.W, None, s, None, capi.PRO_NONE, adj_epilogue)
 
     def refresh(self):
         self.fwd_plan.update(self.W, self.b)
@@ -109,14 +113,20 @@ class TConv:
         y = self.fwd_plan(x, res)
         return y, (x, y)
 
-    def bwd(self, ctx, g, need_dx=True, act_folded=False):
+    def bwd(self, ctx, g, need_dx=True, act_folded=False, adj_res=None):
         x, y = ctx
         if self.act is not None and not act_folded:
             g = ops.act_backward(g, y, self.act)
         ops.conv_wgrad(self.kind, self.k, self.s, self.cin, self.cout, x, g, self.gW)
         if self.gb is not None:
             ops.bias_grad(g, self.gb)
-        return self.adj_plan(g) if need_dx else None
+        if not need_dx:
+            return None
+        if self.adj_epilogue == capi.EPI_MASK_RELU:
+            return self.adj_plan(g, res=x)
+        if self.adj_epilogue == capi.EPI_ADD:
+            return self.adj_plan(g, res=adj_res)
+        return self.adj_plan(g)
 
     def convs(self):
         return [self]
@@ -125,6 +135,14 @@ class TConv:
 class TSeq:
     def __init__(self, items):
         self.items = items
+        # conv (relu) -> conv: the consumer's input-gradient launch applies the producer's relu mask
+        self.folded = [False] * len(items)
+        for i in range(len(items) - 1):
+            a, b = items[i], items[i + 1]
+            if isinstance(a, TConv) and isinstance(b, TConv) and a.act == "relu" and b.adj_epilogue == capi.EPI_STORE:
+                b.adj_epilogue = capi.EPI_MASK_RELU
+                b.adj_plan = ops.ConvPlan("convT" if b.kind == "conv" else "conv", b.W, None, b.s, None, capi.PRO_NONE, capi.EPI_MASK_RELU)
+                self.folded[i] = True
 
     def fwd(self, x):
         ctxs = []
@@ -135,7 +153,10 @@ class TSeq:
 
     def bwd(self, ctxs, g, need_dx=True):
         for i in range(len(self.items) - 1, -1, -1):
-            g = self.items[i].bwd(ctxs[i], g, need_dx or i > 0)
+            if self.folded[i]:
+                g = self.items[i].bwd(ctxs[i], g, need_dx or i > 0, act_folded=True)
+            else:
+                g = self.items[i].bwd(ctxs[i], g, need_dx or i > 0)
         return g
 
     def convs(self):
@@ -155,10 +176,11 @@ class TResidualBlock:
         return y, (k0, k1, k2)
 
     def bwd(self, ctx, g, need_dx=True):
-        d = self.c[2].bwd(ctx[2], g)
-        d = self.c[1].bwd(ctx[1], d)
-        d = self.c[0].bwd(ctx[0], d)
-        return ops.axpy(d, g)                      # + the skip path
+        # the relu backward of conv0 / conv1 rides on the input-gradient launch of the layer above (mask epilogue),
+        # the skip gradient on conv0's (add epilogue): 3 weight gradients + 3 input gradients + 3 bias sums, nothing else
+        d = self.c[2].bwd(ctx[2], g)                               # -> already masked by conv1's relu
+        d = self.c[1].bwd(ctx[1], d, act_folded=True)              # -> already masked by conv0's relu
+        return self.c[0].bwd(ctx[0], d, act_folded=True, adj_res=g)
 
     def convs(self):
         return list(self.c)
@@ -327,8 +349,8 @@ class Trainer:
         self.store.add("synthesis/up/kernel", k1)
         self.store.add("synthesis/up/bias", b1)
 
-    def _conv(self, pre, node, cin, add_res=False):
-        return TConv(self.store, f"{pre}/{node.name}", node.kind, node.k, node.s, cin, node.cout, node.act, node.bias, add_res)
+    def _conv(self, pre, node, cin, add_res=False, adj=capi.EPI_STORE):
+        return TConv(self.store, f"{pre}/{node.name}", node.kind, node.k, node.s, cin, node.cout, node.act, node.bias, add_res, adj)
 
     def _build(self, node, pre, cin):
         if isinstance(node, Conv):
@@ -341,7 +363,8 @@ class Trainer:
             return TSeq(items), cin
         if isinstance(node, ResidualBlock):
             a, bb, c = node._mk(cin)
-            return TResidualBlock(self._conv(pre, a, cin), self._conv(pre, bb, cin // 2), self._conv(pre, c, cin // 2, add_res=True)), cin
+            return TResidualBlock(self._conv(pre, a, cin, adj=capi.EPI_ADD), self._conv(pre, bb, cin // 2, adj=capi.EPI_MASK_RELU),
+                                  self._conv(pre, c, cin // 2, add_res=True, adj=capi.EPI_MASK_RELU)), cin
         if isinstance(node, SimpleAttention):
             trunk, branch, gate = node._mk(cin)
             g = Conv(gate.name, "conv", cin, 1, 1, "sigmoid")               # plain epilogue: the gate is applied by gate_forward
