@@ -661,7 +661,7 @@ extern "C" int sntc_noisy_factorized(const sntc_prior* prior, const float* z_til
   if (grad_record) {                         // sum over ALL elements of d bits / d record (caller applies the loss weight)
     SNTC_HIP(hipMemsetAsync(grad_record, 0, sizeof(float) * (size_t)c * prior->d.stride, s));
     const int64_t npix = (int64_t)n * hw;
-    const int64_t slabs = std::min<int64_t>(64, (npix + 63) / 64);
+    const int64_t slabs = std::min<int64_t>(256, (npix + 3) / 4);       // few elements, heavy threads: spread them wide
     const int64_t pslab = (npix + slabs - 1) / slabs;
     hipLaunchKernelGGL(factorized_param_grad_kernel, dim3((c + 63) / 64, (unsigned)slabs), dim3(256), 0, s, prior->rec, prior->d,
                        z_tilde, npix, c, pslab, grad_record);
