@@ -263,3 +263,40 @@ def test_train_eval_compress_round_trip(dev, tmp_path):
     est = float(bits_z.sum() + bits_y.sum())
     overhead = 8 * (4 * 2 * 256 + 64)                        # 2 streams x 256 B per image + header / length fields
     assert 0.97 * est < 8 * len(blob) < 1.06 * est + overhead, (8 * len(blob), est)
+
+
+def test_train_eval_loop_and_itinf_loop_drivers(dev, tmp_path):
+    """common/train_lib.simple_train_eval_loop (reference :87-258) and common/itinf_lib.itinf_on_data_batch (:26-93):
+    logging / evaluation / checkpoint cadence, JSON-lines records, a restorable checkpoint, SGA variables returned."""
+    import json
+    from shallow_ntc_amd.common import data_lib, eval_lib, itinf_lib, train_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)), synthesis=dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16))
+    model = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=12,
+                  optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
+    batches = [data_lib.normalize_image(data_lib.synthetic_images(2, 64, 64, seed=s)) for s in range(3)]
+
+    def forever():
+        while True:
+            yield from batches
+
+    rows = train_lib.simple_train_eval_loop(dict(num_steps=12, log_metrics_every_steps=4, checkpoint_every_steps=6, eval_every_steps=6),
+                                            tmp_path, model, forever(), batches[:2])
+    assert [r["step"] for r in rows] == [0, 4, 8] and rows[-1]["rd_loss"] < rows[0]["rd_loss"]
+    train_rec = [json.loads(l) for l in (tmp_path / "train" / "record.jsonl").read_text().splitlines()]
+    val_rec = [json.loads(l) for l in (tmp_path / "val" / "record.jsonl").read_text().splitlines()]
+    assert [r["step"] for r in train_rec] == [0, 4, 8] and [r["step"] for r in val_rec] == [6, 12]
+    assert sorted(p.name for p in (tmp_path / "train" / "checkpoints").glob("*.index")) == ["ckpt-12.index", "ckpt-6.index"]
+    restored = eval_lib.load_latest_ckpt(tmp_path, device=dev)
+    assert restored._step == 12
+    a = restored.validation_step(batches[0]).scalars_float
+    b = model.validation_step(batches[0]).scalars_float
+    assert a["bpp"] == b["bpp"] and a["psnr"] == b["psnr"]
+    # SGA loop on one batch with the itinf latent config (mshyper/configs/itinf.py)
+    sga = Model(device=dev, rd_lambda=0.02, transform_config=cfg, quality_metrics=False, scheduled_num_steps=20,
+                optimizer_config=dict(learning_rate=5e-3, warmup_steps=0), latent_config=configs.itinf()["latent_config"])
+    sga.set_weights(restored.get_weights())
+    tm, vm, variables = itinf_lib.itinf_on_data_batch(dict(num_steps=20, log_metrics_every_steps=5, eval_every_steps=10), None, None, sga, batches[0])
+    assert [r["step"] for r in tm] == [0, 5, 10, 15] and [r["step"] for r in vm] == [10, 20]
+    assert set(variables) == {"z_loc", "y_loc"} and variables["y_loc"].shape == (2, 4, 4, 32)
