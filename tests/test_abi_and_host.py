@@ -156,3 +156,25 @@ def test_latest_checkpoint_resolution(tmp_path):
     assert eval_lib.latest_checkpoint(d).name == "ckpt-10"
     (d / "checkpoint").write_text('model_checkpoint_path: "ckpt-9"\nall_model_checkpoint_paths: "ckpt-9"\n')
     assert eval_lib.latest_checkpoint(d).name == "ckpt-9"
+
+
+def test_png_dataset_pipeline(tmp_path):
+    """data_lib.get_dataset over PNG files (reference common/data_lib.py:86-143): ordered full-size evaluation batches,
+    shuffled / repeated / randomly cropped training batches, normalisation to [-0.5, 0.5]."""
+    from PIL import Image
+    from shallow_ntc_amd.common import data_lib
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, size=(40 + 8 * i, 56, 3)).astype(np.uint8) for i in range(3)]
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(tmp_path / f"img{i:02d}.png")
+    val = list(data_lib.get_dataset(str(tmp_path / "*.png"), "val", 1, None))
+    assert [b.shape for b in val] == [(1, 40, 56, 3), (1, 48, 56, 3), (1, 56, 56, 3)]
+    np.testing.assert_array_equal(val[1][0], data_lib.normalize_image(imgs[1]))
+    center = list(data_lib.get_dataset(str(tmp_path / "*.png"), "val", 2, 32))
+    assert [b.shape for b in center] == [(2, 32, 32, 3), (1, 32, 32, 3)]
+    np.testing.assert_array_equal(center[0][0], data_lib.normalize_image(imgs[0][4:36, 12:44]))
+    train = data_lib.get_dataset(str(tmp_path / "*.png"), "train", 2, 16, seed=3)
+    batches = [next(train) for _ in range(5)]                       # repeats past the 3 files, always full batches
+    assert all(b.shape == (2, 16, 16, 3) and b.dtype == np.float32 and -0.5 <= b.min() and b.max() <= 0.5 for b in batches)
+    with pytest.raises(RuntimeError):
+        data_lib.get_dataset_from_glob(str(tmp_path / "*.jpg"), False, False, False, 1)
