@@ -193,27 +193,30 @@ def test_sga_step_at_tecnick_shape(dev):
     assert np.isfinite(val["psnr"])
 
 
-def test_kodak_size_image_against_the_independent_cpu_restatement(dev):
-    """Full-width two_layer_syn model on one 512 x 768 image: the HIP analysis output and the decoded pixels against
-    oracle/torch_ref.py (float32 PyTorch-CPU, library convolutions -- an implementation that shares nothing with the
-    gather-GEMM).  Tolerances: latents 1e-4 of their range (different fp32 summation orders over K up to 4800), decoded
-    u8 pixels equal except for values on a rounding boundary (<= 1 code value on < 1e-3 of the pixels)."""
+@pytest.mark.parametrize("name,shape", [("two_layer_syn", (1, 512, 768)), ("mbt2018", (2, 256, 256)), ("jpegl", (1, 768, 512)),
+                                        ("two_layer_syn2", (1, 256, 320))])
+def test_full_width_models_against_the_independent_cpu_restatement(name, shape, dev):
+    """Full-width reference configs (BASELINE.json configs 2-5) at full-size inputs: the HIP analysis output and the decoded
+    pixels against oracle/torch_ref.py (float32 PyTorch-CPU, library convolutions -- an implementation that shares nothing
+    with the gather-GEMM).  Tolerances: latents 1e-4 of their range (different fp32 summation orders over K up to 4800),
+    decoded u8 pixels equal except for values on a rounding boundary (<= 1 code value on < 1e-3 of the pixels)."""
     from oracle import model_np, torch_ref
     from shallow_ntc_amd.common import data_lib
     from shallow_ntc_amd.mshyper import configs
     from shallow_ntc_amd.mshyper.models import Model
-    cfg = configs.two_layer_syn(rd_lambda=0.02)
+    cfg = configs.CONFIGS[name]()
     model = Model(device=dev, quality_metrics=False, **cfg)
     w = model.get_weights()
-    ref_model = model_np.Model(cfg["transform_config"], rd_lambda=0.02)
-    x = data_lib.normalize_image(data_lib.synthetic_images(1, 512, 768, seed=12))
+    ref_model = model_np.Model(cfg["transform_config"], rd_lambda=cfg["rd_lambda"])
+    n, h, wd = shape
+    x = data_lib.normalize_image(data_lib.synthetic_images(n, h, wd, seed=12))
     lat = model.infer_latent_rvs(x)
     y_ref = torch_ref.to_nhwc(torch_ref.analysis_only(ref_model, w, x))
     y = lat.uq[1].loc.cpu().numpy()
-    assert y.shape == y_ref.shape == (1, 32, 48, 320)
+    assert y.shape == y_ref.shape == (n, h // 16, wd // 16, y.shape[-1])
     assert np.abs(y - y_ref).max() < 1e-4 * np.abs(y_ref).max()
     z_hat, sym, _, _ = model.encode(x)
-    px = model.decode(z_hat, sym, (512, 768)).cpu().numpy()
-    px_ref = torch_ref.decode(ref_model, w, z_hat.cpu().numpy(), sym.cpu().numpy().astype(np.float32), (512, 768))
+    px = model.decode(z_hat, sym, (h, wd)).cpu().numpy()
+    px_ref = torch_ref.decode(ref_model, w, z_hat.cpu().numpy(), sym.cpu().numpy().astype(np.float32), (h, wd))
     diff = np.abs(px.astype(np.int16) - px_ref.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (int(diff.max()), float((diff > 0).mean()))
