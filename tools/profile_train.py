@@ -8,7 +8,6 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import numpy as np
 import torch
 
 import __graft_entry__ as graft
@@ -41,7 +40,6 @@ for _ in range(args.steps):
     m = tr.train_step(x)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-flops_fwd = 0
 print(f"train step: {dt * 1e3:.2f} ms for {n} x {h}x{w} -> {n / dt:.1f} images/s, {n * h * w / dt / 1e6:.2f} Mpixel/s; loss {m['rd_loss']:.4f}")
 
 
@@ -65,9 +63,6 @@ with torch.cuda.device(dev):
     y, k_a = tr.analysis.fwd(x)
     g = torch.randn_like(y)
     t_abwd = timed(lambda: tr.analysis.bwd(k_a, g, need_dx=False))
-    # the largest weight gradient alone: conv1 5x5/2 192->192 at 128x128
-    c = [c for c in tr.analysis.convs() if c.name == "analysis/conv1"][0]
-    xin, yout = k_a[4] if False else (None, None)
 print(f"forward+backward {t_fb:.2f} ms (analysis fwd {t_fwd:.2f}, analysis bwd {t_abwd:.2f}); plan refresh {t_refresh:.2f} ms; adam {t_adam:.3f} ms")
 for kind, k, s, cin, cout, hh in (("conv", 5, 2, 192, 192, h // 2), ("conv", 3, 1, 96, 96, h // 2), ("conv", 1, 1, 192, 96, h // 2),
                                   ("conv", 1, 1, 96, 192, h // 2), ("conv", 5, 2, 3, 192, h), ("convT", 13, 8, 320, 24, h // 16)):
