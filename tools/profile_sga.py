@@ -45,3 +45,11 @@ for e in ops.PROFILE:
     tot += ms
     print(f"  {e['kind']:6s} k{e['k']} s{e['s']} {e['cin']:4d}->{e['cout']:4d} in {e['n']}x{e['h']}x{e['w']:<4d} v{e['variant']} {ms:8.4f} ms {e['flops'] / ms / 1e9:7.1f} TF")
 print(f"  conv total {tot:.3f} ms")
+# host (launch) time of a step vs time until the GPU is done: is the loop launch-bound?
+host = []
+for _ in range(10):
+    t0 = time.perf_counter()
+    model.itinf_train_step(x)
+    host.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+print(f"host time per step (no sync inside the loop body would hide it): {1e3 * sorted(host)[5]:.3f} ms")
