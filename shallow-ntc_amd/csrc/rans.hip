@@ -204,21 +204,22 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
   const unsigned long long lt = (1ull << lane) - 1ull;
 
   // stream words: the ring holds [ptr, ptr + kWordRing) at the start of a chunk; a chunk eats at most kWordRing / 2
-  long long ptr = 128, filled = 128, wfrom = 128, wto = 128;
+  int ptr = 128, filled = 128, wfrom = 128, wto = 128;          // stream positions fit 32 bits (host: cap_words < 2^30)
+  const int len32 = (int)len;
   unsigned short WR[kWordRegs];
-  auto word_fetch = [&](long long target) {
+  auto word_fetch = [&](int target) {
     wfrom = filled;
-    wto = std::min(target, len);
+    wto = std::min(target, len32);
 #pragma unroll
     for (int i = 0; i < kWordRegs; ++i) {
-      const long long q = wfrom + i * 64 + lane;
+      const int q = wfrom + i * 64 + lane;
       WR[i] = q < wto ? w[q] : (unsigned short)0;
     }
   };
   auto word_spill = [&]() {
 #pragma unroll
     for (int i = 0; i < kWordRegs; ++i) {
-      const long long q = wfrom + i * 64 + lane;
+      const int q = wfrom + i * 64 + lane;
       if (q < wto) wring[q & (kWordRing - 1)] = WR[i];
     }
     filled = std::max(filled, wto);
@@ -261,30 +262,27 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
       const int n = active ? (int)(m.y >> 16) : 1, vmin = (int)(short)(m.y & 0xffffu);
       const unsigned short* c = cdf + m.x;
       const unsigned slot = x & 0xffffu;
-      // 4-ary search for the largest sym with cdf[sym] <= slot: three independent probes per level, and the
-      // bracketing cdf values are carried along so that no read follows the search
+      // binary search for the largest sym with cdf[sym] <= slot; the bracketing cdf values are carried along so that no
+      // read follows the search.  (A lone wave is issue-bound: the 4-ary, three-probes-per-level form needs fewer LDS
+      // round trips but ~4x the instructions per level and measured slower.)
       int lo = 0, hi = n;
       unsigned clo = 0u, chi = 65536u;
       while (hi - lo > 1) {
-        const int q = (hi - lo + 3) >> 2;
-        const int p1 = lo + q, p2 = std::min(lo + 2 * q, hi - 1), p3 = std::min(lo + 3 * q, hi - 1);
-        const unsigned v1 = c[p1], v2 = c[p2], v3 = c[p3];
-        // branch-free on purpose: all three probes are consumed unconditionally, so they issue back to back
-        const int kk = (int)(slot >= v1) + (int)(slot >= v2) + (int)(slot >= v3);   // v1 <= v2 <= v3
-        const int nlo = kk == 0 ? lo : (kk == 1 ? p1 : (kk == 2 ? p2 : p3));
-        const unsigned nclo = kk == 0 ? clo : (kk == 1 ? v1 : (kk == 2 ? v2 : v3));
-        hi = kk == 0 ? p1 : (kk == 1 ? p2 : (kk == 2 ? p3 : hi));
-        chi = kk == 0 ? v1 : (kk == 1 ? v2 : (kk == 2 ? v3 : chi));
-        lo = nlo;
-        clo = nclo;
+        const int mid = (lo + hi) >> 1;
+        const unsigned v = c[mid];
+        const bool ge = slot >= v;
+        lo = ge ? mid : lo;
+        clo = ge ? v : clo;
+        hi = ge ? hi : mid;
+        chi = ge ? chi : v;
       }
       if (active) x = (chi - clo) * (x >> 16) + slot - clo;
       const bool need = active && x < (1u << 16);
       const unsigned long long mask = __ballot(need);
       if (mask) {                                            // one word each, in lane order, from the shared pointer
         if (need) {
-          const long long q = ptr + __popcll(mask & lt);
-          ok &= q < len;
+          const int q = ptr + __popcll(mask & lt);
+          ok &= q < len32;
           x = (x << 16) | wring[q & (kWordRing - 1)];
         }
         ptr += __popcll(mask);
@@ -294,8 +292,8 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
       const unsigned long long emask = __ballot(esc);
       if (emask) {
         if (esc) {
-          const long long q = ptr + __popcll(emask & lt);
-          ok &= q < len;
+          const int q = ptr + __popcll(emask & lt);
+          ok &= q < len32;
           v = (int)(x & 0xffffu) - 32768;
           x = (x & 0xffff0000u) | wring[q & (kWordRing - 1)];
         }
@@ -307,7 +305,7 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
     tid_spill((int)((k + 1) & 1));
   }
   // a well-formed stream ends with every state back at its initial value and the pointer at the end
-  const bool good = ok && x == (1u << 16) && ptr == len;
+  const bool good = ok && x == (1u << 16) && ptr == len32;
   if (__ballot(!good) && lane == 0) atomicAdd(bad, 1);
 }
 
