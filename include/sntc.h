@@ -264,6 +264,10 @@ int sntc_distortion_grad(const float* x, const float* x_hat, int n, int h, int w
                          float* g_xhat, double* sse, void* stream);
 /* Backward of the activation + residual split of sntc_two_layer_tail: t is the forward input, g_h the gradient
  * w.r.t. h; g_t[npix, cp] = [d act(base) | g_h (if has_res) | zeros up to cp]. */
+/* Input gradient of the tail's output layer (Conv2DTranspose 5x5 / 2, ch -> 3, SAME; w2 [5,5,3,ch]):
+ * g_h[n, hh, wh, ch] from g_xhat[n, 2 hh, 2 wh, 3] -- an HBM stream, not worth a GEMM launch. */
+int sntc_two_layer_out_adjoint(const float* g_xhat, int n, int hh, int wh, int ch, const float* w2, int k2, int s2, int cout,
+                               float* g_h, void* stream);
 /* abs_x / g_x (both [npix, ch], may both be NULL): |base| and g_h * base, the operands of the IGDN1 parameter
  * gradients of the training step (d gamma = |x|^T (g x) summed over pixels, d beta = column sums of g x). */
 int sntc_two_layer_tail_bwd(const float* t, const float* g_h, int64_t npix, int ch, int has_res, int act_kind,

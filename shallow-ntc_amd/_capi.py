@@ -83,6 +83,7 @@ SIGNATURES = {
     "sntc_sga_chain": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, _P, _P]),
     "sntc_distortion_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
     "sntc_two_layer_tail_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "sntc_two_layer_out_adjoint": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float, _P]),
     "sntc_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),
     "sntc_conv_wgrad": (C.c_int, [C.c_int] * 6 + [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int64, _P]),

@@ -281,6 +281,45 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- input gradient of the 5x5 / stride-2 output layer of the two-layer decoders (Conv2DTranspose Ch -> 3, SAME):
+//   g_h[n, i, j, c] = sum_{ky,kx,o} g_x[n, 2i + ky - 1, 2j + kx - 1, o] W[ky, kx, o, c]
+// 75 Ch multiply-adds per half-resolution pixel on 3-channel data: an HBM stream, not a GEMM -- one thread per output
+// pixel, weights in LDS, the 5x5x3 window read through L1 (the gather-GEMM needs 0.48 ms for 5 x 1216^2, this ~0.1 ms).
+template <int CH>
+__global__ void __launch_bounds__(256) out_adjoint_kernel(const float* __restrict__ gx, int hh, int wh, const float* __restrict__ w2,
+                                                          float* __restrict__ gh) {
+  __shared__ float sw[75 * CH];
+  for (int i = threadIdx.x; i < 75 * CH; i += blockDim.x) sw[i] = w2[i];
+  __syncthreads();
+  const int img = blockIdx.y;
+  const int H = 2 * hh, W = 2 * wh;
+  const float* src = gx + (size_t)img * H * W * 3;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hh * wh; p += gridDim.x * blockDim.x) {
+    const int i = p / wh, j = p - i * wh;
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const int y = 2 * i + ky - 1;
+      if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const int x = 2 * j + kx - 1;
+        if ((unsigned)x >= (unsigned)W) continue;
+        const float* g = src + ((size_t)y * W + x) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        const float* wk = sw + (ky * 5 + kx) * 3 * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] += g0 * wk[c] + g1 * wk[CH + c] + g2 * wk[2 * CH + c];
+      }
+    }
+    float* dst = gh + ((size_t)img * hh * wh + p) * CH;
+#pragma unroll
+    for (int c = 0; c < CH; c += 4) *reinterpret_cast<f32x4*>(dst + c) = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+  }
+}
+
 // ---- Keras Adam (non-amsgrad): alpha = lr sqrt(1-b2^t)/(1-b1^t); p -= alpha m / (sqrt(v) + eps) ----
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps,
@@ -686,4 +725,26 @@ extern "C" int sntc_prior_param_grad(const sntc_prior* prior, const float* matri
                      prior->channels, matrices, factors, grad_record, weight, g_matrices, g_biases, g_factors);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
+}
+
+template <int CH>
+static int launch_out_adjoint(const float* gx, int n, int hh, int wh, const float* w2, float* gh, hipStream_t s) {
+  const int blocks = std::min((hh * wh + 255) / 256, 4096);
+  hipLaunchKernelGGL((out_adjoint_kernel<CH>), dim3(blocks, n), dim3(256), 0, s, gx, hh, wh, w2, gh);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_two_layer_out_adjoint(const float* g_xhat, int n, int hh, int wh, int ch, const float* w2, int k2, int s2,
+                                          int cout, float* g_h, void* stream) {
+  if (!g_xhat || !w2 || !g_h || n < 1 || hh < 1 || wh < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_out_adjoint: bad argument");
+  if (k2 != 5 || s2 != 2 || cout != 3) return fail(SNTC_ERR_UNSUPPORTED, "sntc_two_layer_out_adjoint: 5x5 / stride-2 / 3-channel output layer only");
+  if (n > 65535) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_out_adjoint: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  switch (ch) {
+    case 12: return launch_out_adjoint<12>(g_xhat, n, hh, wh, w2, g_h, s);
+    case 24: return launch_out_adjoint<24>(g_xhat, n, hh, wh, w2, g_h, s);
+    case 48: return launch_out_adjoint<48>(g_xhat, n, hh, wh, w2, g_h, s);
+    default: return fail(SNTC_ERR_UNSUPPORTED, "sntc_two_layer_out_adjoint: hidden channels must be 12, 24 or 48");
+  }
 }

@@ -338,6 +338,15 @@ def two_layer_tail_bwd(t, g_h, ch, has_res, act_kind, beta, gamma, cp, param_ope
     return (g_t, ax, gx) if param_operands else g_t
 
 
+def two_layer_out_adjoint(g_xhat, w2, ch, k2=5, s2=2):
+    """Gradient w.r.t. the hidden layer of a two-layer decoder from the gradient w.r.t. its output image."""
+    _check_nhwc(g_xhat, 3)
+    n, H, W, _ = g_xhat.shape
+    g_h = torch.empty((n, H // s2, W // s2, ch), dtype=torch.float32, device=g_xhat.device)
+    capi.call("sntc_two_layer_out_adjoint", _ptr(g_xhat), n, H // s2, W // s2, ch, _ptr(w2), k2, s2, 3, _ptr(g_h), _stream())
+    return g_h
+
+
 def adam_step(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
     """In-place Keras Adam update of ``param`` (and its moments m, v); t is the 1-based step."""
     capi.call("sntc_adam_step", _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), float(lr), float(beta1),

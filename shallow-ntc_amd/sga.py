@@ -67,7 +67,6 @@ class TwoLayerBackward:
         k1p = np.zeros(k1.shape[:2] + (self.cp, k1.shape[3]), np.float32)
         k1p[:, :, :c2] = k1
         self.up_adj = ops.ConvPlan("conv", ops.to_device(k1p, dev), None, t._s[0])
-        self.out_adj = ops.ConvPlan("conv", t._w2, None, t._s[1])      # [5,5,3,Ch] read as HWIO (3 -> Ch)
 
     def forward(self, x):
         t = self.t
@@ -76,7 +75,7 @@ class TwoLayerBackward:
 
     def backward(self, g_xhat, mid):
         t = self.t
-        g_h = self.out_adj(g_xhat)
+        g_h = ops.two_layer_out_adjoint(g_xhat, t._w2, t._ch, t._k[1], t._s[1])      # 3-channel stream, not a GEMM
         g_t = ops.two_layer_tail_bwd(mid, g_h, t._ch, t._has_res, t._act_kind, t._beta, t._gamma, self.cp)
         return self.up_adj(g_t)
 

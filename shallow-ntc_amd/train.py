@@ -250,7 +250,8 @@ class TTwoLayer:
     def bwd(self, ctx, g, need_dx=True):
         t = self.t
         k_up, k_out, mid = ctx
-        g_h = self.out.bwd(k_out, g)
+        self.out.bwd(k_out, g, need_dx=False)                      # weight / bias gradients of the output layer
+        g_h = ops.two_layer_out_adjoint(g, self.out.W, t._ch, t._k[1], t._s[1])
         c2 = t._ch * (2 if t._has_res else 1)
         if self.gdn:
             g_t, ax, gx = ops.two_layer_tail_bwd(mid, g_h, t._ch, t._has_res, t._act_kind, self.beta, self.gamma, c2, param_operands=True)

@@ -194,3 +194,23 @@ def test_sga_optimisation_improves_rd(dev):
     assert after["rd_loss"] < before["rd_loss"], (before, after)
     assert {"rd_loss", "bpp", "mse", "psnr", "tau", "scheduled_lr", "sched_rd_lambda"} <= set(m)
     assert abs(m["scheduled_lr"] - 5e-3) < 1e-12
+
+
+@pytest.mark.parametrize("ch,n,hh,wh", [(12, 2, 9, 13), (24, 1, 16, 8), (48, 1, 5, 7)])
+def test_out_layer_adjoint_stream_kernel(ch, n, hh, wh, dev):
+    """sntc_two_layer_out_adjoint == the gather-GEMM adjoint plan (Conv2D 5x5/2 on the same kernel array) == float64 autograd."""
+    from shallow_ntc_amd import ops
+    from oracle import train_ref
+    rng = np.random.default_rng(ch)
+    w2 = (rng.standard_normal((5, 5, 3, ch)) * 0.2).astype(np.float32)          # Conv2DTranspose kernel [kh,kw,Cout=3,Cin=ch]
+    g = rng.standard_normal((n, 2 * hh, 2 * wh, 3)).astype(np.float32)
+    wd, gd = torch.from_numpy(w2).to(dev), torch.from_numpy(g).to(dev)
+    got = ops.two_layer_out_adjoint(gd, wd, ch).cpu().numpy()
+    plan = ops.ConvPlan("conv", wd, None, 2)
+    via_gemm = plan(gd).cpu().numpy()
+    h = torch.zeros((n, ch, hh, wh), dtype=torch.float64, requires_grad=True)
+    out = train_ref.conv2d_transpose(h, torch.from_numpy(w2.astype(np.float64)), None, 2)
+    (out * train_ref.as_input(g)).sum().backward()
+    ref = h.grad.permute(0, 2, 3, 1).numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 2e-5 * scale and np.abs(via_gemm - ref).max() < 2e-5 * scale
