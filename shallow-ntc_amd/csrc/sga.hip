@@ -284,13 +284,10 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
 // ---- input gradient of the 5x5 / stride-2 output layer of the two-layer decoders (Conv2DTranspose Ch -> 3, SAME):
 //   g_h[n, i, j, c] = sum_{ky,kx,o} g_x[n, 2i + ky - 1, 2j + kx - 1, o] W[ky, kx, o, c]
 // 75 Ch multiply-adds per half-resolution pixel on 3-channel data: an HBM stream, not a GEMM -- one thread per output
-// pixel, weights in LDS, the 5x5x3 window read through L1 (the gather-GEMM needs 0.48 ms for 5 x 1216^2, this ~0.1 ms).
+// pixel, weights through scalar loads, the 5x5x3 window read through L1 (the gather-GEMM needs 0.48 ms for 5 x 1216^2, this ~0.1 ms).
 template <int CH>
 __global__ void __launch_bounds__(256) out_adjoint_kernel(const float* __restrict__ gx, int hh, int wh, const float* __restrict__ w2,
                                                           float* __restrict__ gh) {
-  __shared__ float sw[75 * CH];
-  for (int i = threadIdx.x; i < 75 * CH; i += blockDim.x) sw[i] = w2[i];
-  __syncthreads();
   const int img = blockIdx.y;
   const int H = 2 * hh, W = 2 * wh;
   const float* src = gx + (size_t)img * H * W * 3;
@@ -309,7 +306,7 @@ __global__ void __launch_bounds__(256) out_adjoint_kernel(const float* __restric
         if ((unsigned)x >= (unsigned)W) continue;
         const float* g = src + ((size_t)y * W + x) * 3;
         const float g0 = g[0], g1 = g[1], g2 = g[2];
-        const float* wk = sw + (ky * 5 + kx) * 3 * CH;
+        const float* wk = w2 + (ky * 5 + kx) * 3 * CH;      // wave-uniform, compile-time offsets: scalar loads
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[c] += g0 * wk[c] + g1 * wk[CH + c] + g2 * wk[2 * CH + c];
       }
