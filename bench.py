@@ -298,7 +298,21 @@ def main():
             if p > 0:
                 times.append(time.perf_counter() - t0)
         t_cpu = float(np.median(times))
+        # the encoder side on a 2-image sample (the ELIC analysis is 12x the decoder's FLOPs: the full set would take minutes)
+        from oracle import transforms_np as T
+        enc_x = batches[0][1][:2].cpu().numpy()
+        enc_times = []
+        for p in range(3):
+            t0 = time.perf_counter()
+            yc = torch_ref.analysis_only(ref_model, weights, enc_x)
+            with torch.no_grad():
+                ref_model.hyper_analysis(T.sub_params(weights, "hyper_analysis/"), yc, be=torch_ref)
+            if p > 0:
+                enc_times.append(time.perf_counter() - t0)
+        enc_px = enc_x.shape[0] * enc_x.shape[1] * enc_x.shape[2]
         cpu_baseline = dict(value=round(pixels_per_step / t_cpu / 1e6, 3), unit="Mpixel/s", cores=torch.get_num_threads(),
+                            encode_transforms_value=round(enc_px / float(np.median(enc_times)) / 1e6, 3),
+                            encode_sample=f"analysis + hyper-analysis of {enc_x.shape[0]} images of the set, median of 2 passes after 1 warm-up",
                             kind="port",
                             sample=f"{n_img} Kodak-shaped images decoded by oracle/torch_ref.py (float32, oneDNN), "
                                    f"median of {args.cpu_passes} passes after 1 warm-up; the reference's TF-CPU path "
