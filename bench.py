@@ -55,9 +55,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=24, help="images per rank (Kodak-24 shaped set)")
-    ap.add_argument("--workload", choices=["kodak24", "w1"], default="kodak24",
+    ap.add_argument("--workload", choices=["kodak24", "w1", "w3"], default="kodak24",
                     help="kodak24: the metric's configuration (default); w1: SURVEY 8d synthetic batches of "
-                         "--images (default 64) 256x256 crops")
+                         "--images (default 64) 256x256 crops; w3: 5 x 1200x1200 (Tecnick-shaped, padded to 1216)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-only", action="store_true",
                     help="only launch decode kernels (the command profiles/ is recorded with): skips the "
@@ -98,6 +98,8 @@ def main():
 
     if args.workload == "w1":
         shapes = [(256, 256)] * (64 if args.images == 24 else args.images)
+    elif args.workload == "w3":
+        shapes = [(1200, 1200)] * (5 if args.images == 24 else args.images)
     else:
         shapes = KODAK_SHAPES[:args.images] if args.images <= 24 else [KODAK_SHAPES[i % 24] for i in range(args.images)]
     groups = {}
@@ -117,8 +119,9 @@ def main():
     g.manual_seed(99 + rank)
     for ids, x, (h, wd) in batches:
         n = len(ids)
-        z_hat = torch.round(3.0 * torch.randn((n, h // 64, wd // 64, 320), device=dev, generator=g)).contiguous()
-        u = torch.rand((n, h // 16, wd // 16, 320), device=dev, generator=g) - 0.5
+        hp, wp = -(-h // 64) * 64, -(-wd // 64) * 64               # latents live on the padded grid (pad_images to a multiple of 64)
+        z_hat = torch.round(3.0 * torch.randn((n, hp // 64, wp // 64, 320), device=dev, generator=g)).contiguous()
+        u = torch.rand((n, hp // 16, wp // 16, 320), device=dev, generator=g) - 0.5
         sym = torch.round(-2.0 * torch.sign(u) * torch.log1p(-2.0 * u.abs())).to(torch.int32).contiguous()
         codes.append((z_hat, sym, (h, wd), x))
     torch.cuda.synchronize()
@@ -331,6 +334,7 @@ def main():
             dtype="f32", data="synthetic",
             config=dict(workload=f"mshyper/configs/two_layer_syn.py (ElicAnalysis 192,192,192,320 + TwoLayerResSynthesis 12,3), "
                                  + (f"W1 synthetic batch per GPU ({len(shapes)} x 256x256), " if args.workload == "w1" else
+                                    f"W3 synthetic batch per GPU ({len(shapes)} x 1200x1200), " if args.workload == "w3" else
                                     f"Kodak-24-shaped synthetic set per GPU ({len(shapes)} images: 512x768 / 768x512), ") +
                                  "random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
                         timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels",
