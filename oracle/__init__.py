@@ -36,5 +36,10 @@ Modules
   model_np       mshyper/models.py and factorized/models.py eval forward + SGA loss.
   torch_ref      independent float32 PyTorch-CPU restatement (also the timed CPU
                  baseline, kind "port").
-  make_golden    generates tests/golden/*.npz from ops_np/transforms_np.
+  train_ref      float64 PyTorch-autograd restatement of the training loss (Model.train_step's forward,
+                 mshyper/models.py:234-359,375-383, 'unoise' / 'mixedq') as a transforms_np backend: the
+                 gradient reference of tests/test_hip_train.py, plus the Keras-Adam / clipnorm arithmetic.
+  rans_np        pure-Python restatement of THIS build's rANS wire format and table construction (the
+                 reference has no bitstream): pins csrc/rans.hip word for word.
+  make_golden    generates tests/golden/*.npz from ops_np/transforms_np/rans_np.
 """
