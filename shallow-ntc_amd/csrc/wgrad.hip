@@ -16,6 +16,7 @@
 // pixel k + 1) -- conflict-free without padding.  Global loads are 16 B per lane along channels, zero outside the
 // image (padding taps) or beyond M / N / the slab.
 #include <algorithm>
+#include <cstdlib>
 #include "sntc_internal.h"
 
 namespace sntc {
@@ -34,6 +35,7 @@ struct WGArgs {
   long long P;         // n*Hd*Wd
   long long pslab;     // pixels per K slab (multiple of BK)
   int ntm, ntn, ksplit;
+  int dbg;             // diagnostic switches (SNTC_WG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers
 };
 
 constexpr int kBK = 16;     // pixels per LDS stage (32 measured slower: fewer, fatter K slabs and half the blocks per CU)
@@ -77,55 +79,71 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
   constexpr int BTOT = kBK * BC4;                           // float4 per stage
   constexpr int BPASS = (BTOT + 255) / 256;
 
-  // the two pixel rows this thread gathers per stage, as (image, i, j): decoded once, then advanced by kBK pixels
-  // per stage (no per-stage division)
-  int pi[kAPass], pj[kAPass], pimg[kAPass];
+  // The pixel rows this thread gathers per stage, as (i, j) + the element offset of S[img, i*s, j*s, 0]: decoded once,
+  // then advanced by kBK pixels per stage (no division, 32-bit offsets: tensors are < 2^31 elements, host check).
+  int pi[kAPass], pj[kAPass];
+  unsigned sbase[kAPass];
+  const unsigned step_j = (unsigned)(a.stride * a.Cs), step_i = (unsigned)(a.stride * a.Ws * a.Cs);
+  const unsigned wrap_j = (unsigned)a.Wd * step_j;                       // what a full row of D pixels adds along j
+  const unsigned next_img = (unsigned)(a.Hs * a.Ws * a.Cs) - (unsigned)a.Hd * step_i;   // (img + 1, 0) - (img, Hd)
 #pragma unroll
   for (int q = 0; q < kAPass; ++q) {
     const long long p = p0 + ar0 + 8 * q;
     const long long hw = (long long)a.Hd * a.Wd;
-    pimg[q] = (int)(p / hw);
-    const int rem = (int)(p - (long long)pimg[q] * hw);
+    const int img = (int)(p / hw);
+    const int rem = (int)(p - (long long)img * hw);
     pi[q] = rem / a.Wd;
     pj[q] = rem - pi[q] * a.Wd;
+    sbase[q] = (unsigned)img * (unsigned)(a.Hs * a.Ws * a.Cs) + (unsigned)pi[q] * step_i + (unsigned)pj[q] * step_j;
+  }
+  // tap offsets of this thread's four gathered columns, relative to S[img, i*s, j*s, 0]
+  int toff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) toff[e] = (aky[e] * a.Ws + akx[e]) * a.Cs + acs[e];
+  unsigned boff[BPASS];                                                  // element offsets into D of this thread's B loads
+#pragma unroll
+  for (int q = 0; q < BPASS; ++q) {
+    const int idx = tid + 256 * q;
+    const int row = idx / BC4, c4 = idx - row * BC4;
+    boff[q] = (unsigned)(p0 + row) * (unsigned)a.Cd + (unsigned)(n0 + 4 * c4);
   }
   f32x4 ra[kAPass], rb[BPASS];
   auto gload = [&](long long pb) {
+    const int left = (int)std::min<long long>(p1 - pb, kBK);             // valid pixel rows in this stage
 #pragma unroll
     for (int q = 0; q < kAPass; ++q) {
-      const long long p = pb + ar0 + 8 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p < p1) {
-        const int img = pimg[q], i = pi[q], j = pj[q];
+      if (ar0 + 8 * q < left) {
+        const int i = pi[q], j = pj[q];
         if (VECS) {
           const int sy = i * a.stride + aky[0], sx = j * a.stride + akx[0];
-          if (aok[0] && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
-            v = *reinterpret_cast<const f32x4*>(a.S + (((size_t)img * a.Hs + sy) * a.Ws + sx) * a.Cs + acs[0]);
+          if (aok[0] && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws)
+            v = *reinterpret_cast<const f32x4*>(a.S + (int)(sbase[q] + (unsigned)toff[0]));
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int sy = i * a.stride + aky[e], sx = j * a.stride + akx[e];
-            if (aok[e] && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
-              v[e] = a.S[(((size_t)img * a.Hs + sy) * a.Ws + sx) * a.Cs + acs[e]];
+            if (aok[e] && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws) v[e] = a.S[(int)(sbase[q] + (unsigned)toff[e])];
           }
         }
       }
       ra[q] = v;
       pj[q] += kBK;                                         // next stage: kBK pixels further
+      sbase[q] += kBK * step_j;
       while (pj[q] >= a.Wd) {
         pj[q] -= a.Wd;
-        if (++pi[q] == a.Hd) { pi[q] = 0; ++pimg[q]; }
+        sbase[q] += step_i - wrap_j;
+        if (++pi[q] == a.Hd) { pi[q] = 0; sbase[q] += next_img; }
       }
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       const int idx = tid + 256 * q;
       const int row = idx / BC4, c4 = idx - row * BC4;
-      const long long p = pb + row;
-      const int bn = n0 + 4 * c4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < BTOT && p < p1 && bn < a.N) v = *reinterpret_cast<const f32x4*>(a.D + (size_t)p * a.Cd + bn);   // N % 4 == 0
+      if (idx < BTOT && row < left && n0 + 4 * c4 < a.N) v = *reinterpret_cast<const f32x4*>(a.D + boff[q]);   // N % 4 == 0
       rb[q] = v;
+      boff[q] += (unsigned)(kBK * a.Cd);
     }
   };
   auto lstore = [&](int buf) {
@@ -157,7 +175,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
   __syncthreads();
   for (long long pb = p0; pb < p1; pb += kBK) {
     const bool more = pb + kBK < p1;
-    if (more) gload(pb + kBK);
+    if (more && !(a.dbg & 1)) gload(pb + kBK);
 #pragma unroll
     for (int kk = 0; kk < kBK / 2; ++kk) {
       float fa[TM], fb[TN];
@@ -170,8 +188,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
+    if (more && !(a.dbg & 2)) lstore(buf ^ 1);
+    if (!(a.dbg & 4)) __syncthreads();
     buf ^= 1;
   }
 
@@ -345,6 +363,7 @@ extern "C" int sntc_conv_wgrad(int kind, int kh, int kw, int stride, int cin, in
     return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_wgrad: tensors of 2^31 elements or more: split the batch");
   a.slab = a.ksplit > 1 ? static_cast<float*>(workspace) : dw;      // one slab: the kernel writes dW itself
   a.accumulate = accumulate;
+  if (const char* e = getenv("SNTC_WG_DBG")) a.dbg = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((long long)a.ntm * a.ntn * a.ksplit));
   const bool vec = g.Cs % 4 == 0;
