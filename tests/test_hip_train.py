@@ -164,7 +164,7 @@ def test_loss_and_gradients_match_autograd(synthesis, analysis, uq, dev):
     worst = max(((_rel(got[k], rg[k]), k) for k in rg), key=lambda t: t[0])
     for k in rg:
         assert np.abs(rg[k]).max() > 0, f"{k}: reference gradient is identically zero (test would be vacuous)"
-    assert worst[0] < 3e-4, worst
+    assert worst[0] < 2e-5, worst          # measured: 3e-6
 
 
 def test_train_step_updates_and_export(dev):
