@@ -220,3 +220,20 @@ def test_full_width_models_against_the_independent_cpu_restatement(name, shape, 
     px_ref = torch_ref.decode(ref_model, w, z_hat.cpu().numpy(), sym.cpu().numpy().astype(np.float32), (h, wd))
     diff = np.abs(px.astype(np.int16) - px_ref.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (int(diff.max()), float((diff > 0).mean()))
+    # rate: the float64 entropy oracle on the SAME latents / hyper-synthesis output (north star: <= 1e-4 bpp, integer
+    # symbols bit-exact), and PSNR of the two pixel sets against the input within 1e-3 dB
+    from oracle import model_np as M
+    from oracle import ops_np as O
+    hyper = model._hyper_synthesis(z_hat).cpu().numpy().astype(np.float64)
+    c = hyper.shape[-1] // 2
+    _, bits_y_ref, sym_ref = O.scale_indexed_normal(y.astype(np.float64), hyper[..., :c], np.exp(hyper[..., c:]))
+    ms, bs, fs = M._prior_lists(w)
+    zq_ref, bits_z_ref = O.batched_deep_factorized(lat.uq[0].loc.cpu().numpy().astype(np.float64), ms, bs, fs)
+    _, _, bits_z, bits_y = model.encode(x)
+    np.testing.assert_array_equal(sym.cpu().numpy(), np.asarray(sym_ref, np.int64))
+    np.testing.assert_array_equal(z_hat.cpu().numpy(), zq_ref)
+    npix = float(h * wd)
+    assert np.abs(bits_y.cpu().numpy() - bits_y_ref).max() / npix < 1e-4 and np.abs(bits_z.cpu().numpy() - bits_z_ref).max() / npix < 1e-4
+    x255 = np.rint((x.astype(np.float64) + 0.5) * 255.0)
+    psnr = lambda p: 10.0 * np.log10(255.0 ** 2 / ((x255 - p.astype(np.float64)) ** 2).mean(axis=(1, 2, 3)))
+    assert np.abs(psnr(px) - psnr(px_ref)).max() < 1e-3
