@@ -196,19 +196,20 @@ int sntc_dequant_scale_normal(const int32_t* symbols, const float* hyper, int n,
  *   Tables: cdf = uint16, concatenated, table t holds cdf[0..n) (cdf[n] = 65536 implicit; pad the array to an even
  *   count); meta = uint32 [ntables][2] = { offset into cdf, (n << 16) | (vmin & 0xffff) }; the last symbol of every
  *   table is ESCAPE, followed in the stream by value + 32768 as a raw 16-bit word.
- *   Stream = [64 x (state hi, state lo)] [16-bit words in decode order]  (format: csrc/rans.hip header).
+ *   Stream = [lanes x (state hi, state lo)] [16-bit words in decode order]  (format: csrc/rans.hip header);
+ *   lanes in {8, 16, 32, 64}: element lanes*j + l belongs to lane l at step j; fewer lanes = fewer flushed bytes.
  * ------------------------------------------------------------------------------------------------------- */
 int64_t sntc_rans_cap_words(int64_t elems_per_image, int segments);
 /* scratch: uint16 [nimages * segments][cap_words]; stream s ends up in the LAST len_words[s] words of its row. */
 int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t elems_per_image, int segments,
-                     const uint16_t* cdf, const uint32_t* meta, int ntables, int total_entries, int64_t cap_words,
+                     int lanes, const uint16_t* cdf, const uint32_t* meta, int ntables, int total_entries, int64_t cap_words,
                      uint16_t* scratch, int32_t* len_words, void* stream);
 /* gathers the streams into one payload; offsets int64 [nstreams + 1] = exclusive prefix sum of len_words */
 int sntc_rans_compact(const uint16_t* scratch, int64_t cap_words, const int32_t* len_words, const int64_t* offsets,
                       int nstreams, uint16_t* payload, void* stream);
 /* bad_streams (int32[1], device) counts streams that did not end at their initial state / length: corruption */
 int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
-                     int64_t elems_per_image, int segments, const uint16_t* cdf, const uint32_t* meta, int ntables,
+                     int64_t elems_per_image, int segments, int lanes, const uint16_t* cdf, const uint32_t* meta, int ntables,
                      int total_entries, int32_t* values, int32_t* bad_streams, void* stream);
 /* table id of every y element = round(clamp(exp(raw), 0, 63)), raw = hyper[..., c:]; of every z element = channel */
 int sntc_scale_table_ids(const float* hyper, int64_t npix, int c, uint16_t* table_ids, void* stream);

@@ -118,7 +118,7 @@ def small_model_fixture():
 
 def bitstream_fixture():
     """A frozen rANS stream of this build's wire format (oracle/rans_np.py): 505 values over all 64 scale tables incl.
-    escapes -> the exact uint16 words, for 1 and 3 segments."""
+    escapes -> the exact uint16 words, for (1 segment, 64 lanes) and (3 segments, 16 lanes)."""
     from . import rans_np
     rng = np.random.default_rng(0)
     tabs = rans_np.normal_tables()
@@ -131,18 +131,19 @@ def bitstream_fixture():
     vals[1, 504] = 32767
     d = dict(values=vals, table_ids=tids, table_sizes=np.array([len(f) for _, f in tabs], np.int32),
              table_min=np.array([lo for lo, _ in tabs], np.int32), table_freqs=np.concatenate([np.asarray(f, np.int32) for _, f in tabs]))
-    for segs in (1, 3):
+    for segs, lanes in ((1, 64), (3, 16)):
         eseg = -(-(-(-E // segs)) // 64) * 64
         words, lens = [], []
         for b in range(n):
             for g in range(segs):
                 sl = slice(g * eseg, min(E, (g + 1) * eseg))
-                w = rans_np.encode_stream(vals[b, sl], tids[b, sl], tabs)
-                assert rans_np.decode_stream(w, tids[b, sl], tabs) == vals[b, sl].tolist()
+                w = rans_np.encode_stream(vals[b, sl], tids[b, sl], tabs, lanes)
+                assert rans_np.decode_stream(w, tids[b, sl], tabs, lanes) == vals[b, sl].tolist()
                 words += w
                 lens.append(len(w))
         d[f"words_s{segs}"] = np.asarray(words, np.uint16)
         d[f"lens_s{segs}"] = np.asarray(lens, np.int64)
+        d[f"lanes_s{segs}"] = np.asarray(lanes, np.int64)
     np.savez_compressed(OUT / "bitstream.npz", **d)
 
 

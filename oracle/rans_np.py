@@ -1,7 +1,7 @@
 """Pure-Python restatement of the interleaved rANS stream format of csrc/rans.hip (TEST INFRASTRUCTURE; small cases).
 
 Not a reference algorithm: the reference has no bitstream (compression=False, mshyper/models.py:246-251).  This pins
-the product's own wire format: 64 lanes, each a 32-bit state with 16-bit renormalisation and 16-bit probability
+the product's own wire format: LANES (8 .. 64) lanes, each a 32-bit state with 16-bit renormalisation and 16-bit probability
 precision, sharing one sequence of 16-bit words; element 64 j + l of the segment belongs to lane l at step j;
 ESCAPE = last symbol of a table, followed by (value + 32768) as a raw 16-bit word;
 stream = [lane 0 state hi, lo, lane 1 state hi, lo, ...] [words in decode order]."""
@@ -57,7 +57,7 @@ def _cdf(f):
     return c
 
 
-def encode_stream(values, tids, tables):
+def encode_stream(values, tids, tables, LANES=LANES):
     """tables[t] = (vmin, freqs incl. ESCAPE last).  Returns the list of uint16 words in stream order.
     Works backward exactly as the kernel does, so ``rev`` collects words from the last address to the first."""
     values, tids = [int(v) for v in values], [int(t) for t in tids]
@@ -91,7 +91,7 @@ def encode_stream(values, tids, tables):
     return list(reversed(rev))
 
 
-def decode_stream(words, tids, tables):
+def decode_stream(words, tids, tables, LANES=LANES):
     tids = [int(t) for t in tids]
     n = len(tids)
     steps = -(-n // LANES)

@@ -4,7 +4,7 @@
 // the *estimated* rate; this coder is this build's own wire format, not TFC's.
 //
 // One stream per (image, segment); ONE WAVE codes a stream: the segment's elements (flat [P, C] order) are dealt
-// round-robin to the 64 lanes (step j, lane l <-> element 64 j + l, so table-id / value accesses are one coalesced
+// round-robin to L = 8 .. 64 lanes (step j, lane l <-> element L j + l, so table-id / value accesses are one coalesced
 // line per step), every lane owns a 32-bit rANS state and all lanes share one sequence of 16-bit words:
 //   decode step:  s = x & 0xffff -> (symbol, f, c);  x = f (x >> 16) + s - c;  lanes with x < 2^16 each take ONE
 //                 word, in lane order, from the shared read pointer (wave ballot + popcount of lower lanes);
@@ -13,9 +13,9 @@
 //   encode step:  the exact mirror, steps in reverse, writing backward: ESCAPE lanes emit x & 0xffff and set
 //                 x = (x & ~0xffff) | (v + 32768); then lanes with x >= f << 16 emit x & 0xffff, x >>= 16;
 //                 x = ((x / f) << 16) + x % f + c.  The highest lane gets the highest address.
-//   stream     =  [64 x (state hi, state lo)] [words in decode order]; every state starts (encoder) and must end
+//   stream     =  [L x (state hi, state lo)] [words in decode order]; every state starts (encoder) and must end
 //                 (decoder) at 2^16, and the read pointer must end at the stream's length: a free integrity check.
-// Cost of the parallelism: 256 bytes of flushed state per stream.  Probability precision 16 bits; CDF tables are
+// Cost of the parallelism: 4 L bytes of flushed state per stream (the host uses fewer lanes on short streams).  Probability precision 16 bits; CDF tables are
 // uint16 (cdf[n] = 65536 implicit) and live in LDS next to a packed (offset, n, vmin) descriptor per table.
 #include <algorithm>
 #include "sntc_internal.h"
@@ -62,7 +62,7 @@ __device__ __forceinline__ void rans_stage_tables(const RansTables& T, unsigned 
 // one wave per stream s = (image b, segment sg): elements [b E + sg Eseg, min((b + 1) E, b E + (sg + 1) Eseg))
 template <bool LDS>
 __global__ void __launch_bounds__(64) rans_encode_kernel(const int* __restrict__ values, const unsigned short* __restrict__ tid,
-                                                         int segs, long long E, long long Eseg, RansTables T, long long cap,
+                                                         int segs, int L, long long E, long long Eseg, RansTables T, long long cap,
                                                          unsigned short* __restrict__ scratch, int* __restrict__ len_words) {
   extern __shared__ unsigned char smem[];
   unsigned short* tring = reinterpret_cast<unsigned short*>(smem);                   // [2][kChunk * 64]
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) rans_encode_kernel(const int* __restrict__
   const int b = s / segs, sg = s - b * segs;
   const long long e0 = (long long)b * E + (long long)sg * Eseg;
   const long long e1 = std::min((long long)(b + 1) * E, e0 + Eseg);
-  const long long steps = e1 > e0 ? (e1 - e0 + 63) / 64 : 0;
+  const long long steps = e1 > e0 ? (e1 - e0 + L - 1) / L : 0;      // L = lanes in use (8 .. 64): short streams flush fewer states
   const long long nchunks = (steps + kChunk - 1) / kChunk;
   unsigned short* out = scratch + (size_t)s * cap;
   long long wp = cap;
@@ -86,8 +86,8 @@ __global__ void __launch_bounds__(64) rans_encode_kernel(const int* __restrict__
   auto fetch = [&](long long k) {
 #pragma unroll
     for (int i = 0; i < kChunk; ++i) {
-      const long long e = e0 + (k * kChunk + i) * 64 + lane;
-      const bool a = k >= 0 && e < e1;
+      const long long e = e0 + (k * kChunk + i) * L + lane;
+      const bool a = k >= 0 && lane < L && e < e1;
       TR[i] = a ? tid[e] : kNoTable;
       VR[i] = a ? values[e] : 0;
     }
@@ -161,9 +161,11 @@ __global__ void __launch_bounds__(64) rans_encode_kernel(const int* __restrict__
     }
     spill((int)((k - 1) & 1));
   }
-  wp -= 128;
-  out[wp + 2 * lane] = (unsigned short)(x >> 16);
-  out[wp + 2 * lane + 1] = (unsigned short)(x & 0xffffu);
+  wp -= 2 * L;
+  if (lane < L) {
+    out[wp + 2 * lane] = (unsigned short)(x >> 16);
+    out[wp + 2 * lane + 1] = (unsigned short)(x & 0xffffu);
+  }
   if (lane == 0) len_words[s] = (int)(cap - wp);
 }
 
@@ -179,7 +181,7 @@ __global__ void rans_compact_kernel(const unsigned short* __restrict__ src, long
 
 template <bool LDS>
 __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* __restrict__ payload, const long long* __restrict__ offsets,
-                                                         const unsigned short* __restrict__ tid, int segs, long long E, long long Eseg,
+                                                         const unsigned short* __restrict__ tid, int segs, int L, long long E, long long Eseg,
                                                          RansTables T, int* __restrict__ values, int* __restrict__ bad) {
   extern __shared__ unsigned char smem[];
   unsigned short* tring = reinterpret_cast<unsigned short*>(smem);                   // [2][kChunk * 64]
@@ -191,20 +193,20 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
   const int b = s / segs, sg = s - b * segs;
   const long long e0 = (long long)b * E + (long long)sg * Eseg;
   const long long e1 = std::min((long long)(b + 1) * E, e0 + Eseg);
-  const long long steps = e1 > e0 ? (e1 - e0 + 63) / 64 : 0;
+  const long long steps = e1 > e0 ? (e1 - e0 + L - 1) / L : 0;
   const long long nchunks = (steps + kChunk - 1) / kChunk;
   const unsigned short* w = payload + offsets[s];
   const long long len = offsets[s + 1] - offsets[s];
-  if (len < 128) {                                           // not even the 64 states: malformed
+  if (len < 2 * L) {                                         // not even the lane states: malformed
     if (lane == 0) atomicAdd(bad, 1);
     return;
   }
-  unsigned x = ((unsigned)w[2 * lane] << 16) | w[2 * lane + 1];
+  unsigned x = lane < L ? (((unsigned)w[2 * lane] << 16) | w[2 * lane + 1]) : (1u << 16);
   bool ok = true;
   const unsigned long long lt = (1ull << lane) - 1ull;
 
   // stream words: the ring holds [ptr, ptr + kWordRing) at the start of a chunk; a chunk eats at most kWordRing / 2
-  int ptr = 128, filled = 128, wfrom = 128, wto = 128;          // stream positions fit 32 bits (host: cap_words < 2^30)
+  int ptr = 2 * L, filled = 2 * L, wfrom = 2 * L, wto = 2 * L;  // stream positions fit 32 bits (host: cap_words < 2^30)
   const int len32 = (int)len;
   unsigned short WR[kWordRegs];
   auto word_fetch = [&](int target) {
@@ -228,8 +230,8 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
   auto tid_fetch = [&](long long k) {
 #pragma unroll
     for (int i = 0; i < kChunk; ++i) {
-      const long long e = e0 + (k * kChunk + i) * 64 + lane;
-      TR[i] = (k < nchunks && e < e1) ? tid[e] : kNoTable;
+      const long long e = e0 + (k * kChunk + i) * L + lane;
+      TR[i] = (k < nchunks && lane < L && e < e1) ? tid[e] : kNoTable;
     }
   };
   auto tid_spill = [&](int buf) {
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
     word_fetch(ptr + kWordRing);
     const unsigned short* tb = tring + (int)(k & 1) * kChunk * 64 + lane;
     const int cnt = (int)std::min<long long>(kChunk, steps - k * kChunk);
-    int* vout = values + e0 + k * kChunk * 64 + lane;
+    int* vout = values + e0 + k * kChunk * L + lane;
     int t1 = tb[0];
     uint2 m1 = meta[t1 == kNoTable ? 0 : t1];
     int t2 = cnt > 1 ? (int)tb[64] : (int)kNoTable;
@@ -299,7 +301,7 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
         }
         ptr += __popcll(emask);
       }
-      if (active) vout[i * 64] = v;
+      if (active) vout[i * L] = v;
     }
     word_spill();
     tid_spill((int)((k + 1) & 1));
@@ -358,12 +360,14 @@ extern "C" int64_t sntc_rans_cap_words(int64_t elems_per_image, int segments) {
   return 2 * segment_elems(elems_per_image, segments) + 128;
 }
 
+static bool lanes_ok(int lanes) { return lanes == 8 || lanes == 16 || lanes == 32 || lanes == 64; }
+
 extern "C" int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimages, int64_t elems_per_image,
-                                int segments, const uint16_t* cdf, const uint32_t* meta, int ntables, int total_entries,
+                                int segments, int lanes, const uint16_t* cdf, const uint32_t* meta, int ntables, int total_entries,
                                 int64_t cap_words, uint16_t* scratch, int32_t* len_words, void* stream) {
   if (!values || !table_ids || !cdf || !meta || !scratch || !len_words)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_encode: null argument");
-  if (nimages < 1 || elems_per_image < 1 || segments < 1 || ntables < 1 || total_entries < 1 ||
+  if (nimages < 1 || elems_per_image < 1 || segments < 1 || !lanes_ok(lanes) || ntables < 1 || total_entries < 1 ||
       cap_words < sntc_rans_cap_words(elems_per_image, segments) || cap_words > 0x3fffffff)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_encode: bad sizes (cap_words must be >= sntc_rans_cap_words())");
   const RansTables T{cdf, reinterpret_cast<const uint2*>(meta), ntables, total_entries};
@@ -372,10 +376,10 @@ extern "C" int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids
   hipStream_t s = (hipStream_t)stream;
   if (tb <= kRansLdsLimit) {
     SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_encode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(rans_encode_kernel<true>, dim3(ns), dim3(64), lds, s, values, table_ids, segments, (long long)elems_per_image,
+    hipLaunchKernelGGL(rans_encode_kernel<true>, dim3(ns), dim3(64), lds, s, values, table_ids, segments, lanes, (long long)elems_per_image,
                        eseg, T, (long long)cap_words, scratch, len_words);
   } else {
-    hipLaunchKernelGGL(rans_encode_kernel<false>, dim3(ns), dim3(64), kStagingBytes, s, values, table_ids, segments, (long long)elems_per_image,
+    hipLaunchKernelGGL(rans_encode_kernel<false>, dim3(ns), dim3(64), kStagingBytes, s, values, table_ids, segments, lanes, (long long)elems_per_image,
                        eseg, T, (long long)cap_words, scratch, len_words);
   }
   SNTC_HIP(hipGetLastError());
@@ -392,11 +396,11 @@ extern "C" int sntc_rans_compact(const uint16_t* scratch, int64_t cap_words, con
 }
 
 extern "C" int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
-                                int64_t elems_per_image, int segments, const uint16_t* cdf, const uint32_t* meta, int ntables,
-                                int total_entries, int32_t* values, int32_t* bad_streams, void* stream) {
+                                int64_t elems_per_image, int segments, int lanes, const uint16_t* cdf, const uint32_t* meta,
+                                int ntables, int total_entries, int32_t* values, int32_t* bad_streams, void* stream) {
   if (!payload || !offsets || !table_ids || !cdf || !meta || !values || !bad_streams)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: null argument");
-  if (nimages < 1 || elems_per_image < 1 || segments < 1 || ntables < 1 || total_entries < 1)
+  if (nimages < 1 || elems_per_image < 1 || segments < 1 || !lanes_ok(lanes) || ntables < 1 || total_entries < 1)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: bad sizes");
   const RansTables T{cdf, reinterpret_cast<const uint2*>(meta), ntables, total_entries};
   const long long eseg = segment_elems(elems_per_image, segments);
@@ -406,10 +410,10 @@ extern "C" int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets,
   if (tb <= kRansLdsLimit) {
     SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(rans_decode_kernel<true>, dim3(ns), dim3(64), lds, s, payload, reinterpret_cast<const long long*>(offsets),
-                       table_ids, segments, (long long)elems_per_image, eseg, T, values, bad_streams);
+                       table_ids, segments, lanes, (long long)elems_per_image, eseg, T, values, bad_streams);
   } else {
     hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(ns), dim3(64), kStagingBytes, s, payload, reinterpret_cast<const long long*>(offsets),
-                       table_ids, segments, (long long)elems_per_image, eseg, T, values, bad_streams);
+                       table_ids, segments, lanes, (long long)elems_per_image, eseg, T, values, bad_streams);
   }
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;

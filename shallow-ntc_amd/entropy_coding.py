@@ -10,8 +10,9 @@ Tables (host, float64, 16-bit precision: frequencies sum to 65536, every symbol 
     on |v| <= L_k = the symbols with pmf >= 2^-17; rarer values are escaped.
   * z: one table per channel from the deep-factorized prior, pmf(v) = sigmoid(L(v+.5)) - sigmoid(L(v-.5)).
 Wire format (little endian): b"SNTC" u16 version | u16 n | u32 H | u32 W | u16 C | u16 hz | u16 wz | u16 h | u16 w |
-  u16 segments_z | u16 segments_y | u32 len_words[n * segments_z] | u32 len_words[n * segments_y] | z payload | y payload;
-  a stream (one per image and segment) = 64 lane states + the interleaved 16-bit words (csrc/rans.hip).
+  u16 segments_z | u16 segments_y | u8 lanes_z | u8 lanes_y | u32 len_words[n * segments_z] | u32 len_words[n * segments_y] |
+  z payload | y payload; a stream (one per image and segment) = the lane states (8 .. 64 of them, fewer on short streams)
+  + the interleaved 16-bit words (csrc/rans.hip).
 The decoder rebuilds mu / scale indexes with the same hyper-synthesis kernels (deterministic, batch-invariant), so
 encoder and decoder agree bit for bit.
 """
@@ -30,7 +31,7 @@ from . import ops
 PRECISION = 16
 TOTAL = 1 << PRECISION
 MAGIC = b"SNTC"
-VERSION = 1
+VERSION = 2
 SCALE_MIN, SCALE_MAX, NUM_SCALES = 0.11, 256.0, 64
 SCALE_FACTOR = (math.log(SCALE_MAX) - math.log(SCALE_MIN)) / (NUM_SCALES - 1.0)
 
@@ -132,18 +133,27 @@ def _segments(elems, segments=None):
     return max(1, min(int(segments), -(-elems // 64)))
 
 
-def rans_encode(values, table_ids, tables: DeviceTables, segments=None):
+def _lanes(elems_per_stream, lanes=None):
+    """Lane states flushed per stream (4 bytes each): all 64 on long streams, fewer on short ones (the hyper-latents of a
+    small image would otherwise pay 256 bytes of states for a few hundred bytes of payload)."""
+    if lanes is not None:
+        return int(lanes)
+    return 64 if elems_per_stream >= 16384 else 32 if elems_per_stream >= 6144 else 16 if elems_per_stream >= 2048 else 8
+
+
+def rans_encode(values, table_ids, tables: DeviceTables, segments=None, lanes=None):
     """values int32 [n, ...], table_ids uint16 (int16 storage) same shape -> (payload int16-storage words on the
     device, len_words int64[n * segments])."""
     n = values.shape[0]
     E = values.numel() // n
     segments = _segments(E, segments)
+    lanes = _lanes(-(-E // segments), lanes)
     cap = int(capi.load().sntc_rans_cap_words(E, segments))
     dev = values.device
     ns = n * segments
     scratch = torch.empty((ns, cap), dtype=torch.int16, device=dev)
     lens = torch.empty((ns,), dtype=torch.int32, device=dev)
-    capi.call("sntc_rans_encode", _p(values), _p(table_ids), n, E, segments, _p(tables.cdf), _p(tables.meta), tables.ntables,
+    capi.call("sntc_rans_encode", _p(values), _p(table_ids), n, E, segments, lanes, _p(tables.cdf), _p(tables.meta), tables.ntables,
               tables.total, cap, _p(scratch), _p(lens), ops._stream())
     lens_h = lens.cpu().numpy().astype(np.int64)
     offsets = np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)
@@ -153,18 +163,19 @@ def rans_encode(values, table_ids, tables: DeviceTables, segments=None):
     return payload, lens_h
 
 
-def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segments=None):
+def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segments=None, lanes=None):
     """-> int32 values of ``shape`` [n, ...]; raises on a malformed stream."""
     n = shape[0]
     E = int(np.prod(shape)) // n
     segments = _segments(E, segments)
+    lanes = _lanes(-(-E // segments), lanes)
     if len(lens_h) != n * segments:
         raise capi.SntcError(capi.ERR_BAD_SHAPE, "stream count does not match the image / segment counts")
     dev = payload.device
     offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)).to(dev)
     values = torch.empty(tuple(shape), dtype=torch.int32, device=dev)
     bad = torch.zeros((1,), dtype=torch.int32, device=dev)
-    capi.call("sntc_rans_decode", _p(payload), _p(offsets), _p(table_ids), n, E, segments, _p(tables.cdf), _p(tables.meta),
+    capi.call("sntc_rans_decode", _p(payload), _p(offsets), _p(table_ids), n, E, segments, lanes, _p(tables.cdf), _p(tables.meta),
               tables.ntables, tables.total, _p(values), _p(bad), ops._stream())
     nbad = int(bad.item())
     if nbad:
@@ -201,7 +212,7 @@ def int_to_float(x):
 class Codec:
     """compress / decompress for a mean-scale hyperprior ``Model``."""
 
-    HEAD = "<HHIIHHHHHHH"
+    HEAD = "<HHIIHHHHHHHBB"
 
     def __init__(self, model):
         self.m = model
@@ -223,10 +234,11 @@ class Codec:
             hyper = m._hyper_synthesis(z_hat)
             _, _, sym = ops.entropy_scale_normal(y, hyper, want_symbols=True)
             sz, sy = _segments(zi[0].numel()), _segments(sym[0].numel())
-            zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz)
-            yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables, sy)
+            lz, ly = _lanes(-(-zi[0].numel() // sz)), _lanes(-(-sym[0].numel() // sy))
+            zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz, lz)
+            yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables, sy, ly)
             zb, yb = zp.cpu().numpy().tobytes(), yp.cpu().numpy().tobytes()
-        head = MAGIC + struct.pack(self.HEAD, VERSION, n, H, W, y.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2], sz, sy)
+        head = MAGIC + struct.pack(self.HEAD, VERSION, n, H, W, y.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2], sz, sy, lz, ly)
         return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
 
     def decompress(self, blob: bytes):
@@ -236,7 +248,7 @@ class Codec:
         pos = 4 + struct.calcsize(self.HEAD)
         if len(blob) < pos:
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
-        ver, n, H, W, c, hz, wz, h, w, sz, sy = struct.unpack_from(self.HEAD, blob, 4)
+        ver, n, H, W, c, hz, wz, h, w, sz, sy, lz, ly = struct.unpack_from(self.HEAD, blob, 4)
         if ver != VERSION:
             raise capi.SntcError(capi.ERR_UNSUPPORTED, f"bitstream version {ver}")
         nz, ny = n * sz, n * sy
@@ -252,8 +264,8 @@ class Codec:
         with torch.cuda.device(dev):
             zp = torch.from_numpy(np.frombuffer(blob, "<i2", zw, pos).copy()).to(dev)
             yp = torch.from_numpy(np.frombuffer(blob, "<i2", yw, pos + 2 * zw).copy()).to(dev)
-            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, c), dev), (n, hz, wz, c), self.z_tables, sz)
+            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, c), dev), (n, hz, wz, c), self.z_tables, sz, lz)
             hyper = m._hyper_synthesis(int_to_float(zi))
-            sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy)
+            sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy, ly)
             y_hat = ops.dequant_scale_normal(sym, hyper)
             return ops.to_pixels(m._synthesis(y_hat), H, W)

@@ -33,9 +33,9 @@ def test_stream_words_match_python_restatement(dev):
     vals[1, 0, 0] = -31000
     vals[1, 100, 4] = 32767
     E = P * c                               # 505 elements: 8 steps of 64 lanes, the last one ragged
-    for segs in (1, 2, 3):
+    for segs, lanes in ((1, 64), (2, 32), (3, 8), (1, 16)):
         eseg = -(-(-(-E // segs)) // 64) * 64
-        payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt, segs)
+        payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt, segs, lanes)
         words = payload.cpu().numpy().view(np.uint16)
         off = np.concatenate([[0], np.cumsum(lens)])
         assert len(lens) == n * segs
@@ -44,16 +44,16 @@ def test_stream_words_match_python_restatement(dev):
                 s = b * segs + g
                 sl = slice(g * eseg, min(E, (g + 1) * eseg))
                 v, t = vals[b].ravel()[sl], tids[b].ravel()[sl]
-                ref = rans_np.encode_stream(v, t, tabs)
+                ref = rans_np.encode_stream(v, t, tabs, lanes)
                 got = words[off[s]:off[s + 1]].tolist()
-                assert got == ref, (segs, b, g)
-                assert rans_np.decode_stream(got, t, tabs) == v.tolist()
-        back = ec.rans_decode(payload, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt, segs)
+                assert got == ref, (segs, lanes, b, g)
+                assert rans_np.decode_stream(got, t, tabs, lanes) == v.tolist()
+        back = ec.rans_decode(payload, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt, segs, lanes)
         np.testing.assert_array_equal(back.cpu().numpy(), vals)
     payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt)
     # corruption: flip one payload word -> decode must refuse
     bad = payload.clone()
-    bad[300] ^= 0x0100
+    bad[60] ^= 0x0100
     from shallow_ntc_amd import _capi
     with pytest.raises(_capi.SntcError, match="corrupt"):
         ec.rans_decode(bad, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt)
@@ -101,9 +101,10 @@ def test_gpu_words_equal_the_golden_stream(dev):
     vals = torch.from_numpy(g["values"]).to(dev).view(2, -1, 1)
     tids = torch.from_numpy(g["table_ids"]).to(dev).view(2, -1, 1)
     for segs in (1, 3):
-        payload, lens = ec.rans_encode(vals, tids, dt, segs)
+        lanes = int(g[f"lanes_s{segs}"])
+        payload, lens = ec.rans_encode(vals, tids, dt, segs, lanes)
         assert lens.tolist() == g[f"lens_s{segs}"].tolist()
         np.testing.assert_array_equal(payload.cpu().numpy().view(np.uint16), g[f"words_s{segs}"])
         gold = torch.from_numpy(g[f"words_s{segs}"].view(np.int16)).to(dev)
-        back = ec.rans_decode(gold, g[f"lens_s{segs}"], tids, tuple(vals.shape), dt, segs)
+        back = ec.rans_decode(gold, g[f"lens_s{segs}"], tids, tuple(vals.shape), dt, segs, lanes)
         assert torch.equal(back, vals)

@@ -193,11 +193,12 @@ def test_bitstream_golden_and_tables():
     for segs in (1, 3):
         eseg = -(-(-(-E // segs)) // 64) * 64
         words, off = g[f"words_s{segs}"].tolist(), 0
+        lanes = int(g[f"lanes_s{segs}"])
         for i, ln in enumerate(g[f"lens_s{segs}"].tolist()):
             b, s = divmod(i, segs)
             sl = slice(s * eseg, min(E, (s + 1) * eseg))
-            assert rans_np.encode_stream(vals[b, sl], tids[b, sl], tabs) == words[off:off + ln]
-            assert rans_np.decode_stream(words[off:off + ln], tids[b, sl], tabs) == vals[b, sl].tolist()
+            assert rans_np.encode_stream(vals[b, sl], tids[b, sl], tabs, lanes) == words[off:off + ln]
+            assert rans_np.decode_stream(words[off:off + ln], tids[b, sl], tabs, lanes) == vals[b, sl].tolist()
             off += ln
     import __graft_entry__ as graft
     graft.load_package()
