@@ -24,10 +24,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import __graft_entry__ as graft  # noqa: E402  (stdlib only: the launcher parent must not touch the GPU)
 
-import __graft_entry__ as graft  # noqa: E402
+np = None      # numpy / torch are imported by main() in the worker processes only: the parent of a self-launched
+torch = None   # N-rank run (launch_ranks) never initialises HIP and never imports them
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 KODAK_SHAPES = [(512, 768)] * 18 + [(768, 512)] * 6
@@ -47,6 +47,74 @@ def synthetic_batch(n, h, w, seed, device):
     img = img + 4.0 * torch.randn(img.shape, device=device, generator=g)
     img = torch.clamp(torch.round(img), 0, 255)
     return (img / 255.0 - 0.5).contiguous()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` outside torchrun: start N child processes of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set),
+    relay rank 0's JSON line, and return non-zero if any rank does.  The parent makes no HIP call and replaces no
+    process image: children are ordinary subprocesses, stopped by their exact PIDs if a sibling fails."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    rc = 0
+    pending = set(range(n))
+    out0 = None
+    while pending:
+        for r in sorted(pending):
+            p = procs[r]
+            if r == 0 and out0 is None:
+                try:
+                    out0, _ = p.communicate(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+            elif p.poll() is None:
+                continue
+            pending.discard(r)
+            if p.returncode != 0 and rc == 0:
+                rc = p.returncode
+                print(f"bench.py: rank {r} exited with {p.returncode}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    return rc if rc >= 0 else 1
+
+
+def launch_check(args):
+    """--launch-check: rendezvous, barrier, one all-gather, one max-reduce -- the collectives of the timed path
+    without any kernel (works on a CPU-only host with gloo).  Prints a line that is visibly NOT a measurement."""
+    from shallow_ntc_amd import distributed as D
+    rank, local_rank, world = D.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("SNTC_LAUNCH_CHECK_FAIL_RANK") == str(rank):     # test hook: a failing rank must fail the job
+        sys.exit(3)
+    D.barrier()
+    info = D.describe_world(None)
+    table = D.gather_rows([[float(rank), 2.0 * rank]], [rank], world)
+    t = D.max_over_ranks(float(rank))
+    D.barrier()
+    if rank == 0:
+        assert t == world - 1 and table[:, 0].tolist() == list(range(world))
+        print(json.dumps(dict(metric="launch-check (no kernels, not a measurement)", value=None, n_gpus=world,
+                              dry_run=True, rccl=info)), flush=True)
+    D.shutdown()
 
 
 def main():
@@ -70,9 +138,19 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
                          "the host already runs ahead of the GPU)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous the ranks and run the path's collectives (no kernels); prints a dry-run line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # not under torchrun: be the launcher (no GPU call before this)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    global np, torch
+    import numpy as np
+    import torch
     graft.load_package()
+    if args.launch_check:
+        return launch_check(args)
     from shallow_ntc_amd import distributed as D
     from shallow_ntc_amd import ops
     from shallow_ntc_amd.mshyper import configs
@@ -85,6 +163,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    world_info = D.describe_world(dev)                # one all_gather_object: backend, world, every rank's device
 
     cfg = configs.two_layer_syn(rd_lambda=0.005)
     model = Model(device=dev, **cfg)
@@ -192,10 +271,23 @@ def main():
         D.barrier()
         return D.max_over_ranks(time.perf_counter() - t0, device=dev)
 
+    def region_frac(fn, seconds_per_step):
+        """Algorithmic conv FLOPs of one pass of ``fn`` (sntc_conv_flops of every launch, recorded by ops.PROFILE in an
+        untimed extra pass) / the region's measured time / the fp32-MFMA peak -- the whole region, stream kernels included."""
+        ops.PROFILE = []
+        fn()
+        torch.cuda.synchronize()
+        flops = sum(e["flops"] for e in ops.PROFILE)
+        ops.PROFILE = None
+        tf = flops / seconds_per_step / 1e12
+        return dict(gflop_per_step=round(flops / 1e9, 2), tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4))
+
     t_dec = timed(decode_step, args.steps, args.warmup)
     ms_per_step = 1e3 * t_dec / args.steps
     value = world * pixels_per_step * args.steps / t_dec / 1e6
-    e2e_value, table, regions = None, None, None
+    e2e_value, table = None, None
+    regions = dict(decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2),
+                               roofline=region_frac(decode_eager, t_dec / args.steps)))
     if not args.decode_only:
         e2e_steps = max(2, args.steps // 4)
         t_e2e = timed(e2e_step, e2e_steps, 1)
@@ -221,12 +313,17 @@ def main():
         train_x = synthetic_batch(8, 256, 256, 777 + rank, dev)
         t_train = timed(lambda: trainer.train_step(train_x), e2e_steps, 2)
         del trainer, train_model
+        enc_fn = lambda: on_streams(lambda b: model.encode(b[1]))
         regions = dict(
-            decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2)),
-            encode=dict(ms_per_step=round(1e3 * t_enc / e2e_steps, 3), mpixels_per_s=mpx(pixels_per_step, t_enc)),
-            encode_decode_score=dict(ms_per_step=round(1e3 * t_e2e / e2e_steps, 3), mpixels_per_s=round(e2e_value, 2)),
+            decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2),
+                        roofline=region_frac(decode_eager, t_dec / args.steps)),
+            encode=dict(ms_per_step=round(1e3 * t_enc / e2e_steps, 3), mpixels_per_s=mpx(pixels_per_step, t_enc),
+                        roofline=region_frac(enc_fn, t_enc / e2e_steps)),
+            encode_decode_score=dict(ms_per_step=round(1e3 * t_e2e / e2e_steps, 3), mpixels_per_s=round(e2e_value, 2),
+                                     roofline=region_frac(e2e_step, t_e2e / e2e_steps)),
             w1_encode_decode_score=dict(workload="64 x 256x256 per GPU", ms_per_step=round(1e3 * t_w1 / e2e_steps, 3),
-                                        mpixels_per_s=mpx(64 * 256 * 256, t_w1)),
+                                        mpixels_per_s=mpx(64 * 256 * 256, t_w1),
+                                        roofline=region_frac(w1_step, t_w1 / e2e_steps)),
             train_step=dict(workload="8 x 256x256 per GPU, unoise, Adam + global_clipnorm, gradient all-reduce when N > 1",
                             ms_per_step=round(1e3 * t_train / e2e_steps, 3),
                             images_per_s=round(world * 8 * e2e_steps / t_train, 1), mpixels_per_s=mpx(8 * 256 * 256, t_train)))
@@ -342,11 +439,10 @@ def main():
                         (f"eager, {min(nstreams, len(codes))} concurrent streams (one per batch)" if nstreams > 1 and len(codes) > 1 else "eager"),
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))"),
             encode_decode_mpixels_per_s=None if e2e_value is None else round(e2e_value, 2),
-            regions=regions, rd=rd, roofline=roofline, cpu_baseline=cpu_baseline,
+            regions=regions, rd=rd, roofline=roofline, cpu_baseline=cpu_baseline, rccl=world_info,
         )
         print(json.dumps(line), flush=True)
-    if torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -110,8 +110,9 @@ int sntc_conv_forward(const sntc_conv_plan* plan, const float* x, int n, int h, 
  * kernel adds in a fixed order; the split depends on the layer and the image shape only, so results are
  * bit-identical for any batch size. */
 int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int w);
-/* Tile-selection override for experiments: 0 = heuristic. Returns previous value. */
-int sntc_conv_set_tile_override(int variant);
+/* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
+ * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */
+int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64) the heuristic picks for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);

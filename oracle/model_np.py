@@ -121,18 +121,32 @@ class Model:
         return p
 
     # ---- inference path (mshyper/models.py:212-232; factorized/models.py:70-87) ---------
-    def infer_latents(self, params, x):
+    def _run(self, transform, params, prefix, x, be):
+        """One transform, on the float64 NumPy ops (be None) or on a float64 backend module that offers
+        ``as_params`` (oracle/train_ref: library convolutions, for full-size images); NHWC float64 in and out."""
+        sub = T.sub_params(params, prefix)
+        if be is None:
+            return transform(sub, x)
+        import torch
+        with torch.no_grad():
+            return be.to_nhwc(transform(be.as_params(sub), x, be=be))
+
+    def infer_latents(self, params, x, be=None):
         xp = ops.pad_images(np.asarray(x, np.float64), self.downsample_factor)
-        y = self.analysis(T.sub_params(params, "analysis/"), xp)
+        y = self._run(self.analysis, params, "analysis/", xp, be)
         if self.factorized:
             return (y,)
-        z = self.hyper_analysis(T.sub_params(params, "hyper_analysis/"), y)
+        z = self._run(self.hyper_analysis, params, "hyper_analysis/", y, be)
         return (z, y)
 
     # ---- generative path + losses, eval branch (mshyper/models.py:234-359) ---------------
-    def frame_loss(self, params, x, latents, sga=None):
+    def frame_loss(self, params, x, latents, sga=None, be=None, force_symbols=None):
         """sga=None: training=False hard rounding.  sga=dict(tau, gumbel_z, gumbel_y): the explicit-
-        sampling training branch used by itinf_train_step (models.py:260-268,285-291)."""
+        sampling training branch used by itinf_train_step (models.py:260-268,285-291).
+        force_symbols (tests only): integer symbols to use INSTEAD of round(y - mu), so that the rate and the
+        reconstruction of another implementation's symbols can be checked separately from the (counted) positions
+        where its float32 y - mu fell on the other side of a rounding boundary; ``tie_distance`` then reports
+        | |frac(y - mu)| - 0.5 | of the oracle at every position."""
         x = np.asarray(x, np.float64)
         ms, bs, fs = _prior_lists(params)
         ln2 = math.log(2.0)
@@ -154,11 +168,18 @@ class Model:
             else:
                 z_hat = ops.sga_round(z_loc, sga["tau"], sga["gumbel_z"], offset=0.0)
                 bits_z = ops.deep_factorized_logprob(z_hat, ms, bs, fs).sum(axis=(1, 2, 3)) / -ln2
-            h = self.hyper_synthesis(T.sub_params(params, "hyper_synthesis/"), z_hat)
+            h = self._run(self.hyper_synthesis, params, "hyper_synthesis/", z_hat, be)
             c = h.shape[-1] // 2
             mu, raw = h[..., :c], h[..., c:]
             indexes = np.exp(raw)                       # models.py:274-276 (sigma used as scale INDEX)
-            if sga is None:
+            if sga is None and force_symbols is not None:
+                sym = np.asarray(force_symbols, np.float64)
+                sigma = ops.scale_fn(np.clip(indexes, 0.0, ops.NUM_SCALES - 1.0))
+                y_hat = sym + mu
+                bits_y = ops.noisy_normal_logprob(sym, sigma).sum(axis=(1, 2, 3)) / -ln2
+                d = np.asarray(y_loc, np.float64) - mu
+                out["symbols_y"], out["tie_distance"] = sym, np.abs(np.abs(d - np.floor(d) - 0.5))
+            elif sga is None:
                 y_hat, bits_y, sym = ops.scale_indexed_normal(y_loc, mu, indexes)
                 out["symbols_y"] = sym
             else:
@@ -166,7 +187,7 @@ class Model:
                 sigma = ops.scale_fn(np.clip(indexes, 0.0, ops.NUM_SCALES - 1.0))
                 bits_y = ops.noisy_normal_logprob(y_hat - mu, sigma).sum(axis=(1, 2, 3)) / -ln2
             out.update(z_hat=z_hat, mu=mu, indexes=indexes)
-        recon = self.synthesis(T.sub_params(params, "synthesis/"), y_hat)
+        recon = self._run(self.synthesis, params, "synthesis/", y_hat, be)
         recon = ops.unpad_images(recon, x.shape)
         npix = float(x.shape[1] * x.shape[2])
         bpp = (0.0 if bits_z is None else bits_z.mean() / npix) + bits_y.mean() / npix
@@ -180,8 +201,8 @@ class Model:
                    rd_loss=bpp + self.rd_lambda * mse)
         return out
 
-    def end_to_end(self, params, x):
-        return self.frame_loss(params, x, self.infer_latents(params, x))
+    def end_to_end(self, params, x, be=None):
+        return self.frame_loss(params, x, self.infer_latents(params, x, be=be), be=be)
 
     def evaluate(self, params, images):
         """models.py:415-433: one image at a time."""

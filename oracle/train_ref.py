@@ -41,6 +41,12 @@ def to_nhwc(x):
     return x.detach().permute(0, 2, 3, 1).contiguous().numpy()
 
 
+def as_params(params):
+    """{name: array} -> {name: float64 tensor} (no gradient): lets the eval forward of model_np run its transforms on
+    this backend (library convolutions in float64) at sizes where the NumPy tap loops would take minutes."""
+    return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)) for k, v in params.items()}
+
+
 def append_ones(x):
     return torch.cat([x, torch.ones_like(x[:, :1])], dim=1)
 

@@ -61,14 +61,14 @@ struct sntc_conv_plan {
     unsigned* cols = nullptr;
   } g[kMaxGroups];
   float* bias = nullptr;
+  int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
 };
 
-static thread_local int g_tile_override = 0;
-
-extern "C" int sntc_conv_set_tile_override(int variant) {
-  int prev = g_tile_override;
-  g_tile_override = variant;
-  return prev;
+extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
+  if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_tile: null plan");
+  if (variant < 0 || variant > kNumVariants) return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_tile: unknown tile variant");
+  p->tile = variant;
+  return SNTC_OK;
 }
 
 extern "C" void sntc_conv_plan_destroy(sntc_conv_plan* p) {
@@ -275,7 +275,7 @@ extern "C" int64_t sntc_conv_flops(const sntc_conv_plan* p, int n, int h, int w)
 }
 
 static int pick_variant(const sntc_conv_plan* p, int64_t M) {
-  if (g_tile_override >= 1 && g_tile_override <= kNumVariants) return g_tile_override;
+  if (p->tile >= 1 && p->tile <= kNumVariants) return p->tile;
   double best = 1e300;
   int bestv = 4;
   for (int v = 1; v <= kNumVariants; ++v) {

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
 
   for (int ks = 0; ks < nsteps; ++ks) {
     const bool more = ks + 1 < nsteps;
-    if (more && !(a.dbg & 1)) load_regs();
+    if (more && !SNTC_DBG(a, 1)) load_regs();
     const float* Ab = As + (ks & 1) * BM * 32 + (wm * TM * 32 + l31) * 32;
     const float* Bb = Bs + (ks & 1) * BN * 32 + (wn * TN * 32 + l31) * 32;
 #pragma unroll
@@ -245,10 +245,10 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    if (more && !(a.dbg & 2)) write_lds((ks + 1) & 1);
-    if (!(a.dbg & 4)) __syncthreads();
+    if (more && !SNTC_DBG(a, 2)) write_lds((ks + 1) & 1);
+    if (!SNTC_DBG(a, 4)) __syncthreads();
   }
-  if (a.dbg & 4) __syncthreads();
+  if (SNTC_DBG(a, 4)) __syncthreads();
 
   // ---------------- epilogue ----------------
   // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private 8-KB LDS
@@ -482,7 +482,9 @@ int gg_init() {
 
 int gg_launch(int variant, bool vec, const GGArgs& args_in, int nblocks, hipStream_t stream) {
   GGArgs args = args_in;
+#ifdef SNTC_DIAG
   if (const char* e = getenv("SNTC_GG_DBG")) args.dbg = atoi(e);
+#endif
   const size_t lds = lds_bytes(variant);
   const bool pro = args.pro != SNTC_PRO_NONE;
   switch (variant) {

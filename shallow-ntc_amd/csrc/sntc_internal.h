@@ -27,6 +27,15 @@ int hip_fail(hipError_t e, const char* what);
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxGroups = 4;
 
+// Diagnostic switches (skip global loads / LDS writes / barriers of a K loop to see what it waits on) exist only in
+// builds made with -DSNTC_DIAG (make DIAG=1); in the shipped library the tests fold to `false` at compile time and no
+// environment variable is read on the launch path.
+#ifdef SNTC_DIAG
+#define SNTC_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define SNTC_DBG(a, bit) false
+#endif
+
 struct GGGroup {
   const float* wp;    // [NcolPad][K], K contiguous (K padded to a multiple of 32 with zeros)
   const int* taps;    // [T]   (ty << 16) | tx
@@ -55,7 +64,7 @@ struct GGArgs {
   int ntm;
   int ksplit;          // >= 1: number of K ranges (blocks per tile)
   float* slab;         // split-K partial sums (workspace) or nullptr
-  int dbg;             // diagnostic switches (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers
+  int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers
   int ngroups;
   GGGroup g[kMaxGroups];
 };

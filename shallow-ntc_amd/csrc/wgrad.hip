@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
   __syncthreads();
   for (long long pb = p0; pb < p1; pb += kBK) {
     const bool more = pb + kBK < p1;
-    if (more && !(a.dbg & 1)) gload(pb + kBK);
+    if (more && !SNTC_DBG(a, 1)) gload(pb + kBK);
 #pragma unroll
     for (int kk = 0; kk < kBK / 2; ++kk) {
       float fa[TM], fb[TN];
@@ -188,8 +188,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WGArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (more && !(a.dbg & 2)) lstore(buf ^ 1);
-    if (!(a.dbg & 4)) __syncthreads();
+    if (more && !SNTC_DBG(a, 2)) lstore(buf ^ 1);
+    if (!SNTC_DBG(a, 4)) __syncthreads();
     buf ^= 1;
   }
 
@@ -363,7 +363,9 @@ extern "C" int sntc_conv_wgrad(int kind, int kh, int kw, int stride, int cin, in
     return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_wgrad: tensors of 2^31 elements or more: split the batch");
   a.slab = a.ksplit > 1 ? static_cast<float*>(workspace) : dw;      // one slab: the kernel writes dW itself
   a.accumulate = accumulate;
+#ifdef SNTC_DIAG
   if (const char* e = getenv("SNTC_WG_DBG")) a.dbg = atoi(e);
+#endif
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((long long)a.ntm * a.ntn * a.ksplit));
   const bool vec = g.Cs % 4 == 0;

@@ -36,6 +36,43 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def describe_world(device=None):
+    """Evidence that the collective backend saw every rank: {backend, world, rccl_version, devices: one entry per
+    rank (index, name, gcnArchName, PCI bus id), collected with ONE all_gather_object}.  ``device`` None = CPU process."""
+    rank, local_rank, world = env_world()
+    me = dict(rank=rank, host_pid=os.getpid())
+    if device is not None and torch.cuda.is_available():
+        props = torch.cuda.get_device_properties(device)
+        me.update(device=torch.cuda.current_device(), name=props.name, arch=getattr(props, "gcnArchName", None),
+                  pci_bus_id=getattr(props, "pci_bus_id", None), cus=props.multi_processor_count)
+    else:
+        me.update(device="cpu")
+    backend, version = None, None
+    devices = [me]
+    if dist.is_initialized():
+        backend = dist.get_backend()
+        devices = [None] * dist.get_world_size()
+        dist.all_gather_object(devices, me)
+        if backend == "nccl":
+            try:
+                version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                version = None
+    return dict(backend=backend if backend != "nccl" else "nccl (RCCL on ROCm)", world=world, rccl_version=version,
+                devices=devices)
+
+
+def deal_units(num_units, rank, world):
+    """Independent work units (images, (lambda, image) pairs, SGA batches) -> the ids this rank owns: unit u goes to
+    rank u mod world.  No unit is dropped or duplicated for any (num_units, world)."""
+    return list(range(rank, num_units, world))
+
+
 def shard_indices(num_items, rank, world):
     """Image i goes to rank i mod world (round-robin keeps the Kodak orientations balanced)."""
     return list(range(rank, num_items, world))

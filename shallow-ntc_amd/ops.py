@@ -20,6 +20,7 @@ KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SI
 
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
+FORCE_TILE = 0   # tools/profile_layers.py --variant: every plan created afterwards is pinned to this tile variant
 
 
 def _stream():
@@ -64,6 +65,8 @@ class ConvPlan:
         self._h = C.c_void_p()
         capi.call("sntc_conv_plan_create", C.byref(desc), _ptr(w), _ptr(b), _stream(), C.byref(self._h))
         torch.cuda.current_stream().synchronize()   # packing reads w/b; they may be freed after this
+        if FORCE_TILE:
+            self.set_tile(FORCE_TILE)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -77,6 +80,10 @@ class ConvPlan:
     def update(self, weight, bias=None):
         """Re-pack from new device weights (training step); the arrays are read asynchronously on the current stream."""
         capi.call("sntc_conv_plan_update", self._h, _ptr(weight), _ptr(bias), _stream())
+
+    def set_tile(self, variant):
+        """Force this plan's gather-GEMM tile variant (0 = heuristic); profiling / tests."""
+        capi.call("sntc_conv_plan_set_tile", self._h, int(variant))
 
     def out_hw(self, h, w):
         ho, wo = C.c_int(), C.c_int()

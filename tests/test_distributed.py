@@ -114,3 +114,31 @@ def test_two_rank_bucketed_gradient_all_reduce():
             np.testing.assert_array_equal(val, want)
         else:
             assert "never launched" in val
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` outside torchrun spawns its own ranks (the parent never touches the GPU), the ranks
+    rendezvous over gloo, run the path's collectives, and rank 0's line comes back through the parent with the world in it."""
+    import json
+    r = _run_bench(dict(SNTC_DIST_BACKEND="gloo"), "--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert line["rccl"]["backend"] == "gloo" and line["rccl"]["world"] == 2
+    assert sorted(d["rank"] for d in line["rccl"]["devices"]) == [0, 1]
+    assert len({d["host_pid"] for d in line["rccl"]["devices"]}) == 2          # two processes, not one
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    r = _run_bench(dict(SNTC_DIST_BACKEND="gloo", SNTC_LAUNCH_CHECK_FAIL_RANK="1"), "--gpus", "2", "--launch-check")
+    assert r.returncode != 0
+    assert "rank 1 exited" in r.stderr

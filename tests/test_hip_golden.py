@@ -63,12 +63,20 @@ def test_model_fixture(dev):
     lat = model.infer_latent_rvs(x)
     assert rel(lat.uq[1].loc.cpu().numpy(), g["y"]) < 5e-5 and rel(lat.uq[0].loc.cpu().numpy(), g["z"]) < 5e-5
     r = model._rate_and_reconstruction(lat, want_symbols=True)
-    flips = int((r["symbols"].cpu().numpy() != g["symbols_y"]).sum())
+    sym = r["symbols"].cpu().numpy()
+    flip = sym != g["symbols_y"]
     np.testing.assert_array_equal(r["z_hat"].cpu().numpy(), g["z_hat"])
-    assert flips <= 1
+    assert int(flip.sum()) <= 1
     _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
     m = metrics.scalars_float
-    tol_bpp, tol_psnr = (1e-4, 1e-3) if flips == 0 else (2e-3, 2e-2)     # BASELINE.json tolerances
-    assert abs(m["bpp"] - float(g["bpp"])) <= tol_bpp
-    assert abs(m["psnr"] - float(g["psnr"])) <= tol_psnr
+    if not flip.any():                       # the frozen numbers themselves
+        want_bpp, want_psnr = float(g["bpp"]), float(g["psnr"])
+    else:                                    # a symbol within 1e-4 of a rounding boundary went the other way (3500-pixel
+        # image: one symbol is ~5e-4 bpp): the oracle's rate / distortion AT THE GPU'S INTEGERS, from the frozen latents
+        from oracle import model_np
+        ref = model_np.Model(tc, rd_lambda=float(g["rd_lambda"])).frame_loss(w, x, (g["z"], g["y"]), force_symbols=sym)
+        assert (ref["tie_distance"][flip] < 1e-4).all()
+        want_bpp, want_psnr = ref["bpp"], ref["psnr"]
+    assert abs(m["bpp"] - want_bpp) <= 1e-4            # BASELINE.json tolerances, both branches
+    assert abs(m["psnr"] - want_psnr) <= 1e-3
     assert abs(m["rd_loss"] - (m["bpp"] + 0.02 * m["mse"])) < 1e-5

@@ -113,25 +113,35 @@ def test_mshyper_model_parity(synth, dev):
     # oracle on the HIP latents (float32 -> float64): isolates the generative path
     ref = ref_model.frame_loss(w, x, (z, y))
     r = model._rate_and_reconstruction(lat, want_symbols=True)
-    flips = int((r["symbols"].cpu().numpy() != ref["symbols_y"]).sum())
-    assert flips <= 2, flips
+    sym = r["symbols"].cpu().numpy()
+    flip = sym != ref["symbols_y"]
+    assert int(flip.sum()) <= 2, int(flip.sum())
     np.testing.assert_array_equal(r["z_hat"].cpu().numpy(), ref["z_hat"])
     per_image = model.evaluate_batched(x)
     _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
     m = metrics.scalars_float
-    if flips == 0:
-        assert abs(m["bpp"] - ref["bpp"]) <= 1e-4                    # BASELINE tolerance
-        assert abs(m["psnr"] - ref["psnr"]) <= 1e-3
-    assert abs(m["bpp"] - ref["bpp"]) <= 1e-3 and abs(m["psnr"] - ref["psnr"]) <= 1e-2
+    # Rounding and arithmetic are checked separately, each without an escape: (1) the integer symbols differ from the
+    # float64 oracle's only where the oracle's own y - mu sits within 1e-4 of a rounding boundary (at most 2 of 24,576
+    # here: one such symbol is 1-3 bits = 1e-4 bpp on an image this small; the BASELINE tolerance on Kodak-size images
+    # is asserted end to end, unconditionally, in test_hip_e2e_parity.py); (2) GIVEN the same integers, rate and
+    # distortion meet the BASELINE tolerance.
+    ref_s = ref_model.frame_loss(w, x, (z, y), force_symbols=sym)
+    assert (ref_s["tie_distance"][flip] < 1e-4).all()
+    assert abs(m["bpp"] - ref_s["bpp"]) <= 1e-4                      # BASELINE tolerance
+    assert abs(m["psnr"] - ref_s["psnr"]) <= 1e-3
     assert abs(m["rd_loss"] - (m["bpp"] + 0.02 * m["mse"])) < 1e-5   # results/readme.md identity
     assert abs(np.mean([d["psnr"] for d in per_image]) - m["psnr"]) < 1e-4
     # eval JSON schema (common/eval_lib.py:92-102 rows carry msssim): 100 x 150 < 160 -> single-scale SSIM
     from oracle import ops_np as O
     q, qdb = O.image_quality(O.floats_to_pixels(x, False).astype(np.float64), ref["recon_pixels"].astype(np.float64))
     assert abs(m["msssim"] - q.mean()) < 5e-4 and abs(m["msssim_db"] - qdb.mean()) < 5e-2
-    # end to end against the oracle's own latents: same numbers up to the counted flips
+    # end to end from pixels against the oracle's own float64 latents: the same two statements
     ref_e2e = ref_model.end_to_end(w, x)
-    assert abs(m["bpp"] - ref_e2e["bpp"]) <= 2e-3 and abs(m["psnr"] - ref_e2e["psnr"]) <= 2e-2
+    flip = sym != ref_e2e["symbols_y"]
+    assert int(flip.sum()) <= 4, int(flip.sum())
+    ref_e2e_s = ref_model.frame_loss(w, x, (rz, ry), force_symbols=sym)
+    assert (ref_e2e_s["tie_distance"][flip] < 1e-3).all()
+    assert abs(m["bpp"] - ref_e2e_s["bpp"]) <= 1e-4 and abs(m["psnr"] - ref_e2e_s["psnr"]) <= 1e-3
     # evaluate() yields one Metrics per image with the reference's scalar keys
     ms = list(model.evaluate(x))
     assert len(ms) == 2 and {"rd_loss", "bpp", "mse", "psnr", "scheduled_lr", "sched_rd_lambda"} <= set(ms[0].scalars)

@@ -76,11 +76,9 @@ def test_every_tile_variant(variant, dev):
     b = rng.standard_normal(200).astype(np.float32)
     ref = O.conv2d_transpose(x, wk, b, 2)
     plan = ops.ConvPlan("convT", dev_t(wk, dev), dev_t(b, dev), 2)
-    prev = _capi.load().sntc_conv_set_tile_override(variant)
-    try:
-        got = plan(dev_t(x, dev)).cpu().numpy()
-    finally:
-        _capi.load().sntc_conv_set_tile_override(prev)
+    plan.set_tile(variant)
+    assert plan.launch_info(2, 11, 13)[0] == variant
+    got = plan(dev_t(x, dev)).cpu().numpy()
     assert rel_err(got, ref) < TOL
 
 

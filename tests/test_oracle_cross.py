@@ -138,3 +138,30 @@ def test_ms_ssim_restatements_agree(h, w):
     v, db = O.image_quality(a[:, :100, :120], b[:, :100, :120])          # both sides < 160: single-scale SSIM
     np.testing.assert_allclose(v, O.ssim(a[:, :100, :120], b[:, :100, :120]))
     np.testing.assert_allclose(db, -10 * np.log10(1 - v))
+
+
+def test_float64_library_backend_equals_the_tap_loop_oracle():
+    """model_np's eval forward with its transforms on oracle/train_ref (float64 library convolutions: the full-size
+    oracle of tests/test_hip_e2e_parity.py) equals the NumPy tap-loop oracle, and ``force_symbols`` at the oracle's own
+    symbols reproduces its numbers."""
+    from oracle import model_np, train_ref
+    tc = dict(analysis=dict(cls="ElicAnalysis", channels=(16, 16, 16, 32)),
+              synthesis=dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5),
+                             activation_type="igdn", res_type="conv"))
+    m = model_np.Model(tc, rd_lambda=0.02)
+    p = m.init_params(3)
+    rng = np.random.default_rng(1)
+    p["analysis/conv3/kernel"] = (p["analysis/conv3/kernel"] * 30).astype(np.float32)
+    x = rng.uniform(-0.5, 0.5, (1, 50, 100, 3))
+    a, b = m.end_to_end(p, x), m.end_to_end(p, x, be=train_ref)
+    assert np.abs(a["symbols_y"]).max() >= 2
+    np.testing.assert_array_equal(a["symbols_y"], b["symbols_y"])
+    assert abs(a["bpp"] - b["bpp"]) < 1e-10 and abs(a["psnr"] - b["psnr"]) < 1e-10
+    assert np.abs(a["recon"] - b["recon"]).max() < 1e-11
+    f = m.frame_loss(p, x, m.infer_latents(p, x), force_symbols=a["symbols_y"])
+    assert abs(f["bpp"] - a["bpp"]) < 1e-12 and abs(f["psnr"] - a["psnr"]) < 1e-12
+    assert f["tie_distance"].shape == a["symbols_y"].shape and (f["tie_distance"] <= 0.5).all()
+    # moving one symbol by one step changes the rate: the forced path really evaluates the given integers
+    s2 = a["symbols_y"].copy()
+    s2[0, 0, 0, 0] += 1
+    assert abs(m.frame_loss(p, x, m.infer_latents(p, x), force_symbols=s2)["bpp"] - a["bpp"]) > 1e-6

@@ -26,10 +26,10 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--decode-only", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+ops.FORCE_TILE = args.variant
 model = Model(device=dev, **configs.CONFIGS[args.config]())
 n, (h, w) = args.batch, args.hw
 x = (torch.rand((n, h, w, 3), device=dev) - 0.5).contiguous()
-_capi.load().sntc_conv_set_tile_override(args.variant)
 
 
 def run(fn, label):
