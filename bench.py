@@ -91,9 +91,8 @@ def launch_ranks(n, argv):
                 for q in pending:
                     procs[q].terminate()
         time.sleep(0.05)
-    if out0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+    for ln in (out0 or "").splitlines():          # rank 0's JSON line to stdout; library chatter (gloo prints there) to stderr
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr, flush=True)
     return rc if rc >= 0 else 1
 
 
