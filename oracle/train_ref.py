@@ -126,9 +126,27 @@ def noisy_deep_factorized_bits(v, mats, biases, factors):
     return -(big + torch.log1p(-torch.exp(small - big))) / math.log(2.0)
 
 
+class _BoundTowards(torch.autograd.Function):
+    """tfc.ops.math_ops.upper_bound / lower_bound with gradient="identity_if_towards" (their default, and what
+    LocationScaleIndexedEntropyModel._normalize_indexes uses [DEP]): forward clamps; backward passes the gradient where
+    the input is inside the bound OR a descent step would move it towards the bound."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.save_for_backward(x)
+        ctx.lo, ctx.hi = lo, hi
+        return torch.clamp(x, lo, hi)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        ok = ((x <= ctx.hi) | (g > 0)) & ((x >= ctx.lo) | (g < 0))
+        return g * ok.to(g.dtype), None, None
+
+
 def noisy_normal_bits(v, raw):
-    """-log2 [Phi((v + .5)/s) - Phi((v - .5)/s)], s = SCALE_FN(clamp(exp(raw), 0, 63)) (mshyper/models.py:28-32,275-279)."""
-    sigma = torch.exp(LOG_SCALE_MIN + SCALE_FACTOR * torch.clamp(torch.exp(raw), 0.0, 63.0))
+    """-log2 [Phi((v + .5)/s) - Phi((v - .5)/s)], s = SCALE_FN(bound(exp(raw), 0, 63)) (mshyper/models.py:28-32,275-279)."""
+    sigma = torch.exp(LOG_SCALE_MIN + SCALE_FACTOR * _BoundTowards.apply(torch.exp(raw), 0.0, 63.0))
     hi, lo = (v + 0.5) / sigma, (v - 0.5) / sigma
     right = hi > 0
     big = torch.special.log_ndtr(torch.where(right, -lo, hi))

@@ -4,6 +4,7 @@
 (``record.jsonl``, as the reference's custom writer also keeps, custom_writers.py:89-128); TensorBoard summaries and
 the tf.data input pipeline are not reproduced -- ``train_dataset`` is any iterable of NHWC float batches."""
 import json
+import re
 import time
 from pathlib import Path
 from typing import Any, Mapping, NamedTuple
@@ -91,6 +92,16 @@ def simple_train_eval_loop(train_eval_config, workdir, model, train_dataset, val
         prefix = warm if not warm.is_dir() else (eval_lib.latest_checkpoint(warm) if list(warm.glob("ckpt-*.index"))
                                                   else eval_lib.latest_checkpoint(warm / TRAIN_COLLECTION / CHECKPOINTS_DIR_NAME))
         model.set_weights(tf_checkpoint.load_reference_checkpoint(prefix, model._transform_config))
+    # restore_or_initialize (:190): a workdir that already holds a checkpoint continues from it -- variables, step (hence
+    # the lr / lambda schedules and Adam's bias correction) and, when this build wrote it, the Adam moments
+    own = workdir / TRAIN_COLLECTION / CHECKPOINTS_DIR_NAME
+    if (own / "checkpoint").exists() or list(own.glob("ckpt-*.index")):
+        prefix = eval_lib.latest_checkpoint(own)
+        model.set_weights(tf_checkpoint.load_reference_checkpoint(prefix, model._transform_config))
+        model._step = int(re.search(r"ckpt-(\d+)", Path(prefix).name).group(1))
+        from ..train import Trainer
+        model.trainer = Trainer(model, seed=model._seed)
+        model.trainer.restore_optimizer(prefix)
     rows = []
 
     def evaluate_fn(step):                                     # :214-229

@@ -37,6 +37,14 @@ __device__ __forceinline__ void sga_sample(float mu, float tau, float g0, float 
   *dout = (ce - fl) * w1 * (1.0f - w1) * (dl1 - dl0) / tau;
 }
 
+// Gradient through idx = clamp(exp(raw), 0, 63): tfc's _normalize_indexes bounds the indexes with math_ops.lower_bound /
+// upper_bound, whose default gradient is "identity_if_towards" [DEP]: a saturated index still receives the gradient when a
+// descent step would move it back towards the bound (d loss / d idx > 0 at the upper bound; the rate's weight in the loss
+// is positive, so the sign of d bits / d sigma decides).  exp(raw) > 0, so the lower bound never binds.
+__device__ __forceinline__ bool scale_index_gate(float e, float dbits_dsigma) {
+  return e <= 63.0f || dbits_dsigma > 0.0f;
+}
+
 // ---- normal (y) : forward sample + rate + partial derivatives ----
 // bits(v, sigma) = -log2 [Phi((v+.5)/s) - Phi((v-.5)/s)];  d bits/d v, d bits/d raw (through
 // idx = clamp(exp(raw), 0, 63), sigma = exp(c0 + c1 idx)).
@@ -72,7 +80,7 @@ __global__ void __launch_bounds__(256) sga_normal_fwd_kernel(const float* __rest
     const float r_hi = expf(lphi_hi), r_lo = expf(lphi_lo);
     const float dlogp_dv = (r_hi - r_lo) / sigma;
     const float dlogp_ds = -(r_hi * hi - r_lo * lo) / sigma;
-    const float dsig_draw = (e > 0.0f && e < 63.0f) ? sigma * kScaleFactor * e : 0.0f;
+    const float dsig_draw = scale_index_gate(e, -dlogp_ds) ? sigma * kScaleFactor * e : 0.0f;
     y_tilde[gi] = v + mu;
     sprime[gi] = sp;
     dbits_dv[gi] = -dlogp_dv * kInvLn2;
@@ -344,7 +352,7 @@ __device__ __forceinline__ void normal_rate_terms(float v, float raw, float* bit
   const float logp = big + log1pf(-expf(small - big));
   const float r_hi = expf(-0.5f * hi * hi - 0.91893853320467274f - logp);
   const float r_lo = expf(-0.5f * lo * lo - 0.91893853320467274f - logp);
-  const float dsig_draw = (e > 0.0f && e < 63.0f) ? sigma * kScaleFactor * e : 0.0f;
+  const float dsig_draw = scale_index_gate(e, (r_hi * hi - r_lo * lo) / sigma) ? sigma * kScaleFactor * e : 0.0f;
   *bits = -logp * kInvLn2;
   *dbits_dv = -(r_hi - r_lo) / sigma * kInvLn2;
   *dbits_draw = (r_hi * hi - r_lo * lo) / sigma * dsig_draw * kInvLn2;

@@ -9,7 +9,7 @@ Tables (host, float64, 16-bit precision: frequencies sum to 65536, every symbol 
     (mshyper/models.py:28-32; rounding the index is what TFC's compress() path does), pmf(v) = Phi((v+.5)/s) - Phi((v-.5)/s)
     on |v| <= L_k = the symbols with pmf >= 2^-17; rarer values are escaped.
   * z: one table per channel from the deep-factorized prior, pmf(v) = sigmoid(L(v+.5)) - sigmoid(L(v-.5)).
-Wire format (little endian): b"SNTC" u16 version | u16 n | u32 H | u32 W | u16 C | u16 hz | u16 wz | u16 h | u16 w |
+Wire format v3 (little endian): b"SNTC" u16 version | u16 n | u32 H | u32 W | u16 C | u16 Cz | u16 hz | u16 wz | u16 h | u16 w |
   u16 segments_z | u16 segments_y | u8 lanes_z | u8 lanes_y | u32 len_words[n * segments_z] | u32 len_words[n * segments_y] |
   z payload | y payload; a stream (one per image and segment) = the lane states (8 .. 64 of them, fewer on short streams)
   + the interleaved 16-bit words (csrc/rans.hip).
@@ -31,7 +31,7 @@ from . import ops
 PRECISION = 16
 TOTAL = 1 << PRECISION
 MAGIC = b"SNTC"
-VERSION = 2
+VERSION = 3
 SCALE_MIN, SCALE_MAX, NUM_SCALES = 0.11, 256.0, 64
 SCALE_FACTOR = (math.log(SCALE_MAX) - math.log(SCALE_MIN)) / (NUM_SCALES - 1.0)
 
@@ -212,7 +212,8 @@ def int_to_float(x):
 class Codec:
     """compress / decompress for a mean-scale hyperprior ``Model``."""
 
-    HEAD = "<HHIIHHHHHHHBB"
+    HEAD = "<HHIIHHHHHHHHBB"
+    MAX_IMAGES, MAX_SIDE = 4096, 1 << 16
 
     def __init__(self, model):
         self.m = model
@@ -221,6 +222,16 @@ class Codec:
         with torch.cuda.device(dev):
             self.y_tables = DeviceTables(normal_tables(), dev)
             self.z_tables = DeviceTables(factorized_tables(model._prior_weights, nl), dev)
+
+    def latent_shapes(self, H, W):
+        """(C, Cz, hz, wz, h, w) of this model's latents for an H x W image (pad to the downsample factor, then the
+        transforms' own shape arithmetic)."""
+        m = self.m
+        f = m.downsample_factor
+        hp, wp = -(-H // f) * f, -(-W // f) * f
+        h, w = m._analysis.out_hw(hp, wp)
+        hz, wz = m._hyper_analysis.out_hw(h, w)
+        return (m._bottleneck_size, m._hyper_bottleneck_size, hz, wz, h, w)
 
     def compress(self, x) -> bytes:
         m = self.m
@@ -238,7 +249,8 @@ class Codec:
             zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz, lz)
             yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables, sy, ly)
             zb, yb = zp.cpu().numpy().tobytes(), yp.cpu().numpy().tobytes()
-        head = MAGIC + struct.pack(self.HEAD, VERSION, n, H, W, y.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2], sz, sy, lz, ly)
+        head = MAGIC + struct.pack(self.HEAD, VERSION, n, H, W, y.shape[-1], z.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2],
+                                   sz, sy, lz, ly)
         return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
 
     def decompress(self, blob: bytes):
@@ -248,9 +260,20 @@ class Codec:
         pos = 4 + struct.calcsize(self.HEAD)
         if len(blob) < pos:
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
-        ver, n, H, W, c, hz, wz, h, w, sz, sy, lz, ly = struct.unpack_from(self.HEAD, blob, 4)
+        ver, n, H, W, c, cz, hz, wz, h, w, sz, sy, lz, ly = struct.unpack_from(self.HEAD, blob, 4)
         if ver != VERSION:
             raise capi.SntcError(capi.ERR_UNSUPPORTED, f"bitstream version {ver}")
+        # Nothing below trusts the header: every dimension is recomputed from (H, W) and THIS model, so a corrupt or crafted
+        # blob cannot size an allocation or index a table-id tensor beyond what the model itself would produce.
+        if not (1 <= n <= self.MAX_IMAGES and 1 <= H <= self.MAX_SIDE and 1 <= W <= self.MAX_SIDE):
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream header: implausible batch / image size n={n} H={H} W={W}")
+        want = self.latent_shapes(H, W)
+        if (c, cz, hz, wz, h, w) != want:
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream header (C, Cz, hz, wz, h, w) = {(c, cz, hz, wz, h, w)} does not match "
+                                 f"this model's latents for a {H} x {W} image: {want}")
+        ez, ey = hz * wz * cz, h * w * c
+        if (sz, sy) != (_segments(ez), _segments(ey)) or (lz, ly) != (_lanes(-(-ez // sz)), _lanes(-(-ey // sy))):
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream header: segment / lane counts do not match the latent sizes")
         nz, ny = n * sz, n * sy
         if len(blob) < pos + 4 * (nz + ny):
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
@@ -264,8 +287,10 @@ class Codec:
         with torch.cuda.device(dev):
             zp = torch.from_numpy(np.frombuffer(blob, "<i2", zw, pos).copy()).to(dev)
             yp = torch.from_numpy(np.frombuffer(blob, "<i2", yw, pos + 2 * zw).copy()).to(dev)
-            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, c), dev), (n, hz, wz, c), self.z_tables, sz, lz)
+            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, cz), dev), (n, hz, wz, cz), self.z_tables, sz, lz)
             hyper = m._hyper_synthesis(int_to_float(zi))
+            if tuple(hyper.shape) != (n, h, w, 2 * c):
+                raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents {(n, h, w, c)}")
             sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy, ly)
             y_hat = ops.dequant_scale_normal(sym, hyper)
             return ops.to_pixels(m._synthesis(y_hat), H, W)

@@ -68,6 +68,23 @@ def deep_factorized_init(channels, num_filters=(3, 3), init_scale=10.0, seed=432
     return out
 
 
+def compression_lr(optimizer_config, scheduled_num_steps, step):
+    """Learning rate the reference's Adam uses for the update taken at optimizer iteration ``step`` (0-based):
+    CompressionSchedule (common/schedule.py:155-176 via mshyper/models.py:95-108) = base * piecewise-constant
+    [1, reduce_lr_factor] switching at int(reduce_lr_after * total) (boundary <= step picks the second value,
+    schedule.py:46-48) * linear warm-up min(1, (step + 1) / warmup_steps) (schedule.py:121-123 -- the `+ 1` makes the
+    very first update non-zero, and the warm-up factor also multiplies the dropped value)."""
+    cfg = optimizer_config
+    lr = cfg.get("learning_rate", 1e-4)
+    after = cfg.get("reduce_lr_after", 0.8)
+    factor = cfg.get("reduce_lr_factor", 0.1)
+    warmup = cfg["warmup_steps"] if "warmup_steps" in cfg else int(cfg.get("warmup_until", 0.02) * scheduled_num_steps)
+    value = lr * (factor if step >= int(after * scheduled_num_steps) else 1.0)
+    if warmup > 0:
+        value *= min(1.0, (step + 1) / warmup)
+    return value
+
+
 class Model:
     """Encapsulates the transforms + entropy models (reference :45-149)."""
 
@@ -145,7 +162,12 @@ class Model:
         out.update(self._prior_weights)
         return out
 
-    def set_weights(self, weights):
+    def set_weights(self, weights, _from_trainer=False):
+        """Load variables (``get_weights()`` naming).  A ``Trainer`` attached to this model keeps its own flat copy of the
+        variables and the Adam moments: weights set from anywhere else make that state stale, so it is dropped and the
+        next ``train_step`` builds a fresh one from these weights and ``self._step``."""
+        if not _from_trainer:
+            self.trainer = None
         for pre, t in self._transforms().items():
             sub = {k[len(pre) + 1:]: v for k, v in weights.items() if k.startswith(pre + "/")}
             t.set_weights(sub)
@@ -181,15 +203,7 @@ class Model:
 
     @property
     def _scheduled_lr(self):
-        cfg = self._optimizer_config
-        lr = cfg.get("learning_rate", 1e-4)
-        after = cfg.get("reduce_lr_after", 0.8)
-        factor = cfg.get("reduce_lr_factor", 0.1)
-        warmup = cfg.get("warmup_steps", int(cfg.get("warmup_until", 0.02) * self._scheduled_num_steps))
-        step = self.global_step
-        if warmup > 0 and step < warmup:
-            return lr * step / warmup
-        return lr * (factor if step >= int(after * self._scheduled_num_steps) else 1.0)
+        return compression_lr(self._optimizer_config, self._scheduled_num_steps, self.global_step)
 
     @property
     def _scheduled_rd_lambda(self):

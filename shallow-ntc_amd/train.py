@@ -332,7 +332,7 @@ class Trainer:
                                      f=self.store.offsets.get("prior/factor_0", (0, ()))[0])
             self._grad_rec = torch.empty((capi.load().sntc_prior_record_floats(self._prior._h),), dtype=torch.float32, device=self.device)
             self._refresh()
-        self.step_count = 0
+        self.step_count = int(model._step)      # a restored / warm-started model continues its schedules and Adam bias correction
         self._handles = []
 
     # ---- construction -----------------------------------------------------------------------------
@@ -477,27 +477,29 @@ class Trainer:
             out = self.loss_and_grads(x, rd_lambda, noise_z, noise_y, on_bucket=reducer.launch)
             inv_world = reducer.finish()
             clip = m._optimizer_config.get("global_clipnorm")
+            # ONE device -> host copy of everything the step's control flow needs, BEFORE any state is touched
+            host = torch.stack([out["bits_z"], out["bits_y"], out["sse"]]).cpu().numpy()
+            norm = math.sqrt(float(ops.sumsq(self.store.grad).item())) * inv_world
+            n, h, w, c = x.shape
+            bpp = float(host[0].mean() / (h * w) + host[1].mean() / (h * w))
+            mse_i = host[2] / (h * w * c)
+            mse = float(mse_i.mean())
+            loss = bpp + rd_lambda * mse
+            if not (math.isfinite(loss) and math.isfinite(norm)):
+                # tf.debugging.check_numerics inside the loss (mshyper/models.py:308-309,356) fires before apply_gradients:
+                # parameters, Adam moments and the packed plans are left exactly as they were
+                raise capi.NonFiniteError(capi.ERR_NONFINITE, f"rd_loss / gradient norm is not finite (bpp {bpp}, mse {mse}, |g| {norm}); "
+                                          "the optimizer step was skipped")
             gscale = inv_world
-            norm = None
-            if clip is not None:
-                norm = math.sqrt(float(ops.sumsq(self.store.grad).item())) * inv_world
-                if norm > clip:
-                    gscale *= clip / norm
+            if clip is not None and norm > clip:
+                gscale *= clip / norm
             cfg = m._optimizer_config
             ops.adam_step(self.store.param, self.store.grad, self.store.m, self.store.v, lr, self.step_count + 1,
                           cfg.get("beta_1", 0.9), cfg.get("beta_2", 0.999), cfg.get("epsilon", 1e-7), grad_scale=gscale)
             self._refresh()
-            host = torch.stack([out["bits_z"], out["bits_y"], out["sse"]]).cpu().numpy()
         self.step_count += 1
         m._step = self.step_count
-        n, h, w, c = x.shape
-        bpp = float(host[0].mean() / (h * w) + host[1].mean() / (h * w))
-        mse_i = host[2] / (h * w * c)
-        mse = float(mse_i.mean())
         psnr = float(np.mean(-10.0 * (np.log(mse_i) - 2.0 * math.log(255.0)) / math.log(10.0)))
-        loss = bpp + rd_lambda * mse
-        if not math.isfinite(loss):
-            raise capi.NonFiniteError(capi.ERR_NON_FINITE, "rd_loss is not finite")
         return dict(rd_loss=loss, bpp=bpp, mse=mse, psnr=psnr, scheduled_lr=lr, sched_rd_lambda=rd_lambda, grad_norm=norm)
 
     # ---- weights out ---------------------------------------------------------------------------------
@@ -528,7 +530,7 @@ class Trainer:
 
     def sync_model(self):
         """Load the trained variables into the inference ``Model`` (validation / checkpoint)."""
-        self.m.set_weights(self.export_weights())
+        self.m.set_weights(self.export_weights(), _from_trainer=True)
 
     def save_checkpoint(self, workdir, model_config=None):
         """``workdir/train/checkpoints/ckpt-<step>`` in the reference's TensorBundle layout (+ ``config.json``), i.e. what
@@ -543,5 +545,35 @@ class Trainer:
             scheduled_num_steps=self.m._scheduled_num_steps, rd_lambda=self.m._rd_lambda, transform_config=self.m._transform_config,
             optimizer_config=self.m._optimizer_config, latent_config=self.m._latent_config)
         (Path(workdir) / "config.json").write_text(json.dumps(dict(model_config=cfg), indent=1, default=lambda o: list(o)))
-        return tf_checkpoint.save_reference_checkpoint(ckdir / f"ckpt-{self.step_count}", self.export_weights(),
-                                                       self.m._transform_config, self.step_count)
+        prefix = tf_checkpoint.save_reference_checkpoint(ckdir / f"ckpt-{self.step_count}", self.export_weights(),
+                                                         self.m._transform_config, self.step_count)
+        # optimizer state for THIS build's resume (the reference keeps iterations + Adam m / v as slot variables inside the
+        # bundle; here they sit next to it): the flat moment buffers in the store's own order, keyed by its layout
+        np.savez(ckdir / f"ckpt-{self.step_count}.optimizer.npz", step=np.int64(self.step_count),
+                 m=self.store.m.cpu().numpy(), v=self.store.v.cpu().numpy(),
+                 layout=np.array(json.dumps({k: [int(o), list(map(int, shp))] for k, (o, shp) in self.store.offsets.items()})))
+        # tf.train.CheckpointManager's state file: what tf.train.latest_checkpoint (reference eval_lib.py:42-44) reads
+        name = f"ckpt-{self.step_count}"
+        (ckdir / "checkpoint").write_text(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
+        for old in ckdir.glob("ckpt-*"):                       # CheckpointManager(max_to_keep=1), train_lib.py:124-126
+            if not old.name.startswith(name + "."):
+                old.unlink()
+        return prefix
+
+    def restore_optimizer(self, prefix):
+        """Adam moments + iteration count written by ``save_checkpoint`` next to ``prefix``; False when there are none (a
+        checkpoint of the reference, or variables only): training then continues with fresh moments at the stored step."""
+        import json
+        from pathlib import Path
+        f = Path(str(prefix) + ".optimizer.npz")
+        if not f.exists():
+            return False
+        d = np.load(f)
+        layout = {k: [int(o), list(map(int, shp))] for k, (o, shp) in self.store.offsets.items()}
+        if json.loads(str(d["layout"])) != layout:
+            raise ValueError(f"{f}: optimizer state was written for a different model layout")
+        self.store.m.copy_(torch.from_numpy(d["m"]).to(self.device))
+        self.store.v.copy_(torch.from_numpy(d["v"]).to(self.device))
+        self.step_count = int(d["step"])
+        self.m._step = self.step_count
+        return True

@@ -178,3 +178,26 @@ def test_png_dataset_pipeline(tmp_path):
     assert all(b.shape == (2, 16, 16, 3) and b.dtype == np.float32 and -0.5 <= b.min() and b.max() <= 0.5 for b in batches)
     with pytest.raises(RuntimeError):
         data_lib.get_dataset_from_glob(str(tmp_path / "*.jpg"), False, False, False, 1)
+
+
+def test_learning_rate_schedule_matches_the_reference_closed_form():
+    """CompressionSchedule (reference common/schedule.py:121-123,155-176): base * [1, drop] at int(after * total), times
+    min(1, (step + 1) / warmup): the FIRST update already has lr > 0 and warm-up also scales the dropped value."""
+    from shallow_ntc_amd.mshyper.models import compression_lr
+    cfg = dict(learning_rate=2e-4, reduce_lr_after=0.8, reduce_lr_factor=0.1)          # warmup_until default 0.02
+    total = 1000                                                                       # warm-up 20 steps, drop at 800
+    assert compression_lr(cfg, total, 0) == pytest.approx(2e-4 * 1 / 20)
+    assert compression_lr(cfg, total, 9) == pytest.approx(2e-4 * 10 / 20)
+    assert compression_lr(cfg, total, 19) == pytest.approx(2e-4)
+    assert compression_lr(cfg, total, 20) == pytest.approx(2e-4)
+    assert compression_lr(cfg, total, 799) == pytest.approx(2e-4)
+    assert compression_lr(cfg, total, 800) == pytest.approx(2e-5)
+    # explicit warmup_steps takes precedence; warm-up that outlasts the drop scales the dropped value too
+    late = dict(cfg, warmup_steps=1000)
+    assert compression_lr(late, total, 899) == pytest.approx(2e-5 * 900 / 1000)
+    assert compression_lr(dict(cfg, warmup_steps=0), total, 0) == pytest.approx(2e-4)
+    # independent restatement of schedule_at_step for every step of a short run
+    for step in range(0, 60):
+        want = 1e-3 * (0.5 if step >= int(0.5 * 50) else 1.0) * min(1.0, (step + 1) / 7)
+        got = compression_lr(dict(learning_rate=1e-3, reduce_lr_after=0.5, reduce_lr_factor=0.5, warmup_steps=7), 50, step)
+        assert got == pytest.approx(want)

@@ -90,6 +90,18 @@ def test_codec_round_trip_and_rate(dev):
         model.decompress(blob[:-10])
     with pytest.raises(_capi.SntcError):
         model.decompress(b"JUNK" + blob[4:])
+    # a header that lies about any dimension is refused before anything is allocated or decoded with it
+    import struct
+    from shallow_ntc_amd.entropy_coding import Codec
+    head = list(struct.unpack_from(Codec.HEAD, blob, 4))       # ver n H W C Cz hz wz h w sz sy lz ly
+    assert head[1:10] == [2, 512, 768, 320, 320, 8, 12, 32, 48]
+    hsize = struct.calcsize(Codec.HEAD)
+    for field, value in ((1, 60000), (2, 100000), (4, 640), (5, 64), (6, 9), (8, 64), (9, 4800), (10, 7), (12, 3)):
+        bad = list(head)
+        bad[field] = value
+        forged = blob[:4] + struct.pack(Codec.HEAD, *bad) + blob[4 + hsize:]
+        with pytest.raises(_capi.SntcError, match="header"):
+            model.decompress(forged)
 
 
 def test_gpu_words_equal_the_golden_stream(dev):

@@ -93,6 +93,33 @@ def test_elementwise_training_kernels(dev):
     assert np.array_equal(u, u2) and not np.array_equal(u, u3)
 
 
+def test_rate_gradient_through_a_saturated_scale_index(dev):
+    """exp(raw) > 63 saturates the scale index; tfc bounds it with `identity_if_towards`, so such an element still gets
+    d bits / d raw when descent would pull it back (here: whenever sigma = 256 is too wide for v) and none otherwise."""
+    from oracle import train_ref
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(7)
+    c = 8
+    mu = rng.standard_normal((2, 4, 5, c)).astype(np.float32)
+    raw = rng.uniform(-2.0, 5.0, size=mu.shape).astype(np.float32)          # ln 63 = 4.14: about an eighth saturate
+    raw[0, 0, 0, :4] = [4.2, 4.5, 4.9, 4.1431]
+    v = rng.laplace(0, 3, size=mu.shape).astype(np.float32)
+    v[0, 0, 0, 0], v[0, 0, 0, 1] = 900.0, 0.25                            # sigma = 256 too narrow / too wide
+    hyper = np.concatenate([mu, raw], -1)
+    bits, dv, dr = ops.noisy_normal(torch.from_numpy(v + mu).to(dev), torch.from_numpy(hyper).to(dev))
+    vt = torch.from_numpy(v.astype(np.float64)).requires_grad_(True)
+    rt = torch.from_numpy(raw.astype(np.float64)).requires_grad_(True)
+    ref = train_ref.noisy_normal_bits(vt, rt)
+    ref.sum().backward()
+    np.testing.assert_allclose(bits.cpu().numpy(), ref.detach().numpy().sum(axis=(1, 2, 3)), rtol=2e-5)
+    np.testing.assert_allclose(dv.cpu().numpy(), vt.grad.numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(dr.cpu().numpy(), rt.grad.numpy(), rtol=2e-4, atol=1e-6)
+    sat = np.exp(raw.astype(np.float64)) > 63
+    got = dr.cpu().numpy()
+    assert sat.sum() >= 8 and (got[sat] >= 0).all() and (got[sat] > 0).any() and (got[sat] == 0).any()
+    assert got[0, 0, 0, 0] == 0.0 and got[0, 0, 0, 1] > 0.0
+
+
 def _small_model(dev, synthesis, analysis=None, uq="unoise"):
     from shallow_ntc_amd.mshyper.models import Model
     cfg = dict(analysis=analysis or dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)), synthesis=synthesis)
@@ -265,6 +292,63 @@ def test_train_eval_compress_round_trip(dev, tmp_path):
     assert 0.97 * est < 8 * len(blob) < 1.06 * est + overhead, (8 * len(blob), est)
 
 
+def test_non_finite_loss_leaves_the_training_state_untouched(dev):
+    """check_numerics semantics (reference mshyper/models.py:308-309,356 fire inside the loss, before apply_gradients): a
+    NaN batch raises NonFiniteError and neither the variables, the Adam moments, the packed plans nor the step move."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.train import Trainer
+    model, _ = _small_model(dev, SYNTHESES[1])
+    tr = Trainer(model, seed=3)
+    x = data_lib.normalize_image(data_lib.synthetic_images(2, 64, 64, seed=9))
+    tr.train_step(x)
+    snap = [tr.store.param.clone(), tr.store.m.clone(), tr.store.v.clone()]
+    good = tr.loss_and_grads(torch.from_numpy(x).to(dev), 0.02)
+    loss_before = float(good["bits_y"].sum())
+    bad = x.copy()
+    bad[0, 3, 4, 1] = np.nan
+    with pytest.raises(capi.NonFiniteError):
+        tr.train_step(bad)
+    assert tr.step_count == 1 and model._step == 1
+    for a, b in zip(snap, [tr.store.param, tr.store.m, tr.store.v]):
+        assert torch.equal(a, b)
+    assert float(tr.loss_and_grads(torch.from_numpy(x).to(dev), 0.02)["bits_y"].sum()) == loss_before     # plans not re-packed from NaNs
+    assert math.isfinite(tr.train_step(x)["rd_loss"]) and tr.step_count == 2
+
+
+def test_resume_continues_step_schedules_and_adam_moments(dev, tmp_path):
+    """A run that is stopped after 3 steps, restored from its own workdir and continued takes the SAME 4th and 5th steps
+    as the uninterrupted run: the step (learning-rate warm-up, Adam bias correction, noise stream), the variables and
+    the Adam moments all come back (reference train_lib.py:123-126,190 restore_or_initialize)."""
+    from shallow_ntc_amd.common import data_lib, eval_lib
+    from shallow_ntc_amd.mshyper.models import Model
+    from shallow_ntc_amd.train import Trainer
+    cfg = dict(analysis=dict(cls="ElicAnalysis", channels=(32, 32, 32, 32)), synthesis=dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16))
+    kw = dict(rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=100, quality_metrics=False,
+              optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=10))
+    x = data_lib.normalize_image(data_lib.synthetic_images(2, 64, 64, seed=9))
+    a = Model(device=dev, **kw)
+    lrs = [a.train_step(x).scalars_float["scheduled_lr"] for _ in range(3)]
+    assert lrs == pytest.approx([1e-4, 2e-4, 3e-4])                      # min(1, (step + 1) / 10): first update is not zero
+    a.trainer.save_checkpoint(tmp_path)
+    b = eval_lib.load_latest_ckpt(tmp_path, device=dev)
+    assert b._step == 3
+    b.trainer = Trainer(b, seed=b._seed)
+    assert b.trainer.step_count == 3 and b.trainer.restore_optimizer(eval_lib.latest_checkpoint(tmp_path / "train" / "checkpoints"))
+    for _ in range(2):
+        ma, mb = a.train_step(x).scalars_float, b.train_step(x).scalars_float
+        assert ma["scheduled_lr"] == mb["scheduled_lr"] and ma["rd_loss"] == mb["rd_loss"]
+    assert ma["scheduled_lr"] == pytest.approx(5e-4) and a._step == b._step == 5
+    assert torch.equal(a.trainer.store.param, b.trainer.store.param) and torch.equal(a.trainer.store.m, b.trainer.store.m)
+    # without the optimizer file (a reference checkpoint): fresh moments, but the step still continues
+    c = eval_lib.load_latest_ckpt(tmp_path, device=dev)
+    c.trainer = Trainer(c, seed=c._seed)
+    assert not c.trainer.restore_optimizer(tmp_path / "nowhere" / "ckpt-3") and c.trainer.step_count == 3
+    # weights set from outside drop the stale trainer state
+    a.set_weights(b.get_weights())
+    assert a.trainer is None
+
+
 def test_train_eval_loop_and_itinf_loop_drivers(dev, tmp_path):
     """common/train_lib.simple_train_eval_loop (reference :87-258) and common/itinf_lib.itinf_on_data_batch (:26-93):
     logging / evaluation / checkpoint cadence, JSON-lines records, a restorable checkpoint, SGA variables returned."""
@@ -287,7 +371,9 @@ def test_train_eval_loop_and_itinf_loop_drivers(dev, tmp_path):
     train_rec = [json.loads(l) for l in (tmp_path / "train" / "record.jsonl").read_text().splitlines()]
     val_rec = [json.loads(l) for l in (tmp_path / "val" / "record.jsonl").read_text().splitlines()]
     assert [r["step"] for r in train_rec] == [0, 4, 8] and [r["step"] for r in val_rec] == [6, 12]
-    assert sorted(p.name for p in (tmp_path / "train" / "checkpoints").glob("*.index")) == ["ckpt-12.index", "ckpt-6.index"]
+    # CheckpointManager(max_to_keep=1) (reference train_lib.py:124-126): only the newest survives, named by the state file
+    assert sorted(p.name for p in (tmp_path / "train" / "checkpoints").glob("*.index")) == ["ckpt-12.index"]
+    assert 'model_checkpoint_path: "ckpt-12"' in (tmp_path / "train" / "checkpoints" / "checkpoint").read_text()
     restored = eval_lib.load_latest_ckpt(tmp_path, device=dev)
     assert restored._step == 12
     a = restored.validation_step(batches[0]).scalars_float
