@@ -117,6 +117,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C shallow-ntc_amd/csrc`.  There is no CPU fallback for the hot path.")
+    # torch first: its wheel carries its own libamdhip64, and the library below must bind to THAT runtime (the one that owns
+    # torch's streams and allocations).  Loaded the other way round, /opt/rocm's copy comes in first, torch then brings a
+    # second HIP runtime into the process, and one of them sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

@@ -112,8 +112,9 @@ def test_rate_gradient_through_a_saturated_scale_index(dev):
     ref = train_ref.noisy_normal_bits(vt, rt)
     ref.sum().backward()
     np.testing.assert_allclose(bits.cpu().numpy(), ref.detach().numpy().sum(axis=(1, 2, 3)), rtol=2e-5)
-    np.testing.assert_allclose(dv.cpu().numpy(), vt.grad.numpy(), rtol=2e-4, atol=1e-6)
-    np.testing.assert_allclose(dr.cpu().numpy(), rt.grad.numpy(), rtol=2e-4, atol=1e-6)
+    # float32 derivatives of far-tail terms (|v| / sigma up to ~60 at sigma = 0.11: gradients of +-900 bits per unit)
+    np.testing.assert_allclose(dv.cpu().numpy(), vt.grad.numpy(), rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(dr.cpu().numpy(), rt.grad.numpy(), rtol=1e-3, atol=2e-6)
     sat = np.exp(raw.astype(np.float64)) > 63
     got = dr.cpu().numpy()
     assert sat.sum() >= 8 and (got[sat] >= 0).all() and (got[sat] > 0).any() and (got[sat] == 0).any()
@@ -337,7 +338,8 @@ def test_resume_continues_step_schedules_and_adam_moments(dev, tmp_path):
     assert b.trainer.step_count == 3 and b.trainer.restore_optimizer(eval_lib.latest_checkpoint(tmp_path / "train" / "checkpoints"))
     for _ in range(2):
         ma, mb = a.train_step(x).scalars_float, b.train_step(x).scalars_float
-        assert ma["scheduled_lr"] == mb["scheduled_lr"] and ma["rd_loss"] == mb["rd_loss"]
+        assert ma["scheduled_lr"] == mb["scheduled_lr"]
+        assert abs(ma["rd_loss"] - mb["rd_loss"]) <= 1e-12 * ma["rd_loss"]       # per-image double sums land by atomics: last-bit order effects
     assert ma["scheduled_lr"] == pytest.approx(5e-4) and a._step == b._step == 5
     assert torch.equal(a.trainer.store.param, b.trainer.store.param) and torch.equal(a.trainer.store.m, b.trainer.store.m)
     # without the optimizer file (a reference checkpoint): fresh moments, but the step still continues
