@@ -105,14 +105,19 @@ int64_t sntc_conv_flops(const sntc_conv_plan* plan, int n, int h, int w);
  * res / aux are NHWC tensors of the OUTPUT shape (NULL unless the epilogue uses them). */
 int sntc_conv_forward(const sntc_conv_plan* plan, const float* x, int n, int h, int w, float* y,
                       const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream);
-/* Device scratch the call above needs (0 for most shapes).  Layers that offer few output tiles per image but a
- * long contraction (hyper transforms, SGA input-gradient convolutions) are split along K into slabs that a second
- * kernel adds in a fixed order; the split depends on the layer and the image shape only, so results are
- * bit-identical for any batch size. */
+/* Device scratch the call above needs.  Large launches run on persistent stream-K workers that hand a tile's
+ * accumulators to the next worker through this scratch (a few tens of MB, contents irrelevant before and after the call).
+ * Layers that offer few output tiles per image but a long contraction (hyper transforms, SGA input-gradient
+ * convolutions) are split along K into slabs that a second kernel adds in a fixed order; the split depends on the
+ * layer and the image shape only.  Either way results are bit-identical for any batch size. */
 int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int w);
 /* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
  * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */
 int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
+/* stream_k = 0 forces the static schedule (one workgroup per tile) for THIS plan, 1 (default) lets large launches run on
+ * the persistent stream-K workers.  Both schedules produce bit-identical outputs (every element is the same k-ordered
+ * fma chain); the switch exists so that a test can assert exactly that. */
+int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int stream_k);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64) the heuristic picks for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);

@@ -55,6 +55,7 @@ struct sntc_conv_plan {
   bool exact_grid = false;  // phase mode: every group has one grid origin -> macro grid == input grid (no +1 row/col)
   struct Grp {
     int T = 0, K = 0, Ncol = 0;
+    int tw = 1;               // taps form a dense th x tw grid in row-major order (checked when the plan is built)
     int q0y = 0, q0x = 0;
     float* wp = nullptr;
     int* taps = nullptr;
@@ -62,12 +63,19 @@ struct sntc_conv_plan {
   } g[kMaxGroups];
   float* bias = nullptr;
   int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
+  bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
 };
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_tile: null plan");
   if (variant < 0 || variant > kNumVariants) return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_tile: unknown tile variant");
   p->tile = variant;
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int stream_k) {
+  if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_schedule: null plan");
+  p->no_stream_k = stream_k == 0;
   return SNTC_OK;
 }
 
@@ -141,11 +149,15 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     if (p->exact_grid) { G.q0y = hg.q0y; G.q0x = hg.q0x; }
     G.T = (int)hg.taps.size();
     G.Ncol = (int)hg.cols.size();
-    G.K = ((G.T * d.cin + 31) / 32) * 32;
+    G.tw = 1;
+    for (int t = 0; t < G.T; ++t) G.tw = std::max(G.tw, (hg.taps[t] & 0xffff) + 1);
+    for (int t = 0; t < G.T; ++t)     // the kernel walks taps arithmetically: (t / tw, t % tw)
+      if (hg.taps[t] != (((t / G.tw) << 16) | (t % G.tw))) return fail(SNTC_ERR_UNSUPPORTED, "tap table is not a dense row-major grid");
+    G.K = ((G.T * d.cin + kStage - 1) / kStage) * kStage;
     if ((int64_t)G.Ncol * G.K * 4 >= (1LL << 31)) return fail(SNTC_ERR_UNSUPPORTED, "packed weights of one phase group must be < 2 GiB");
     SNTC_HIP(hipMalloc(&G.taps, sizeof(int) * std::max(1, G.T)));
     SNTC_HIP(hipMalloc(&G.cols, sizeof(unsigned) * G.Ncol));
-    SNTC_HIP(hipMalloc(&G.wp, sizeof(float) * (size_t)G.Ncol * std::max(32, G.K)));
+    SNTC_HIP(hipMalloc(&G.wp, sizeof(float) * (size_t)G.Ncol * std::max(kStage, G.K)));
     SNTC_HIP(hipMemcpyAsync(G.taps, hg.taps.data(), sizeof(int) * G.T, hipMemcpyHostToDevice, stream));
     SNTC_HIP(hipMemcpyAsync(G.cols, hg.cols.data(), sizeof(unsigned) * G.Ncol, hipMemcpyHostToDevice, stream));
     // the host vectors must outlive the async copies
@@ -193,7 +205,7 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
     p->pt = d.kh / 2;
     p->pl = d.kw / 2;
   }
-  p->vec = (d.cin % 32) == 0;
+  p->vec = (d.cin % kStage) == 0;
   rc = build_plan(p, weight, bias, (hipStream_t)stream);
   if (rc) {
     sntc_conv_plan_destroy(p);
@@ -274,37 +286,20 @@ extern "C" int64_t sntc_conv_flops(const sntc_conv_plan* p, int n, int h, int w)
   return 2 * (int64_t)n * px * d.kh * d.kw * d.cin * d.cout;
 }
 
-static int pick_variant(const sntc_conv_plan* p, int64_t M) {
-  if (p->tile >= 1 && p->tile <= kNumVariants) return p->tile;
-  double best = 1e300;
-  int bestv = 4;
-  for (int v = 1; v <= kNumVariants; ++v) {
-    const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
-    const int64_t ntm = (M + bm - 1) / bm;
-    double work = 0;   // padded multiply-adds
-    int64_t nb = 0;
-    for (int gi = 0; gi < p->ngroups; ++gi) {
-      const int64_t ntn = (p->g[gi].Ncol + bn - 1) / bn;
-      work += (double)p->g[gi].K * (double)(ntn * bn) * (double)(ntm * bm);
-      nb += ntn * ntm;
-    }
-    const double waves = (double)nb / 256.0;   // 256 CUs
-    const double tail = waves < 1.0 ? 1.0 / waves : std::ceil(waves) / waves;
-    double cost = work * tail;
-    // fewer than ~3 workgroups per CU leaves nothing to overlap a block's barriers / epilogue with
-    // (measured: 240 blocks 68 TFLOP/s vs 640 blocks 87 TFLOP/s on the same layer)
-    if (nb < 768) cost *= 1.0 + 0.5 * (double)(768 - nb) / 768.0;
-    int kmax = 0;
-    for (int gi = 0; gi < p->ngroups; ++gi) kmax = std::max(kmax, p->g[gi].K);
-    // 64x64: half the MFMAs per staged byte -- except on short contractions (1x1 convolutions, K <= 192), where the
-    // tile's prologue / epilogue dominates and four small blocks per CU overlap them best (measured on 96->192 and
-    // 192->192: 65 / 78 TFLOP/s against 61 / 62 with the 128-row tiles)
-    if (v == 8) cost *= kmax <= 192 ? 0.90 : 1.15;
-    if (v == 1) cost *= 1.10;
-    if (v == 7) cost *= 1.08;   // 92 KB of LDS: one block per CU
-    if (cost < best) { best = cost; bestv = v; }
-  }
-  return bestv;
+// Launch schedule of one call: tile variant, split-K factor, and whether the persistent stream-K workers run it.
+struct Sched {
+  int variant = 2;
+  int ksplit = 1;
+  bool sk = false;
+  int workers = 0;        // stream-K: resident workgroups
+  int64_t units = 0;      // sum over groups of tiles * stages
+  int64_t blocks = 0;     // workgroups launched
+};
+
+static int max_steps(const sntc_conv_plan* p) {
+  int s = 0;
+  for (int gi = 0; gi < p->ngroups; ++gi) s = std::max(s, p->g[gi].K / kStage);
+  return s;
 }
 
 // Deterministic split-K factor: a function of the layer and the per-image geometry only (never of the
@@ -315,7 +310,7 @@ static int pick_ksplit(const sntc_conv_plan* p, const Geo& g) {
   int64_t bpi = 0;
   const int64_t mt = ((int64_t)g.Qh * g.Qw + 127) / 128;
   for (int gi = 0; gi < p->ngroups; ++gi) {
-    const int steps = p->g[gi].K / 32;
+    const int steps = p->g[gi].K / 32;                 // in 32-deep units, as the round-1 rule was tuned
     steps_min = std::min(steps_min, steps);
     steps_max = std::max(steps_max, steps);
     bpi += mt * ((p->g[gi].Ncol + 63) / 64);
@@ -325,18 +320,74 @@ static int pick_ksplit(const sntc_conv_plan* p, const Geo& g) {
   return std::max(1, std::min({8, want, std::max(1, steps_min / 8)}));
 }
 
-static int64_t workspace_floats(const sntc_conv_plan* p, int64_t M, int ksplit) {
-  if (ksplit <= 1) return 0;
+static void count_work(const sntc_conv_plan* p, int v, int64_t M, int64_t* tiles, int64_t* units, double* padded_macs) {
+  const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
+  const int64_t ntm = (M + bm - 1) / bm;
+  *tiles = 0; *units = 0; *padded_macs = 0;
+  for (int gi = 0; gi < p->ngroups; ++gi) {
+    const int64_t ntn = (p->g[gi].Ncol + bn - 1) / bn;
+    *tiles += ntn * ntm;
+    *units += ntn * ntm * (p->g[gi].K / kStage);
+    *padded_macs += (double)p->g[gi].K * (double)(ntn * bn) * (double)(ntm * bm);
+  }
+}
+
+// Tile variant: least padded multiply-adds x (rounds of resident workgroups actually run / rounds of work) -- the second
+// factor is 1 under stream-K, where every worker gets the same number of stages -- with the measured per-variant biases:
+// short contractions (1x1 convolutions, K <= 192) like the 64 x 64 tile, whose four small blocks per CU overlap each
+// other's prologue / epilogue; the 128 x 32 tile stages twice the bytes per MFMA.
+static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
+  Sched best;
+  const int64_t M = n * g.Qh * g.Qw;
+  const int ksplit = pick_ksplit(p, g);
+  const int msteps = max_steps(p);
+  const bool pro = p->d.prologue != SNTC_PRO_NONE;
+  double best_cost = 1e300;
+  for (int v = 1; v <= kNumVariants; ++v) {
+    if (p->tile >= 1 && p->tile <= kNumVariants && v != p->tile) continue;
+    if (p->tile == 0 && (v == 6 || v == 7)) continue;   // the two widest tiles run single-buffered (register budget): tests only
+    int64_t tiles, units;
+    double macs;
+    count_work(p, v, M, &tiles, &units, &macs);
+    const int resident = std::max(1, gg_resident_blocks(v, p->vec, pro));
+    Sched s;
+    s.variant = v;
+    s.ksplit = ksplit;
+    s.units = units;
+    // stream-K when every resident worker gets at least one longest tile's worth of stages (then a tile is shared by at
+    // most two workers) and the unit count fits the kernel's 32-bit unit arithmetic
+    s.sk = ksplit == 1 && !p->no_stream_k && units < (1LL << 31) && units / resident >= msteps && (resident % 8) == 0;
+    s.workers = s.sk ? resident : 0;
+    s.blocks = s.sk ? resident : tiles * ksplit;
+    double cost = macs;
+    if (!s.sk) {
+      const double rounds = (double)(tiles * ksplit) / resident;
+      cost *= rounds < 1.0 ? 1.0 / rounds : std::ceil(rounds) / rounds;
+      if (tiles * ksplit < 768) cost *= 1.0 + 0.5 * (double)(768 - tiles * ksplit) / 768.0;
+    }
+    int kmax = 0;
+    for (int gi = 0; gi < p->ngroups; ++gi) kmax = std::max(kmax, p->g[gi].K);
+    if (v == 8) cost *= kmax <= 192 ? 0.90 : 1.15;
+    if (v == 1) cost *= 1.10;
+    if (v == 7) cost *= 1.08;   // 72 KB of LDS: two blocks per CU
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
+static int64_t workspace_floats(const sntc_conv_plan* p, int64_t M, const Sched& s) {
+  if (s.sk) return (int64_t)s.workers * (int64_t)gg_sk_slab_floats(s.variant) + s.workers;   // slabs + one flag per worker
+  if (s.ksplit <= 1) return 0;
   int64_t cols = 0;
   for (int gi = 0; gi < p->ngroups; ++gi) cols += p->g[gi].Ncol;
-  return (int64_t)ksplit * M * cols;
+  return (int64_t)s.ksplit * M * cols;
 }
 
 extern "C" int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* p, int n, int h, int w) {
   if (!p) return 0;
   Geo g;
   if (geometry(p, h, w, &g)) return 0;
-  return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, pick_ksplit(p, g));
+  return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, schedule(p, g, n));
 }
 
 extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int w, int* variant, int* nblocks) {
@@ -344,14 +395,9 @@ extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int 
   Geo g;
   int rc = geometry(p, h, w, &g);
   if (rc) return rc;
-  const int64_t M = (int64_t)n * g.Qh * g.Qw;
-  const int ksplit = pick_ksplit(p, g);
-  const int v = pick_variant(p, M * ksplit);
-  const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
-  int64_t nb = 0;
-  for (int gi = 0; gi < p->ngroups; ++gi) nb += (int64_t)((p->g[gi].Ncol + bn - 1) / bn) * ((M + bm - 1) / bm) * ksplit;
-  *variant = v;
-  *nblocks = (int)nb;
+  const Sched s = schedule(p, g, n);
+  *variant = s.variant;
+  *nblocks = (int)s.blocks;
   return SNTC_OK;
 }
 
@@ -370,14 +416,15 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   const int64_t x_bytes = (int64_t)n * h * w * d.cin * 4;
   if (M > 0x7fffffffLL || x_bytes >= (1LL << 31))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: input tensor must be < 2 GiB (32-bit buffer offsets); split the batch");
-  const int ksplit = pick_ksplit(p, g);
-  const int64_t ws_floats = workspace_floats(p, M, ksplit);
+  const Sched sc = schedule(p, g, n);
+  const int64_t ws_floats = workspace_floats(p, M, sc);
   if (ws_floats > 0 && (!workspace || workspace_bytes < (size_t)ws_floats * 4))
-    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: this call needs sntc_conv_workspace_bytes() of workspace (split-K)");
-  const int v = pick_variant(p, M * ksplit);      // the split multiplies the number of workgroups
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: this call needs sntc_conv_workspace_bytes() of workspace "
+                                    "(split-K slabs / stream-K hand-off)");
+  const int v = sc.variant;
   const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
   GGArgs a{};
-  a.ksplit = ksplit;
+  a.ksplit = sc.ksplit;
   a.slab = static_cast<float*>(workspace);
   a.x = x; a.y = y; a.bias = p->bias; a.res = res; a.aux = aux;
   a.x_bytes = (unsigned)x_bytes;
@@ -388,20 +435,35 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   a.act = d.act; a.epi = d.epilogue; a.pro = d.prologue;
   a.ntm = (int)((M + bm - 1) / bm);
   a.ngroups = p->ngroups;
-  int nb = 0;
+  a.sk = sc.sk ? 1 : 0;
+  a.nworkers = sc.workers;
+  a.units = sc.units;
+  if (sc.sk) {
+    a.sk_slab = static_cast<float*>(workspace);
+    a.sk_flags = reinterpret_cast<int*>(a.sk_slab + (size_t)sc.workers * gg_sk_slab_floats(v));
+    a.slab = nullptr;
+    SNTC_HIP(hipMemsetAsync(a.sk_flags, 0, sizeof(int) * sc.workers, (hipStream_t)stream));
+  }
+  int nb = 0, tile0 = 0;
+  long long unit0 = 0;
   size_t slab_off = 0;
   for (int gi = 0; gi < p->ngroups; ++gi) {
     GGGroup& G = a.g[gi];
     G.wp = p->g[gi].wp; G.taps = p->g[gi].taps; G.cols = reinterpret_cast<const int*>(p->g[gi].cols);
-    G.T = p->g[gi].T; G.K = p->g[gi].K; G.Ncol = p->g[gi].Ncol;
+    G.T = p->g[gi].T; G.K = p->g[gi].K; G.Ncol = p->g[gi].Ncol; G.tw = p->g[gi].tw;
     G.ntn = (G.Ncol + bn - 1) / bn;
+    G.steps = G.K / kStage;
     G.blk0 = nb;
-    nb += G.ntn * a.ntm * ksplit;
+    G.tile0 = tile0;
+    G.unit0 = unit0;
+    nb += G.ntn * a.ntm * sc.ksplit;
+    tile0 += G.ntn * a.ntm;
+    unit0 += (long long)G.ntn * a.ntm * G.steps;
     G.slab_off = slab_off;
     G.q0y = p->g[gi].q0y; G.q0x = p->g[gi].q0x;
-    slab_off += (size_t)ksplit * M * G.Ncol;
+    slab_off += (size_t)sc.ksplit * M * G.Ncol;
   }
-  rc = gg_launch(v, p->vec, a, nb, (hipStream_t)stream);
-  if (rc || ksplit <= 1) return rc;
+  rc = gg_launch(v, p->vec, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
+  if (rc || sc.sk || sc.ksplit <= 1) return rc;
   return gg_reduce_launch(a, (hipStream_t)stream);
 }

@@ -5,18 +5,30 @@
 //     out[m, col] = sum_t sum_c x[src(m, t), c] * Wp[col][t*Cin + c]          (sntc_internal.h)
 // with pixels on the MFMA row (A) side and output columns on the column (B) side.
 //
-// Block: 256 threads = 4 waves arranged WM x WN; each wave owns TM x TN tiles of 32x32; BK = 32.
-//   HBM/L2 -> registers: buffer_load_dwordx4 through two wave-uniform descriptors (input, packed
-//   weights) with a 32-bit per-lane byte offset that changes only when the tap changes and a scalar
-//   offset that walks the channel slabs / K steps; a tile row is one full 128-B line; rows whose source
-//   pixel falls outside the image carry an out-of-range offset and read zeros from the bounds check
-//   (no branches, no 64-bit address arithmetic in the loop).
-//   registers -> LDS: 128-B rows, 16-B chunks XOR-swizzled by (row>>1)&7 so both the staging
-//   ds_write_b128 and the fragment ds_read_b128 are bank-conflict free without padding.
-//   Two LDS buffers, one barrier per K step; the next step's loads are issued before the MFMAs of
-//   the current one.  Per lane a ds_read_b128 fetches k = 8g+4h..8g+4h+3 (h = lane>>5): MFMA j of
-//   k-group g sums k in {8g+j, 8g+4+j}; A and B use the same permutation, so the products pair up.
+// Workgroup: 256 threads = 4 waves arranged WM x WN; each wave owns TN tiles of 32x32; a K stage is 16 deep.
+//   HBM/L2 -> registers: buffer_load_dwordx4 through two wave-uniform descriptors (input, packed weights) with a
+//   32-bit per-lane byte offset that changes only when the tap changes and a scalar offset that walks the channel
+//   slabs / K stages; rows whose source pixel falls outside the image carry an out-of-range offset and read zeros
+//   from the bounds check (no branches, no 64-bit address arithmetic in the loop).  Cin % 16 != 0 (the RGB first
+//   layer, reduced-width test nets) takes the dword gather path: one k column per thread, (tap, channel) advanced
+//   incrementally, same bounds-check zero fill.
+//   registers -> LDS: a ring of THREE 16-deep stages, 64-B rows, 16-B chunks XOR-swizzled by (row >> 2) & 3, so the
+//   staging ds_write_b128 and the fragment ds_read_b128 are bank-conflict free without padding.
+//   Pipeline, ONE barrier per stage: in step j a wave (1) writes stage j+2 (loaded during step j-1) into the slot that
+//   held stage j-1, (2) issues the global loads of stage j+3, (3) multiplies stage j from fragments it prefetched,
+//   reading the second half's fragments and then the FIRST fragments of stage j+1 under the MFMAs -- so nothing
+//   waits on LDS after the barrier.  Per lane a ds_read_b128 fetches k = 8g+4h..8g+4h+3 (h = lane>>5): MFMA e of
+//   k-group g sums k in {8g+e, 8g+4+e}; A and B use the same permutation, so the products pair up.
 //   C/D layout: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+//
+// Scheduling.  Static mode: one workgroup per (tile, K range); K ranges > 1 leave raw partial sums for
+// gg_reduce_kernel (deterministic split-K for layers with few tiles per image).  Stream-K mode: as many workgroups
+// as the device keeps resident each take an equal share of the launch's (tile, stage) units.  A worker whose share
+// ends inside a tile computes that tile's first stages FIRST and publishes the raw accumulators; the next worker
+// finishes the tile LAST, starting its fma chains from those accumulators.  Every output element is therefore the
+// same k-ordered chain as in an unsplit tile: results do not depend on the worker count, the batch size or the tile
+// shape, and no tile quantisation is left (2160 tiles on 768 slots used to run 3 rounds for 2.81 rounds of work).
+// Between tiles the next tile's first two stages are in flight while the current tile's epilogue runs.
 #include <algorithm>
 #include <cstdlib>
 #include "sntc_internal.h"
@@ -28,6 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kOutOfRange = 0x80000000u;   // > any in-range offset: buffers are < 2 GiB (host check)
+constexpr int kSpinLimit = 1 << 22;             // bounded wait on a neighbour's hand-off (~seconds), then trap
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -43,100 +56,244 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return __builtin_bit_cast(f32x4, v);
 }
 
-template <int TM, int TN, int WM, int WN, bool VEC, bool PRO>
-__global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
-  constexpr int BM = WM * TM * 32;
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rsrc, f32x4 v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
+}
+
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, 0, 0));
+}
+
+__device__ __forceinline__ f32x4 apply_epilogue(f32x4 v, int epi, const f32x4 rs, const float* aux, size_t idx) {
+  switch (epi) {
+    case SNTC_EPI_ADD: return v + rs;
+    case SNTC_EPI_GATE: return rs + *reinterpret_cast<const f32x4*>(aux + idx) * v;
+    case SNTC_EPI_RES_DIV: return rs / v;
+    case SNTC_EPI_RES_MUL: return rs * v;
+    case SNTC_EPI_RES_DIV_SQRT:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rs[e] / sqrtf(v[e]);
+      return v;
+    case SNTC_EPI_RES_MUL_SQRT:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rs[e] * sqrtf(v[e]);
+      return v;
+    case SNTC_EPI_MASK_RELU:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rs[e] > 0.0f ? v[e] : 0.0f;
+      return v;
+    case SNTC_EPI_MASK_LEAKY:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rs[e] >= 0.0f ? v[e] : 0.2f * v[e];
+      return v;
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float apply_epilogue1(float v, int epi, const float* res, const float* aux, size_t idx) {
+  switch (epi) {
+    case SNTC_EPI_ADD: return v + res[idx];
+    case SNTC_EPI_GATE: return res[idx] + aux[idx] * v;
+    case SNTC_EPI_RES_DIV: return res[idx] / v;
+    case SNTC_EPI_RES_MUL: return res[idx] * v;
+    case SNTC_EPI_RES_DIV_SQRT: return res[idx] / sqrtf(v);
+    case SNTC_EPI_RES_MUL_SQRT: return res[idx] * sqrtf(v);
+    case SNTC_EPI_MASK_RELU: return res[idx] > 0.0f ? v : 0.0f;
+    case SNTC_EPI_MASK_LEAKY: return res[idx] >= 0.0f ? v : 0.2f * v;
+    default: return v;
+  }
+}
+
+// The kernel arguments through an OPAQUE pointer to the kernarg segment: loads through it cannot be hoisted out of the
+// persistent tile loop, so a phase that runs once per tile (piece bookkeeping, row table, epilogue) re-reads its few
+// scalars from the scalar cache instead of pinning ~60 SGPRs (and, once those run out, VGPRs) through the K loop.
+typedef const GGArgs __attribute__((address_space(4))) KArgs;
+__device__ __forceinline__ KArgs& fresh_args() {
+  KArgs* kp = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return *kp;
+}
+
+// One unit of a workgroup's work: stages [k0, k1) of tile (gi, mt, nt).
+struct Piece {
+  int gi, mt, nt, k0, k1;
+  int consume;   // worker whose published accumulators this piece continues (-1: start from zero)
+  int publish;   // 1: the tile is finished by the next worker: leave raw accumulators in sk_slab[self]
+  int split;     // static split-K: index of this K range
+};
+
+// workgroups per CU the register budget must allow (= waves per SIMD for 256-thread workgroups): what the LDS ring admits
+constexpr int gg_waves(int tn, int wm) { return wm == 2 || tn == 1 ? 4 : (tn <= 3 ? 3 : 2); }
+
+template <int TN, int WM, int WN, bool VEC, bool PRO>
+__global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs a) {
+  constexpr int BM = WM * 32;
   constexpr int BN = WN * TN * 32;
-  constexpr int A_CH = BM / 32;   // 16-B chunks per thread per K step (A)
-  constexpr int B_CH = BN / 32;
+  constexpr int SLOT = (BM + BN) * kStage;            // floats per ring slot: A rows, then B rows, 16 floats each
+  constexpr int A_CH = BM / 64;                       // 16-B chunks per thread per stage (A, vector path)
+  constexpr int B_CH = (BN + 63) / 64;
+  constexpr int A_SC = BM / 16;                       // dwords per thread per stage (A, gather path)
+  constexpr int EPW = 32 * (TN >= 2 ? 64 : 32);       // floats of epilogue staging per wave
+  constexpr bool DBUF = TN <= 5;                      // fragment / prologue register double buffering (112+ accumulator
+                                                      // registers leave no room for it: the widest tiles run single-buffered)
+  static_assert(3 * SLOT >= 4 * EPW, "epilogue staging must fit in the stage ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);          // [2][BM][32]
-  float* Bs = As + 2 * BM * 32;                        // [2][BN][32]
-  int4* rinfo = reinterpret_cast<int4*>(Bs + 2 * BN * 32);   // [BM] (n, qy, qx, valid)
+  float* ring = reinterpret_cast<float*>(smem);                  // [3][BM + BN][16]
+  int4* rinfo_all = reinterpret_cast<int4*>(ring + 3 * SLOT);    // [2][BM] (n, qy, qx, valid) of the current / next tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN;
   const int wn = wave % WN;
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
 
-  int gi = 0;
+  // ------------------------------------------------------------------------------------------------------
+  // the worker's list of pieces
+  // ------------------------------------------------------------------------------------------------------
+  // stream-K: [head piece of the LAST tile of the share (published)] [whole tiles] [tail piece of the FIRST tile]
+  int sk_head_t = -1, sk_head_k1 = 0;       // global tile id / end stage of the head piece
+  int sk_tail_t = -1, sk_tail_k0 = 0;
+  int sk_cur = 0, sk_last = -1;             // whole tiles [sk_cur, sk_last]
+  int sk_phase = 0;                         // 0 head, 1 whole tiles, 2 tail, 3 done
+  int wl = 0;
+  if (a.sk) {
+    const int w = blockIdx.x;
+    wl = (w & 7) * (a.nworkers >> 3) + (w >> 3);      // workers on one XCD (b, b + 8, ...) own one contiguous eighth
+    const int u_lo = (int)(a.units * wl / a.nworkers);
+    const int u_hi = (int)(a.units * (wl + 1) / a.nworkers);
+    auto locate = [&](int u, int* t, int* k, int* steps) {
+      int gi = 0;
 #pragma unroll
-  for (int i = 1; i < kMaxGroups; ++i)
-    if (i < a.ngroups && (int)blockIdx.x >= a.g[i].blk0) gi = i;
-  const GGGroup G = a.g[gi];
-  const int lb0 = blockIdx.x - G.blk0;
-  const int split = lb0 % a.ksplit;          // K range of this block (deterministic split-K)
-  const int lb = lb0 / a.ksplit;
-  // XCD-aware tile order: blocks b and b + 8 share an XCD (and its 4 MB L2).  Inside one XCD's sequence the column
-  // tile runs fastest, so the ~64 blocks resident on an XCD cover a few row strips x all column tiles: an
-  // activation strip is fetched into ONE L2 instead of eight, and the weight tiles are shared by the co-resident strips.
-  int mt, nt;
-  const int full = a.ntm & ~7;
-  if (lb < full * G.ntn) {
-    const int l = lb >> 3;
-    mt = (l / G.ntn) * 8 + (lb & 7);
-    nt = l % G.ntn;
-  } else {                                   // ragged tail: fewer than 8 row strips left
-    const int r = lb - full * G.ntn, rem = a.ntm - full;
-    mt = full + r % rem;
-    nt = r / rem;
-  }
-  const int m0 = mt * BM;
-  const int n0 = nt * BN;
-
-  for (int r = tid; r < BM; r += 256) {
-    const int m = m0 + r;
-    int4 ri = make_int4(0, 0, 0, 0);
-    if (m < a.M) {
-      const int per = a.Qh * a.Qw;
-      const int n = m / per;
-      const int rem = m - n * per;
-      const int qy = rem / a.Qw;
-      ri = make_int4(n, qy + G.q0y, rem - qy * a.Qw + G.q0x, 1);   // per-group origin of the macro grid
+      for (int i = 1; i < kMaxGroups; ++i)
+        if (i < a.ngroups && (long long)u >= a.g[i].unit0) gi = i;
+      const int r = u - (int)a.g[gi].unit0;
+      const int lb = r / a.g[gi].steps;
+      *t = a.g[gi].tile0 + lb;
+      *k = r - lb * a.g[gi].steps;
+      *steps = a.g[gi].steps;
+    };
+    if (u_hi > u_lo) {
+      int tF, kF, sF, tL, kL, sL;
+      locate(u_lo, &tF, &kF, &sF);
+      locate(u_hi - 1, &tL, &kL, &sL);
+      sk_cur = tF;
+      sk_last = tL;
+      if (kF > 0) { sk_tail_t = tF; sk_tail_k0 = kF; sk_cur = tF + 1; }
+      if (kL + 1 < sL) { sk_head_t = tL; sk_head_k1 = kL + 1; sk_last = tL - 1; }
+      // host guarantee: a share is at least as long as the longest tile, so head and tail are different tiles
+    } else {
+      sk_phase = 3;
     }
-    rinfo[r] = ri;
   }
-  __syncthreads();
 
-  // ---------------- loader state ----------------
-  const int c = tid & 7;     // 16-B chunk inside the 128-B K slab
-  const int r0 = tid >> 3;   // row 0..31 (+32 i)
-  int a_iy0[A_CH], a_ix0[A_CH];
-  unsigned a_img[A_CH];      // byte offset of the row's image (+ chunk), or kOutOfRange for padding rows
+  auto tile_of = [&](int t, Piece* p) {          // global tile id -> (group, row strip, column tile): column fastest
+    KArgs& a = fresh_args();
+    int gi = 0;
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    const int4 ri = rinfo[r0 + 32 * i];
-    a_iy0[i] = ri.y * a.sA + a.offy;
-    a_ix0[i] = ri.z * a.sA + a.offx;
-    a_img[i] = ri.w ? (unsigned)ri.x * (unsigned)(a.H * a.W) * (unsigned)a.Cin * 4u + (unsigned)c * 16u : kOutOfRange;
-  }
-  unsigned b_off[B_CH];
+    for (int i = 1; i < kMaxGroups; ++i)
+      if (i < a.ngroups && t >= a.g[i].tile0) gi = i;
+    const int lb = t - a.g[gi].tile0;
+    p->gi = gi;
+    p->mt = lb / a.g[gi].ntn;
+    p->nt = lb - p->mt * a.g[gi].ntn;
+  };
+
+  auto next_piece = [&](Piece* p) -> bool {
+    KArgs& a = fresh_args();
+    if (!a.sk) return false;
+    if (sk_phase == 0) {
+      sk_phase = 1;
+      if (sk_head_t >= 0) {
+        tile_of(sk_head_t, p);
+        p->k0 = 0; p->k1 = sk_head_k1; p->consume = -1; p->publish = 1; p->split = 0;
+        return true;
+      }
+    }
+    if (sk_phase == 1) {
+      if (sk_cur <= sk_last) {
+        tile_of(sk_cur++, p);
+        p->k0 = 0; p->k1 = a.g[p->gi].steps; p->consume = -1; p->publish = 0; p->split = 0;
+        return true;
+      }
+      sk_phase = 2;
+    }
+    if (sk_phase == 2) {
+      sk_phase = 3;
+      if (sk_tail_t >= 0) {
+        tile_of(sk_tail_t, p);
+        p->k0 = sk_tail_k0; p->k1 = a.g[p->gi].steps; p->consume = wl - 1; p->publish = 0; p->split = 0;
+        return true;
+      }
+    }
+    return false;
+  };
+
+  Piece P;
+  bool have;
+  if (a.sk) {
+    have = next_piece(&P);
+  } else {
+    int gi = 0;
 #pragma unroll
-  for (int i = 0; i < B_CH; ++i) {   // rows past Ncol re-read the last column (finite, discarded)
-    const int brow = min(n0 + r0 + 32 * i, G.Ncol - 1);
-    b_off[i] = (unsigned)brow * (unsigned)G.K * 4u + (unsigned)c * 16u;
+    for (int i = 1; i < kMaxGroups; ++i)
+      if (i < a.ngroups && (int)blockIdx.x >= a.g[i].blk0) gi = i;
+    const int lb0 = blockIdx.x - a.g[gi].blk0;
+    const int split = lb0 % a.ksplit;          // K range of this block (deterministic split-K)
+    const int lb = lb0 / a.ksplit;
+    // XCD-aware tile order: blocks b and b + 8 share an XCD (and its 4 MB L2).  Inside one XCD's sequence the column
+    // tile runs fastest, so the blocks resident on an XCD cover a few row strips x all column tiles.
+    const int ntn = a.g[gi].ntn;
+    const int full = a.ntm & ~7;
+    if (lb < full * ntn) {
+      const int l = lb >> 3;
+      P.mt = (l / ntn) * 8 + (lb & 7);
+      P.nt = l % ntn;
+    } else {                                   // ragged tail: fewer than 8 row strips left
+      const int r = lb - full * ntn, rem = a.ntm - full;
+      P.mt = full + r % rem;
+      P.nt = r / rem;
+    }
+    const int steps = a.g[gi].steps;
+    P.gi = gi;
+    P.k0 = (int)(((long long)split * steps) / a.ksplit);
+    P.k1 = (int)(((long long)(split + 1) * steps) / a.ksplit);
+    P.consume = -1; P.publish = 0; P.split = split;
+    have = true;
   }
+  if (!have) return;
+
+  // ------------------------------------------------------------------------------------------------------
+  // per-piece loader state
+  // ------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t xs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ws =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 4, 0x00020000);
+  const int c = tid & 3;          // vector path: 16-B chunk inside the 64-B K slab
+  const int r0 = tid >> 2;        // vector path: row 0..63 (+64 i)
+  const int wsw = (c ^ ((r0 >> 2) & 3)) << 2;
+  const int kk = tid & 15;        // gather path: k column inside the stage
+  const int rs = tid >> 4;        // gather path: row 0..15 (+16 i)
+  const int gsw = (((kk >> 2) ^ ((rs >> 2) & 3)) << 2) + (kk & 3);
+  constexpr int NROW = VEC ? A_CH : A_SC;
 
-  const int nsteps_all = G.K >> 5;
-  const int ks0 = (int)(((long long)split * nsteps_all) / a.ksplit);
-  const int ks1 = (int)(((long long)(split + 1) * nsteps_all) / a.ksplit);
-  const int nsteps = ks1 - ks0;
-  const int ncc = VEC ? (a.Cin >> 5) : 1;
-  const int ktrue = G.T * a.Cin;
-  int ld_step = ks0;
-  int ld_t = VEC ? ks0 / ncc : 0, ld_cc = VEC ? ks0 % ncc : 0;
-  unsigned a_off[A_CH];
+  int a_iy0[NROW], a_ix0[NROW];
+  unsigned a_img[NROW];           // byte offset of the row's image (+ chunk), or kOutOfRange for padding rows
+  unsigned a_off[NROW];           // vector path: current tap's byte offset per row
+  unsigned b_off[B_CH];
+  int ld_stage = 0, ld_t = 0, ld_cc = 0;        // next stage to load; vector path: its (tap, channel slab)
+  int ld_ty = 0, ld_tx = 0;                     // vector path: the tap's (row, column) in the group's tw-wide tap grid
+  int g_t = 0, g_ch = 0, g_ty = 0, g_tx = 0;    // gather path: (tap, channel) of this thread's k column
+  int g_T = a.g[P.gi].T, g_tw = a.g[P.gi].tw;   // hot fields of the current piece's group: taps form a dense grid, tap t
+                                                // = (t / tw, t % tw), walked incrementally (no table load in the loop)
+  __amdgpu_buffer_rsrc_t ws =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[P.gi].wp), 0, a.g[P.gi].Ncol * a.g[P.gi].K * 4, 0x00020000);
+  int m0 = 0, n0 = 0;
+  const int ncc = VEC ? (a.Cin >> 4) : 1;
 
-  auto set_tap = [&](int t) {
-    const int tap = G.taps[t];
-    const int ty = tap >> 16, tx = tap & 0xffff;
+  auto set_tap = [&](int ty, int tx) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
+    for (int i = 0; i < NROW; ++i) {
       const int iy = a_iy0[i] + ty * a.tstep;
       const int ix = a_ix0[i] + tx * a.tstep;
       const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a_img[i] & kOutOfRange);
@@ -144,241 +301,375 @@ __global__ void __launch_bounds__(256, 2) gg_kernel(const GGArgs a) {
       a_off[i] = ok ? a_img[i] + pix : kOutOfRange;
     }
   };
-  if (VEC && ld_t < G.T) set_tap(ld_t);
 
-  f32x4 ra[A_CH], rb[B_CH];
-  auto load_regs = [&]() {
+  // rinfo of piece `p` into buffer `rb`; caller synchronises before reading it
+  auto write_rinfo = [&](const Piece& p, int rb) {
+    KArgs& a = fresh_args();
+    int4* rinfo = rinfo_all + rb * BM;
+    const int mbase = p.mt * BM;
+    const int q0y = a.g[p.gi].q0y, q0x = a.g[p.gi].q0x;
+    for (int r = tid; r < BM; r += 256) {
+      const int m = mbase + r;
+      int4 ri = make_int4(0, 0, 0, 0);
+      if (m < a.M) {
+        const int per = a.Qh * a.Qw;
+        const int n = m / per;
+        const int rem = m - n * per;
+        const int qy = rem / a.Qw;
+        ri = make_int4(n, qy + q0y, rem - qy * a.Qw + q0x, 1);   // per-group origin of the macro grid
+      }
+      rinfo[r] = ri;
+    }
+  };
+
+  auto init_loader = [&](const Piece& p, int rb) {
+    KArgs& a = fresh_args();
+    const int4* rinfo = rinfo_all + rb * BM;
+    const auto& G = a.g[p.gi];
+    g_T = G.T;
+    g_tw = G.tw;
+    ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 4, 0x00020000);
+    m0 = p.mt * BM;
+    n0 = p.nt * BN;
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+      const int4 ri = rinfo[VEC ? r0 + 64 * i : rs + 16 * i];
+      a_iy0[i] = ri.y * a.sA + a.offy;
+      a_ix0[i] = ri.z * a.sA + a.offx;
+      a_img[i] = ri.w ? (unsigned)ri.x * (unsigned)(a.H * a.W) * (unsigned)a.Cin * 4u + (VEC ? (unsigned)c * 16u : 0u)
+                      : kOutOfRange;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {   // rows past Ncol re-read the last column (finite, discarded)
+      const int brow = min(n0 + r0 + 64 * i, G.Ncol - 1);
+      b_off[i] = (unsigned)brow * (unsigned)G.K * 4u + (unsigned)c * 16u;
+    }
+    ld_stage = p.k0;
     if (VEC) {
-      const unsigned soff = (unsigned)ld_cc * 128u;
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) ra[i] = buf_load(xs, a_off[i], soff);
+      ld_t = p.k0 / ncc;
+      ld_cc = p.k0 - ld_t * ncc;
+      ld_ty = ld_t / g_tw;
+      ld_tx = ld_t - ld_ty * g_tw;
+      if (ld_t < g_T) set_tap(ld_ty, ld_tx);
     } else {
+      const int k = p.k0 * kStage + kk;
+      g_t = k / a.Cin;
+      g_ch = k - g_t * a.Cin;
+      g_ty = g_t / g_tw;
+      g_tx = g_t - g_ty * g_tw;
+    }
+  };
+
+  struct Regs {
+    f32x4 a[VEC ? A_CH : 1];
+    float s[VEC ? 1 : A_SC];
+    f32x4 b[B_CH];
+  };
+
+  auto load_regs = [&](Regs& R) {
+    if (VEC) {
+      const unsigned soff = (unsigned)ld_cc * 64u;
 #pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < A_CH; ++i) R.a[i] = buf_load(xs, a_off[i], soff);
+    } else {
+      const bool kok = g_t < g_T;
+      const int ty = g_ty * a.tstep, tx = g_tx * a.tstep;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = ld_step * 32 + c * 4 + e;
-          if (k < ktrue && !(a_img[i] & kOutOfRange)) {
-            const int t = k / a.Cin;
-            const int ch = k - t * a.Cin;
-            const int tap = G.taps[t];
-            const int iy = a_iy0[i] + (tap >> 16) * a.tstep;
-            const int ix = a_ix0[i] + (tap & 0xffff) * a.tstep;
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-              v[e] = a.x[(size_t)(a_img[i] >> 2) - c * 4 + ((size_t)iy * a.W + ix) * a.Cin + ch];
-          }
-        }
-        ra[i] = v;
+      for (int i = 0; i < A_SC; ++i) {
+        const int iy = a_iy0[i] + ty;
+        const int ix = a_ix0[i] + tx;
+        const bool ok = kok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a_img[i] & kOutOfRange);
+        const unsigned off = a_img[i] + ((unsigned)(iy * a.W + ix) * (unsigned)a.Cin + (unsigned)g_ch) * 4u;
+        R.s[i] = buf_load1(xs, ok ? off : kOutOfRange);
+      }
+      g_ch += kStage;
+      while (g_ch >= a.Cin) {
+        g_ch -= a.Cin;
+        ++g_t;
+        if (++g_tx == g_tw) { g_tx = 0; ++g_ty; }
       }
     }
-    const unsigned wsoff = (unsigned)ld_step * 128u;
+    const unsigned wsoff = (unsigned)ld_stage * 64u;
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load(ws, b_off[i], wsoff);
-    ++ld_step;
+    for (int i = 0; i < B_CH; ++i)
+      if (BN % 64 == 0 || r0 + 64 * i < BN) R.b[i] = buf_load(ws, b_off[i], wsoff);
+    ++ld_stage;
     if (VEC) {
       if (++ld_cc == ncc) {
         ld_cc = 0;
-        if (++ld_t < G.T) set_tap(ld_t);
+        if (++ld_tx == g_tw) { ld_tx = 0; ++ld_ty; }
+        if (++ld_t < g_T) set_tap(ld_ty, ld_tx);
       }
     }
   };
-  auto write_lds = [&](int buf) {
-    float* Ab = As + buf * BM * 32;
-    float* Bb = Bs + buf * BN * 32;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int r = r0 + 32 * i;
-      f32x4 v = ra[i];
-      if (PRO) {
-        if (a.pro == SNTC_PRO_ABS) {
-          v[0] = fabsf(v[0]); v[1] = fabsf(v[1]); v[2] = fabsf(v[2]); v[3] = fabsf(v[3]);
-        } else if (a.pro == SNTC_PRO_SQUARE) {
-          v = v * v;
-        }
-      }
-      *reinterpret_cast<f32x4*>(Ab + r * 32 + ((c ^ ((r >> 1) & 7)) << 2)) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      const int r = r0 + 32 * i;
-      *reinterpret_cast<f32x4*>(Bb + r * 32 + ((c ^ ((r >> 1) & 7)) << 2)) = rb[i];
-    }
-  };
 
-  f32x16 acc[TM][TN];
+  auto write_lds = [&](const Regs& R, int slot) {
+    float* Ab = ring + slot * SLOT;
+    float* Bb = Ab + BM * kStage;
+    if (VEC) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  const int l31 = lane & 31;
-  const int h = lane >> 5;
-  const int swz = (l31 >> 1) & 7;
-
-  if (nsteps > 0) {
-    load_regs();
-    write_lds(0);
-  }
-  __syncthreads();
-
-  for (int ks = 0; ks < nsteps; ++ks) {
-    const bool more = ks + 1 < nsteps;
-    if (more && !SNTC_DBG(a, 1)) load_regs();
-    const float* Ab = As + (ks & 1) * BM * 32 + (wm * TM * 32 + l31) * 32;
-    const float* Bb = Bs + (ks & 1) * BN * 32 + (wn * TN * 32 + l31) * 32;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int off = ((2 * g + h) ^ swz) << 2;
-      f32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * 32 + off);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * 32 + off);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    }
-    if (more && !SNTC_DBG(a, 2)) write_lds((ks + 1) & 1);
-    if (!SNTC_DBG(a, 4)) __syncthreads();
-  }
-  if (SNTC_DBG(a, 4)) __syncthreads();
-
-  // ---------------- epilogue ----------------
-  // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private 8-KB LDS
-  // slice (the staging buffers are dead after the last barrier) so that every lane owns 4
-  // consecutive channels of one pixel: bias / residual / gate operands are read and the output is
-  // written with 16-B accesses, 256 contiguous bytes per 16 lanes.
-  if (a.ksplit > 1) {
-    // split-K: raw partial sums go to slab[group][split][m][col]; gg_reduce_kernel adds the splits in a
-    // fixed order and applies bias / activation / epilogue, so the result does not depend on scheduling.
-    float* slab = a.slab + G.slab_off + (size_t)split * a.M * G.Ncol;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + l31;
-      if (col >= G.Ncol) continue;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < a.M) slab[(size_t)m * G.Ncol + col] = acc[i][j][r];
-        }
-    }
-    return;
-  }
-  if ((a.Cout & 3) == 0) {
-    static_assert(TM == 1, "wide epilogue assumes one M tile per wave");
-    float* stage = reinterpret_cast<float*>(smem) + wave * 2048;   // 32 rows x 64 floats
-#pragma unroll
-    for (int j0 = 0; j0 < TN; j0 += 2) {
-      const int ct = (TN - j0) >= 2 ? 2 : 1;          // tiles in this chunk
-      const int wfl = ct * 32;                         // chunk width in floats
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        if (jj < ct) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            stage[((r & 3) + 8 * (r >> 2) + 4 * h) * wfl + jj * 32 + l31] = acc[0][j0 + jj][r];
-        }
-      }
-      const int lanes_per_row = wfl >> 2;              // 16 or 8
-      const int rows_per_pass = 64 / lanes_per_row;    // 4 or 8
-      const int c4 = (lane % lanes_per_row) << 2;
-      const int rsub = lane / lanes_per_row;
-      const int col = n0 + (wn * TN + j0) * 32 + c4;
-      const bool col_ok = col < G.Ncol;
-      unsigned ce = 0;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (col_ok) {
-        ce = G.cols[col];
-        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (ce & 0xffff));
-      }
-      const int ch = ce & 0xffff;
-      const int oyo = (int)((ce >> 24) & 0xff) - 128;
-      const int oxo = (int)((ce >> 16) & 0xff) - 128;
-      for (int rp = 0; rp < 32; rp += rows_per_pass) {
-        const int rloc = rp + rsub;
-        const int4 ri = rinfo[wm * 32 + rloc];
-        const int oy = ri.y * a.sO + oyo;
-        const int ox = ri.z * a.sO + oxo;
-        if (!col_ok || !ri.w || (unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
-        const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * wfl + c4) + bv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
-        if (a.epi != SNTC_EPI_STORE) {
-          const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + idx);
-          switch (a.epi) {
-            case SNTC_EPI_ADD: v = v + rs; break;
-            case SNTC_EPI_GATE: v = rs + *reinterpret_cast<const f32x4*>(a.aux + idx) * v; break;
-            case SNTC_EPI_RES_DIV: v = rs / v; break;
-            case SNTC_EPI_RES_MUL: v = rs * v; break;
-            case SNTC_EPI_RES_DIV_SQRT:
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rs[e] / sqrtf(v[e]);
-              break;
-            case SNTC_EPI_RES_MUL_SQRT:
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rs[e] * sqrtf(v[e]);
-              break;
-            case SNTC_EPI_MASK_RELU:
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rs[e] > 0.0f ? v[e] : 0.0f;
-              break;
-            case SNTC_EPI_MASK_LEAKY:
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rs[e] >= 0.0f ? v[e] : 0.2f * v[e];
-              break;
-            default: break;
+      for (int i = 0; i < A_CH; ++i) {
+        f32x4 v = R.a[i];
+        if (PRO) {
+          if (a.pro == SNTC_PRO_ABS) {
+            v[0] = fabsf(v[0]); v[1] = fabsf(v[1]); v[2] = fabsf(v[2]); v[3] = fabsf(v[3]);
+          } else if (a.pro == SNTC_PRO_SQUARE) {
+            v = v * v;
           }
         }
-        *reinterpret_cast<f32x4*>(a.y + idx) = v;
+        *reinterpret_cast<f32x4*>(Ab + (r0 + 64 * i) * kStage + wsw) = v;
       }
-    }
-    return;
-  }
+    } else {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + l31;
-    if (col >= G.Ncol) continue;
-    const unsigned ce = G.cols[col];
-    const int ch = ce & 0xffff;
-    const int oyo = (int)((ce >> 24) & 0xff) - 128;
-    const int oxo = (int)((ce >> 16) & 0xff) - 128;
-    const float bv = a.bias ? a.bias[ch] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int4 ri = rinfo[row];
-        if (!ri.w) continue;
-        const int oy = ri.y * a.sO + oyo;
-        const int ox = ri.z * a.sO + oxo;
-        if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
-        const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
-        float v = apply_act(acc[i][j][r] + bv, a.act);
-        switch (a.epi) {
-          case SNTC_EPI_ADD: v = v + a.res[idx]; break;
-          case SNTC_EPI_GATE: v = a.res[idx] + a.aux[idx] * v; break;
-          case SNTC_EPI_RES_DIV: v = a.res[idx] / v; break;
-          case SNTC_EPI_RES_MUL: v = a.res[idx] * v; break;
-          case SNTC_EPI_RES_DIV_SQRT: v = a.res[idx] / sqrtf(v); break;
-          case SNTC_EPI_RES_MUL_SQRT: v = a.res[idx] * sqrtf(v); break;
-          case SNTC_EPI_MASK_RELU: v = a.res[idx] > 0.0f ? v : 0.0f; break;
-          case SNTC_EPI_MASK_LEAKY: v = a.res[idx] >= 0.0f ? v : 0.2f * v; break;
-          default: break;
+      for (int i = 0; i < A_SC; ++i) {
+        float v = R.s[i];
+        if (PRO) {
+          if (a.pro == SNTC_PRO_ABS) v = fabsf(v);
+          else if (a.pro == SNTC_PRO_SQUARE) v = v * v;
         }
-        a.y[idx] = v;
+        Ab[(rs + 16 * i) * kStage + gsw] = v;
       }
     }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      if (BN % 64 == 0 || r0 + 64 * i < BN)
+        *reinterpret_cast<f32x4*>(Bb + (r0 + 64 * i) * kStage + wsw) = R.b[i];
+  };
+
+  // fragment addresses: row = 32-row block + l31, chunk (2g + h) ^ ((row >> 2) & 3)
+  const int swz = (l31 >> 2) & 3;
+  const int fa_row = (wm * 32 + l31) * kStage;
+  const int fb_row = (BM + wn * TN * 32 + l31) * kStage;
+  const int foff0 = ((0 + h) ^ swz) << 2, foff1 = ((2 + h) ^ swz) << 2;
+
+  struct Frag {
+    f32x4 a;
+    f32x4 b[TN];
+  };
+  auto read_frag = [&](Frag& F, int slot, int g) {
+    const float* base = ring + slot * SLOT;
+    const int off = g ? foff1 : foff0;
+    F.a = *reinterpret_cast<const f32x4*>(base + fa_row + off);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) F.b[j] = *reinterpret_cast<const f32x4*>(base + fb_row + j * 32 * kStage + off);
+  };
+
+  f32x16 acc[TN];
+  auto mfma_group = [&](const Frag& F) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e], F.b[j][e], acc[j], 0, 0, 0);
+  };
+
+  // ------------------------------------------------------------------------------------------------------
+  // the piece loop
+  // ------------------------------------------------------------------------------------------------------
+  int rb = 0;                                  // rinfo buffer of the current piece
+  Regs R0, R1;
+  write_rinfo(P, rb);
+  __syncthreads();
+  init_loader(P, rb);
+  {
+    const int n = P.k1 - P.k0;
+    if (n > 0) load_regs(R0);
+    if (DBUF && n > 1) load_regs(R1);
+  }
+
+  while (true) {
+    const int n = P.k1 - P.k0;
+    // ---- accumulators: zero, or the previous worker's published partial sums (stream-K continuation)
+    if (P.consume >= 0) {
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(a.sk_flags + P.consume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > kSpinLimit) __builtin_trap();      // a neighbour that never published: fail loudly, never hang
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      // slab layout [TN * 4 quads][256 threads][4 floats]: 16 B per lane, 1 KB per wave instruction; addressed through a
+      // buffer descriptor with constant scalar offsets (no per-store 64-bit address registers)
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+          a.sk_slab + (size_t)P.consume * (TN * 16 * 256), 0, TN * 16 * 256 * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = buf_load(sr, (unsigned)tid * 16u, (unsigned)(j * 4 + q) * 4096u);
+          acc[j][4 * q] = v[0]; acc[j][4 * q + 1] = v[1]; acc[j][4 * q + 2] = v[2]; acc[j][4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    }
+
+    // ---- prologue: stages k0, k0+1 -> ring slots 0, 1; stage k0+2 in flight
+    int s_cur = 0, s_n1 = 1, s_n2 = 2;
+    if (n > 0) write_lds(R0, 0);
+    if (DBUF) {
+      if (n > 1) write_lds(R1, 1);
+    } else if (n > 1) {
+      load_regs(R0);
+      write_lds(R0, 1);
+    }
+    if (n > 2) load_regs(R0);
+    __syncthreads();
+    Frag F0, F1;
+    if (DBUF && n > 0) read_frag(F0, 0, 0);
+
+    for (int j = 0; j < n; ++j) {
+      if (j + 2 < n) write_lds(R0, s_n2);          // stage j+2, loaded during step j-1
+      if (j + 3 < n) load_regs(R0);                // stage j+3
+      if (DBUF) {
+        read_frag(F1, s_cur, 1);
+        mfma_group(F0);
+        if (j + 1 < n) read_frag(F0, s_n1, 0);     // first fragments of the next stage, under this stage's MFMAs
+        mfma_group(F1);
+      } else {
+        read_frag(F0, s_cur, 0);
+        mfma_group(F0);
+        read_frag(F0, s_cur, 1);
+        mfma_group(F0);
+      }
+      __syncthreads();
+      const int t = s_cur; s_cur = s_n1; s_n1 = s_n2; s_n2 = t;
+    }
+
+    // ---- the next piece's first stages go in flight before this piece's results are stored
+    Piece Q;
+    const bool more = next_piece(&Q);
+    const int qb = rb ^ 1;
+    const int4* rinfo = rinfo_all + rb * BM;
+    const int m0d = m0, n0d = n0;
+    if (more) {
+      write_rinfo(Q, qb);
+      __syncthreads();
+      init_loader(Q, qb);
+      const int nq = Q.k1 - Q.k0;
+      if (nq > 0) load_regs(R0);
+      if (DBUF && nq > 1) load_regs(R1);
+    }
+
+    // ---- finish the piece that just ran.  Lane constants and kernel arguments of this phase are re-derived from an
+    // opaque copy of the thread id / of the kernel-argument pointer: the compiler would otherwise hoist them out of the
+    // persistent loop and keep ~40 registers alive through the K loop for values that are used once per tile.
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    const int lane = te & 63, wave = te >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    KArgs& a = fresh_args();          // shadows the by-value copy inside this phase
+    const auto& Gd = a.g[P.gi];
+    if (P.publish) {
+      // stream-K hand-off, producer side (cdna_hip_programming.md Guideline 16): plain stores, every wave drains its
+      // stores, workgroup barrier, ONE agent-scope release, then the flag
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+          a.sk_slab + (size_t)wl * (TN * 16 * 256), 0, TN * 16 * 256 * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+          buf_store(sr, v, (unsigned)tid * 16u, (unsigned)(j * 4 + q) * 4096u);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.sk_flags + wl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (a.ksplit > 1) {
+      // split-K: raw partial sums go to slab[group][split][m][col]; gg_reduce_kernel adds the splits in a
+      // fixed order and applies bias / activation / epilogue, so the result does not depend on scheduling.
+      float* slab = a.slab + Gd.slab_off + (size_t)P.split * a.M * Gd.Ncol;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0d + (wn * TN + j) * 32 + l31;
+        if (col >= Gd.Ncol) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0d + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < a.M) slab[(size_t)m * Gd.Ncol + col] = acc[j][r];
+        }
+      }
+    } else if ((a.Cout & 3) == 0) {
+      // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private LDS slice (the stage
+      // ring is idle after the last barrier) so that every lane owns 4 consecutive channels of one pixel: bias /
+      // residual / gate operands are read and the output is written with 16-B accesses.
+      float* stage = ring + wave * EPW;
+#pragma unroll
+      for (int j0 = 0; j0 < TN; j0 += 2) {
+        const int ct = (TN - j0) >= 2 ? 2 : 1;          // tiles in this chunk
+        const int wfl = ct * 32;                         // chunk width in floats
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          if (jj < ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              stage[((r & 3) + 8 * (r >> 2) + 4 * h) * wfl + jj * 32 + l31] = acc[j0 + jj][r];
+          }
+        }
+        const int lanes_per_row = wfl >> 2;              // 16 or 8
+        const int rows_per_pass = 64 / lanes_per_row;    // 4 or 8
+        const int c4 = (lane % lanes_per_row) << 2;
+        const int rsub = lane / lanes_per_row;
+        const int col = n0d + (wn * TN + j0) * 32 + c4;
+        const bool col_ok = col < Gd.Ncol;
+        unsigned ce = 0;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (col_ok) {
+          ce = Gd.cols[col];
+          if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (ce & 0xffff));
+        }
+        const int ch = ce & 0xffff;
+        const int oyo = (int)((ce >> 24) & 0xff) - 128;
+        const int oxo = (int)((ce >> 16) & 0xff) - 128;
+        for (int rp = 0; rp < 32; rp += rows_per_pass) {
+          const int rloc = rp + rsub;
+          const int4 ri = rinfo[wm * 32 + rloc];
+          const int oy = ri.y * a.sO + oyo;
+          const int ox = ri.z * a.sO + oxo;
+          if (!col_ok || !ri.w || (unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
+          const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
+          f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * wfl + c4) + bv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+          if (a.epi != SNTC_EPI_STORE) v = apply_epilogue(v, a.epi, *reinterpret_cast<const f32x4*>(a.res + idx), a.aux, idx);
+          *reinterpret_cast<f32x4*>(a.y + idx) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0d + (wn * TN + j) * 32 + l31;
+        if (col >= Gd.Ncol) continue;
+        const unsigned ce = Gd.cols[col];
+        const int ch = ce & 0xffff;
+        const int oyo = (int)((ce >> 24) & 0xff) - 128;
+        const int oxo = (int)((ce >> 16) & 0xff) - 128;
+        const float bv = a.bias ? a.bias[ch] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int4 ri = rinfo[row];
+          if (!ri.w) continue;
+          const int oy = ri.y * a.sO + oyo;
+          const int ox = ri.z * a.sO + oxo;
+          if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
+          const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
+          a.y[idx] = apply_epilogue1(apply_act(acc[j][r] + bv, a.act), a.epi, a.res, a.aux, idx);
+        }
+      }
+    }
+    if (!more) break;
+    __syncthreads();          // epilogue staging reads done before the next piece's stages land in the ring
+    P = Q;
+    rb = qb;
   }
 }
 
@@ -403,18 +694,7 @@ __global__ void __launch_bounds__(256) gg_reduce_kernel(const GGArgs a) {
     if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
     const size_t idx = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
     v = apply_act(v + (a.bias ? a.bias[ch] : 0.0f), a.act);
-    switch (a.epi) {
-      case SNTC_EPI_ADD: v = v + a.res[idx]; break;
-      case SNTC_EPI_GATE: v = a.res[idx] + a.aux[idx] * v; break;
-      case SNTC_EPI_RES_DIV: v = a.res[idx] / v; break;
-      case SNTC_EPI_RES_MUL: v = a.res[idx] * v; break;
-      case SNTC_EPI_RES_DIV_SQRT: v = a.res[idx] / sqrtf(v); break;
-      case SNTC_EPI_RES_MUL_SQRT: v = a.res[idx] * sqrtf(v); break;
-      case SNTC_EPI_MASK_RELU: v = a.res[idx] > 0.0f ? v : 0.0f; break;
-      case SNTC_EPI_MASK_LEAKY: v = a.res[idx] >= 0.0f ? v : 0.2f * v; break;
-      default: break;
-    }
-    a.y[idx] = v;
+    a.y[idx] = apply_epilogue1(v, a.epi, a.res, a.aux, idx);
   }
 }
 
@@ -433,71 +713,74 @@ int gg_reduce_launch(const GGArgs& args, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 int gg_variant_bm(int v) { return v == 8 ? 64 : 128; }
 int gg_variant_bn(int v) { return v == 8 ? 64 : 32 * v; }
+size_t gg_sk_slab_floats(int v) { return (size_t)(v == 8 ? 1 : v) * 16 * 256; }
 
 static size_t lds_bytes(int v) {
-  return (size_t)2 * (gg_variant_bm(v) + gg_variant_bn(v)) * 32 * sizeof(float) + gg_variant_bm(v) * sizeof(int4);
+  return (size_t)3 * (gg_variant_bm(v) + gg_variant_bn(v)) * kStage * sizeof(float) + 2 * gg_variant_bm(v) * sizeof(int4);
 }
 
-template <int TM, int TN, int WM, int WN>
-static int launch_t(bool vec, bool pro, const GGArgs& args, int nblocks, size_t lds, hipStream_t stream) {
-  if (vec && !pro)
-    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, true, false>), dim3(nblocks), dim3(256), lds, stream, args);
-  else if (vec)
-    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, true, true>), dim3(nblocks), dim3(256), lds, stream, args);
-  else
-    hipLaunchKernelGGL((gg_kernel<TM, TN, WM, WN, false, true>), dim3(nblocks), dim3(256), lds, stream, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
-  return SNTC_OK;
+template <int TN, int WM, int WN>
+static const void* kernel_ptr(bool vec, bool pro) {
+  if (vec && !pro) return reinterpret_cast<const void*>(&gg_kernel<TN, WM, WN, true, false>);
+  if (vec) return reinterpret_cast<const void*>(&gg_kernel<TN, WM, WN, true, true>);
+  return reinterpret_cast<const void*>(&gg_kernel<TN, WM, WN, false, true>);
 }
 
-template <int TM, int TN, int WM, int WN>
-static hipError_t set_attr(size_t lds) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+static const void* variant_kernel(int v, bool vec, bool pro) {
+  switch (v) {
+    case 1: return kernel_ptr<1, 4, 1>(vec, pro);
+    case 2: return kernel_ptr<2, 4, 1>(vec, pro);
+    case 3: return kernel_ptr<3, 4, 1>(vec, pro);
+    case 4: return kernel_ptr<4, 4, 1>(vec, pro);
+    case 5: return kernel_ptr<5, 4, 1>(vec, pro);
+    case 6: return kernel_ptr<6, 4, 1>(vec, pro);
+    case 7: return kernel_ptr<7, 4, 1>(vec, pro);
+    case 8: return kernel_ptr<1, 2, 2>(vec, pro);
+    default: return nullptr;
+  }
 }
+
+static thread_local int g_init_device = -1;
+static thread_local int g_resident[kNumVariants + 1][3];      // per (variant, {vec, vec+pro, gather}) workgroups per device
+static thread_local int g_num_cus = 0;
 
 int gg_init() {
-  static thread_local int done_device = -1;
   int dev = 0;
   SNTC_HIP(hipGetDevice(&dev));
-  if (done_device == dev) return SNTC_OK;
-  SNTC_HIP((set_attr<1, 1, 4, 1>(lds_bytes(1))));
-  SNTC_HIP((set_attr<1, 2, 4, 1>(lds_bytes(2))));
-  SNTC_HIP((set_attr<1, 3, 4, 1>(lds_bytes(3))));
-  SNTC_HIP((set_attr<1, 4, 4, 1>(lds_bytes(4))));
-  SNTC_HIP((set_attr<1, 5, 4, 1>(lds_bytes(5))));
-  SNTC_HIP((set_attr<1, 6, 4, 1>(lds_bytes(6))));
-  SNTC_HIP((set_attr<1, 7, 4, 1>(lds_bytes(7))));
-  SNTC_HIP((set_attr<1, 1, 2, 2>(lds_bytes(8))));
-  done_device = dev;
+  if (g_init_device == dev) return SNTC_OK;
+  hipDeviceProp_t prop;
+  SNTC_HIP(hipGetDeviceProperties(&prop, dev));
+  g_num_cus = prop.multiProcessorCount;
+  for (int v = 1; v <= kNumVariants; ++v) {
+    for (int k = 0; k < 3; ++k) {
+      const void* fn = variant_kernel(v, k < 2, k >= 1);
+      SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(v)));
+      int per_cu = 0;
+      SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes(v)));
+      // the API can answer one workgroup per CU high near an SGPR allocation edge (MI355X_MICROARCH.md, Residency):
+      // stream-K needs every worker resident, so stay at or below 8 and keep the LDS bound exact
+      per_cu = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(v))}));
+      g_resident[v][k] = per_cu * g_num_cus;
+    }
+  }
+  g_init_device = dev;
   return SNTC_OK;
 }
 
-int gg_launch(int variant, bool vec, const GGArgs& args_in, int nblocks, hipStream_t stream) {
-  GGArgs args = args_in;
-#ifdef SNTC_DIAG
-  if (const char* e = getenv("SNTC_GG_DBG")) args.dbg = atoi(e);
-#endif
-  const size_t lds = lds_bytes(variant);
+int gg_resident_blocks(int variant, bool vec, bool pro) {
+  if (variant < 1 || variant > kNumVariants || g_init_device < 0) return 0;
+  return g_resident[variant][!vec ? 2 : (pro ? 1 : 0)];
+}
+
+int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {
   const bool pro = args.pro != SNTC_PRO_NONE;
-  switch (variant) {
-    case 1: return launch_t<1, 1, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 2: return launch_t<1, 2, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 3: return launch_t<1, 3, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 4: return launch_t<1, 4, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 5: return launch_t<1, 5, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 6: return launch_t<1, 6, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 7: return launch_t<1, 7, 4, 1>(vec, pro, args, nblocks, lds, stream);
-    case 8: return launch_t<1, 1, 2, 2>(vec, pro, args, nblocks, lds, stream);
-    default: return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
-  }
+  const void* fn = variant_kernel(variant, vec, pro || !vec);
+  if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
+  GGArgs a = args;
+  void* params[] = {&a};
+  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params, lds_bytes(variant), stream);
+  if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
+  return SNTC_OK;
 }
 
 }  // namespace sntc

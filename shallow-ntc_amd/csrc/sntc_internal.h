@@ -37,16 +37,20 @@ constexpr int kMaxGroups = 4;
 #endif
 
 struct GGGroup {
-  const float* wp;    // [NcolPad][K], K contiguous (K padded to a multiple of 32 with zeros)
+  const float* wp;    // [NcolPad][K], K contiguous (K padded to a multiple of 16 with zeros)
   const int* taps;    // [T]   (ty << 16) | tx
   const int* cols;    // [NcolPad] ((oyoff+128) << 24) | ((oxoff+128) << 16) | ch ; -1 = padding
-  int T;              // taps
+  int T;              // taps: a dense th x tw grid, tap t = (t / tw, t % tw)
+  int tw;             // taps per row of that grid
   int K;              // padded K
   int Ncol;           // real columns
   int ntn;            // N tiles for the launched variant
-  int blk0;           // first block of this group
+  int blk0;           // static mode: first block of this group
   size_t slab_off;    // float offset of this group's split-K slabs [ksplit][M][Ncol]
   int q0y, q0x;       // origin of this group's macro-pixel grid (phase groups whose first valid q is 1)
+  int steps;          // K / 16: K stages of one tile
+  int tile0;          // stream-K: global id of the group's first tile
+  long long unit0;    // stream-K: first work unit (one unit = one K stage of one tile) of the group
 };
 
 struct GGArgs {
@@ -62,20 +66,30 @@ struct GGArgs {
   int sA, tstep, offy, offx, sO;
   int act, epi, pro;
   int ntm;
-  int ksplit;          // >= 1: number of K ranges (blocks per tile)
+  int ksplit;          // static mode, >= 1: number of K ranges (blocks per tile), summed by gg_reduce_kernel
   float* slab;         // split-K partial sums (workspace) or nullptr
-  int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers
+  // Persistent stream-K mode: `nworkers` resident workgroups share the launch's work units evenly;
+  // a tile cut between workers w and w + 1 is CONTINUED, not re-summed: w publishes its accumulators (sk_slab[w],
+  // sk_flags[w]), w + 1 starts its fma chains from them, so every output is the same k-ordered chain as in an unsplit tile.
+  int sk;              // 0: static (one K range of one tile per block); 1: stream-K
+  int nworkers;
+  long long units;     // sum over groups of tiles * steps
+  float* sk_slab;      // [nworkers][256 threads * 16 TN floats], raw accumulators in register layout
+  int* sk_flags;       // [nworkers], zeroed on the stream before the launch
   int ngroups;
   GGGroup g[kMaxGroups];
 };
 
 // variant ids (BM x BN):  1..7 -> 128 x 32*v ;  8 -> 64 x 64
 constexpr int kNumVariants = 8;
+constexpr int kStage = 16;         // K depth of one pipeline stage
 int gg_variant_bm(int v);
 int gg_variant_bn(int v);
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream);
 int gg_reduce_launch(const GGArgs& args, hipStream_t stream);
-int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent)
+int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent), measures occupancy
+int gg_resident_blocks(int variant, bool vec, bool pro);   // workgroups of this instantiation the device keeps resident
+size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off
 
 // ---- deep-factorized prior (entropy.hip, sga.hip) ----
 constexpr int kMaxW = 4;   // max hidden width

@@ -85,6 +85,10 @@ class ConvPlan:
         """Force this plan's gather-GEMM tile variant (0 = heuristic); profiling / tests."""
         capi.call("sntc_conv_plan_set_tile", self._h, int(variant))
 
+    def set_stream_k(self, enabled):
+        """False forces the static one-workgroup-per-tile schedule for this plan (tests: identical bits either way)."""
+        capi.call("sntc_conv_plan_set_schedule", self._h, int(bool(enabled)))
+
     def out_hw(self, h, w):
         ho, wo = C.c_int(), C.c_int()
         capi.call("sntc_conv_out_shape", self._h, h, w, C.byref(ho), C.byref(wo))

@@ -237,3 +237,43 @@ def test_full_width_models_against_the_independent_cpu_restatement(name, shape, 
     x255 = np.rint((x.astype(np.float64) + 0.5) * 255.0)
     psnr = lambda p: 10.0 * np.log10(255.0 ** 2 / ((x255 - p.astype(np.float64)) ** 2).mean(axis=(1, 2, 3)))
     assert np.abs(psnr(px) - psnr(px_ref)).max() < 1e-3
+
+
+@pytest.mark.parametrize("kind,k,s,cin,cout,n,h,w,epi", [
+    ("convT", 3, 1, 480, 640, 18, 32, 48, False),      # 2160 tiles of 270 stages: the decode's largest layer
+    ("convT", 5, 2, 320, 480, 18, 16, 24, False),      # four phase groups, 7.5 column tiles each
+    ("convT", 13, 8, 320, 24, 18, 32, 48, False),      # groups with 40 / 20 / 20 / 10 stages per tile
+    ("conv", 5, 2, 192, 192, 6, 128, 192, False),
+    ("conv", 1, 1, 96, 192, 6, 128, 192, True),        # short K (6 stages) + residual epilogue
+    ("conv", 5, 2, 3, 192, 4, 256, 384, False),        # the RGB first layer: dword gather path
+])
+def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout, n, h, w, epi, dev):
+    """Persistent stream-K workers cut tiles between workgroups and CONTINUE the fma chains (csrc/gather_gemm.hip), so
+    the result must equal the one-workgroup-per-tile schedule bit for bit, for every tile shape, and an image must
+    come out the same alone as inside the batch."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(k * 1000 + cin)
+    x = torch.randn((n, h, w, cin), device=dev, generator=g)
+    wshape = (k, k, cout, cin) if kind == "convT" else (k, k, cin, cout)
+    wk = torch.randn(wshape, device=dev, generator=g) * 0.05
+    b = torch.randn((cout,), device=dev, generator=g)
+    plan = ops.ConvPlan(kind, wk, b, s, "relu" if epi else None, capi.PRO_NONE, capi.EPI_ADD if epi else capi.EPI_STORE)
+    ho, wo = plan.out_hw(h, w)
+    res = torch.randn((n, ho, wo, cout), device=dev, generator=g) if epi else None
+    v_auto, blocks = plan.launch_info(n, h, w)
+    y_sk = plan(x, res=res).clone()
+    plan.set_stream_k(False)
+    _, blocks_static = plan.launch_info(n, h, w)
+    y_static = plan(x, res=res).clone()
+    assert blocks_static > blocks, "the shape was meant to run on the persistent workers"      # stream-K really ran
+    assert torch.equal(y_sk, y_static)
+    plan.set_stream_k(True)
+    for variant in (1, 2, 3, 4, 5, 8):
+        plan.set_tile(variant)
+        assert torch.equal(plan(x, res=res), y_static), variant
+    plan.set_tile(0)
+    one = plan(x[2:3].contiguous(), res=None if res is None else res[2:3].contiguous())
+    assert torch.equal(one, y_static[2:3])
+    torch.cuda.synchronize()
