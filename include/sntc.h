@@ -118,7 +118,7 @@ int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
  * the persistent stream-K workers.  Both schedules produce bit-identical outputs (every element is the same k-ordered
  * fma chain); the switch exists so that a test can assert exactly that. */
 int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int stream_k);
-/* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64) the heuristic picks for this call shape,
+/* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);
 

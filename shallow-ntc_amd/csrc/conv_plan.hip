@@ -333,9 +333,8 @@ static void count_work(const sntc_conv_plan* p, int v, int64_t M, int64_t* tiles
 }
 
 // Tile variant: least padded multiply-adds x (rounds of resident workgroups actually run / rounds of work) -- the second
-// factor is 1 under stream-K, where every worker gets the same number of stages -- with the measured per-variant biases:
-// short contractions (1x1 convolutions, K <= 192) like the 64 x 64 tile, whose four small blocks per CU overlap each
-// other's prologue / epilogue; the 128 x 32 tile stages twice the bytes per MFMA.
+// factor is 1 under stream-K, where every worker gets the same number of stages -- divided by the measured relative MFMA
+// rate of the tile shape.
 static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   Sched best;
   const int64_t M = n * g.Qh * g.Qw;
@@ -345,7 +344,7 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   double best_cost = 1e300;
   for (int v = 1; v <= kNumVariants; ++v) {
     if (p->tile >= 1 && p->tile <= kNumVariants && v != p->tile) continue;
-    if (p->tile == 0 && (v == 6 || v == 7)) continue;   // the two widest tiles run single-buffered (register budget): tests only
+    if (p->tile == 0 && (v == 6 || v == 7 || v == 10)) continue;   // single-buffered / one wave per SIMD: tests only
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
@@ -356,20 +355,26 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     s.units = units;
     // stream-K when every resident worker gets at least one longest tile's worth of stages (then a tile is shared by at
     // most two workers) and the unit count fits the kernel's 32-bit unit arithmetic
-    s.sk = ksplit == 1 && !p->no_stream_k && units < (1LL << 31) && units / resident >= msteps && (resident % 8) == 0;
-    s.workers = s.sk ? resident : 0;
-    s.blocks = s.sk ? resident : tiles * ksplit;
+    // workers: every resident slot, or fewer when the launch is too small to give each of them a longest tile's worth
+    // of stages (an idle slot costs less than a second, half-empty round of whole tiles); a multiple of 8 (XCD dealing)
+    const int64_t fit = msteps > 0 ? units / msteps : 0;
+    const int workers = (int)(std::min<int64_t>(resident, fit) & ~7LL);
+    s.sk = ksplit == 1 && !p->no_stream_k && units < (1LL << 31) && workers >= 8 && 2 * workers >= resident;
+    s.workers = s.sk ? workers : 0;
+    s.blocks = s.sk ? workers : tiles * ksplit;
     double cost = macs;
-    if (!s.sk) {
+    if (s.sk) {
+      cost *= (double)resident / workers;
+    } else {
       const double rounds = (double)(tiles * ksplit) / resident;
       cost *= rounds < 1.0 ? 1.0 / rounds : std::ceil(rounds) / rounds;
       if (tiles * ksplit < 768) cost *= 1.0 + 0.5 * (double)(768 - tiles * ksplit) / 768.0;
     }
-    int kmax = 0;
-    for (int gi = 0; gi < p->ngroups; ++gi) kmax = std::max(kmax, p->g[gi].K);
-    if (v == 8) cost *= kmax <= 192 ? 0.90 : 1.15;
-    if (v == 1) cost *= 1.10;
-    if (v == 7) cost *= 1.08;   // 72 KB of LDS: two blocks per CU
+    // measured MFMA rate of each tile shape on exact-fit layers, relative to 128 x 128 (tools/ab_layers.sh, round 2): a wave
+    // that owns more accumulators reads fewer LDS bytes and stages fewer global bytes per MFMA, and the chip holds a
+    // higher clock for it; 256 x 128 leaves one wave per SIMD and stalls on every barrier
+    static const double kRate[kNumVariants + 1] = {0, 0.86, 0.93, 0.97, 1.00, 0.97, 0.90, 0.85, 0.90, 1.02, 0.40};
+    cost /= kRate[v];
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
@@ -457,12 +462,14 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
     G.tile0 = tile0;
     G.unit0 = unit0;
     nb += G.ntn * a.ntm * sc.ksplit;
-    tile0 += G.ntn * a.ntm;
-    unit0 += (long long)G.ntn * a.ntm * G.steps;
+    tile0 += G.ntn;
+    unit0 += (long long)G.ntn * G.steps;
     G.slab_off = slab_off;
     G.q0y = p->g[gi].q0y; G.q0x = p->g[gi].q0x;
     slab_off += (size_t)sc.ksplit * M * G.Ncol;
   }
+  a.tps = tile0;
+  a.ups = (int)unit0;
   rc = gg_launch(v, p->vec, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
   if (rc || sc.sk || sc.ksplit <= 1) return rc;
   return gg_reduce_launch(a, (hipStream_t)stream);

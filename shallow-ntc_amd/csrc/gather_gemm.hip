@@ -31,6 +31,7 @@
 // Between tiles the next tile's first two stages are in flight while the current tile's epilogue runs.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "sntc_internal.h"
 
 namespace sntc {
@@ -123,19 +124,20 @@ struct Piece {
 };
 
 // workgroups per CU the register budget must allow (= waves per SIMD for 256-thread workgroups): what the LDS ring admits
-constexpr int gg_waves(int tn, int wm) { return wm == 2 || tn == 1 ? 4 : (tn <= 3 ? 3 : 2); }
+constexpr int gg_waves(int tiles) { return tiles == 1 ? 4 : (tiles <= 3 ? 3 : 2); }
 
-template <int TN, int WM, int WN, bool VEC, bool PRO>
-__global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs a) {
-  constexpr int BM = WM * 32;
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO>
+__global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
+  constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int SLOT = (BM + BN) * kStage;            // floats per ring slot: A rows, then B rows, 16 floats each
   constexpr int A_CH = BM / 64;                       // 16-B chunks per thread per stage (A, vector path)
   constexpr int B_CH = (BN + 63) / 64;
   constexpr int A_SC = BM / 16;                       // dwords per thread per stage (A, gather path)
   constexpr int EPW = 32 * (TN >= 2 ? 64 : 32);       // floats of epilogue staging per wave
-  constexpr bool DBUF = TN <= 5;                      // fragment / prologue register double buffering (112+ accumulator
-                                                      // registers leave no room for it: the widest tiles run single-buffered)
+  constexpr bool DBUF = TM * TN <= 8 && TN <= 5;      // fragment double buffering (the two widest 32-row tiles, 96+ accumulator
+                                                      // registers and 7-8 fragment quads, run single-buffered)
+  constexpr bool RBUF = DBUF && TM * TN <= 3;         // second staging register set for a tile's first two stages
   static_assert(3 * SLOT >= 4 * EPW, "epilogue staging must fit in the stage ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ring = reinterpret_cast<float*>(smem);                  // [3][BM + BN][16]
@@ -163,15 +165,20 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
     wl = (w & 7) * (a.nworkers >> 3) + (w >> 3);      // workers on one XCD (b, b + 8, ...) own one contiguous eighth
     const int u_lo = (int)(a.units * wl / a.nworkers);
     const int u_hi = (int)(a.units * (wl + 1) / a.nworkers);
+    // tile order: row strip major, then group, then column tile -- every worker's share mixes the groups (their tiles
+    // differ in length, so a group-major order would hand some workers only short, epilogue-heavy tiles) and one strip's
+    // input rows serve all groups while they are hot in L2
     auto locate = [&](int u, int* t, int* k, int* steps) {
+      const int mt = u / a.ups;
+      const int r = u - mt * a.ups;
       int gi = 0;
 #pragma unroll
       for (int i = 1; i < kMaxGroups; ++i)
-        if (i < a.ngroups && (long long)u >= a.g[i].unit0) gi = i;
-      const int r = u - (int)a.g[gi].unit0;
-      const int lb = r / a.g[gi].steps;
-      *t = a.g[gi].tile0 + lb;
-      *k = r - lb * a.g[gi].steps;
+        if (i < a.ngroups && r >= (int)a.g[i].unit0) gi = i;
+      const int r2 = r - (int)a.g[gi].unit0;
+      const int nt = r2 / a.g[gi].steps;
+      *t = mt * a.tps + a.g[gi].tile0 + nt;
+      *k = r2 - nt * a.g[gi].steps;
       *steps = a.g[gi].steps;
     };
     if (u_hi > u_lo) {
@@ -190,14 +197,15 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
 
   auto tile_of = [&](int t, Piece* p) {          // global tile id -> (group, row strip, column tile): column fastest
     KArgs& a = fresh_args();
+    const int mt = t / a.tps;
+    const int r = t - mt * a.tps;
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroups; ++i)
-      if (i < a.ngroups && t >= a.g[i].tile0) gi = i;
-    const int lb = t - a.g[gi].tile0;
+      if (i < a.ngroups && r >= a.g[i].tile0) gi = i;
     p->gi = gi;
-    p->mt = lb / a.g[gi].ntn;
-    p->nt = lb - p->mt * a.g[gi].ntn;
+    p->mt = mt;
+    p->nt = r - a.g[gi].tile0;
   };
 
   auto next_piece = [&](Piece* p) -> bool {
@@ -296,9 +304,11 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
     for (int i = 0; i < NROW; ++i) {
       const int iy = a_iy0[i] + ty * a.tstep;
       const int ix = a_ix0[i] + tx * a.tstep;
-      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a_img[i] & kOutOfRange);
-      const unsigned pix = (unsigned)(iy * a.W + ix) * (unsigned)a.Cin * 4u;
-      a_off[i] = ok ? a_img[i] + pix : kOutOfRange;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const unsigned pix = ((unsigned)(iy * a.W + ix) * (unsigned)a.Cin * 4u) & 0x7fffffffu;
+      // branch-free: in-range sums stay below 2^31 (host check); a padding row (a_img = 2^31) or a tap outside the image
+      // gets bit 31 and reads zeros from the descriptor's bounds check
+      a_off[i] = (a_img[i] + pix) | (ok ? 0u : kOutOfRange);
     }
   };
 
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
       ld_cc = p.k0 - ld_t * ncc;
       ld_ty = ld_t / g_tw;
       ld_tx = ld_t - ld_ty * g_tw;
-      if (ld_t < g_T) set_tap(ld_ty, ld_tx);
+      set_tap(ld_ty, ld_tx);
     } else {
       const int k = p.k0 * kStage + kk;
       g_t = k / a.Cin;
@@ -395,11 +405,15 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
       if (BN % 64 == 0 || r0 + 64 * i < BN) R.b[i] = buf_load(ws, b_off[i], wsoff);
     ++ld_stage;
     if (VEC) {
-      if (++ld_cc == ncc) {
-        ld_cc = 0;
-        if (++ld_tx == g_tw) { ld_tx = 0; ++ld_ty; }
-        if (++ld_t < g_T) set_tap(ld_ty, ld_tx);
-      }
+      // next stage's channel slab / tap, without a branch (the steady-state loop stays one basic block: the scheduler
+      // can then place every load, LDS write and fragment read between MFMAs); the per-row offsets are recomputed every
+      // stage -- ~10 VALU per row against 1024 MFMA cycles
+      const int wrap = (ld_cc + 1 == ncc) ? 1 : 0;
+      ld_cc = wrap ? 0 : ld_cc + 1;
+      const int wrap2 = (wrap && ld_tx + 1 == g_tw) ? 1 : 0;
+      ld_tx = wrap2 ? 0 : ld_tx + wrap;
+      ld_ty += wrap2;
+      set_tap(ld_ty, ld_tx);
     }
   };
 
@@ -438,28 +452,32 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
 
   // fragment addresses: row = 32-row block + l31, chunk (2g + h) ^ ((row >> 2) & 3)
   const int swz = (l31 >> 2) & 3;
-  const int fa_row = (wm * 32 + l31) * kStage;
+  const int fa_row = (wm * TM * 32 + l31) * kStage;
   const int fb_row = (BM + wn * TN * 32 + l31) * kStage;
   const int foff0 = ((0 + h) ^ swz) << 2, foff1 = ((2 + h) ^ swz) << 2;
 
   struct Frag {
-    f32x4 a;
+    f32x4 a[TM];
     f32x4 b[TN];
   };
   auto read_frag = [&](Frag& F, int slot, int g) {
     const float* base = ring + slot * SLOT;
     const int off = g ? foff1 : foff0;
-    F.a = *reinterpret_cast<const f32x4*>(base + fa_row + off);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) F.a[i] = *reinterpret_cast<const f32x4*>(base + fa_row + i * 32 * kStage + off);
 #pragma unroll
     for (int j = 0; j < TN; ++j) F.b[j] = *reinterpret_cast<const f32x4*>(base + fb_row + j * 32 * kStage + off);
   };
 
-  f32x16 acc[TN];
+  f32x16 acc[TM][TN];
   auto mfma_group = [&](const Frag& F) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e], F.b[j][e], acc[j], 0, 0, 0);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[i][e], F.b[j][e], acc[i][j], 0, 0, 0);
   };
 
   // ------------------------------------------------------------------------------------------------------
@@ -473,7 +491,7 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
   {
     const int n = P.k1 - P.k0;
     if (n > 0) load_regs(R0);
-    if (DBUF && n > 1) load_regs(R1);
+    if (RBUF && n > 1) load_regs(R1);
   }
 
   while (true) {
@@ -493,25 +511,29 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
       // slab layout [TN * 4 quads][256 threads][4 floats]: 16 B per lane, 1 KB per wave instruction; addressed through a
       // buffer descriptor with constant scalar offsets (no per-store 64-bit address registers)
       const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-          a.sk_slab + (size_t)P.consume * (TN * 16 * 256), 0, TN * 16 * 256 * 4, 0x00020000);
+          a.sk_slab + (size_t)P.consume * (TM * TN * 16 * 256), 0, TM * TN * 16 * 256 * 4, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = buf_load(sr, (unsigned)tid * 16u, (unsigned)(j * 4 + q) * 4096u);
-          acc[j][4 * q] = v[0]; acc[j][4 * q + 1] = v[1]; acc[j][4 * q + 2] = v[2]; acc[j][4 * q + 3] = v[3];
-        }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = buf_load(sr, (unsigned)tid * 16u, (unsigned)((i * TN + j) * 4 + q) * 4096u);
+            acc[i][j][4 * q] = v[0]; acc[i][j][4 * q + 1] = v[1]; acc[i][j][4 * q + 2] = v[2]; acc[i][j][4 * q + 3] = v[3];
+          }
     } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
 
     // ---- prologue: stages k0, k0+1 -> ring slots 0, 1; stage k0+2 in flight
     int s_cur = 0, s_n1 = 1, s_n2 = 2;
     if (n > 0) write_lds(R0, 0);
-    if (DBUF) {
+    if (RBUF) {
       if (n > 1) write_lds(R1, 1);
     } else if (n > 1) {
       load_regs(R0);
@@ -522,13 +544,15 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
     Frag F0, F1;
     if (DBUF && n > 0) read_frag(F0, 0, 0);
 
-    for (int j = 0; j < n; ++j) {
-      if (j + 2 < n) write_lds(R0, s_n2);          // stage j+2, loaded during step j-1
-      if (j + 3 < n) load_regs(R0);                // stage j+3
+    // one step = one stage.  WR: stage j+2 goes from registers into the ring; LD: stage j+3's global loads are issued;
+    // PF: the first fragments of stage j+1 are prefetched.  The steady-state steps have all three and no branch.
+    auto step = [&](auto WR, auto LD, auto PF) {
+      if (decltype(WR)::value) write_lds(R0, s_n2);        // stage j+2, loaded during step j-1
+      if (decltype(LD)::value) load_regs(R0);              // stage j+3
       if (DBUF) {
         read_frag(F1, s_cur, 1);
         mfma_group(F0);
-        if (j + 1 < n) read_frag(F0, s_n1, 0);     // first fragments of the next stage, under this stage's MFMAs
+        if (decltype(PF)::value) read_frag(F0, s_n1, 0);   // under this stage's remaining MFMAs
         mfma_group(F1);
       } else {
         read_frag(F0, s_cur, 0);
@@ -536,9 +560,33 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
         read_frag(F0, s_cur, 1);
         mfma_group(F0);
       }
+      if (DBUF && VEC && decltype(WR)::value && decltype(LD)::value && decltype(PF)::value) {
+        // steady state: order the step's memory instructions BETWEEN its MFMAs (mask 0x8 MFMA, 0x200 DS write, 0x20 VMEM
+        // read, 0x100 DS read): an MFMA occupies the pipe for 64 cycles but its issue slot for a few, so everything
+        // placed behind the first one is free; the fragment reads get a full MFMA group to land before they are used
+        constexpr int NW = A_CH + B_CH, NR = TM + TN, NM = 4 * TM * TN;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, NW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);                   // every MFMA of the step is issued before the wave waits
       __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
       const int t = s_cur; s_cur = s_n1; s_n1 = s_n2; s_n2 = t;
-    }
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    for (int j = 0; j + 3 < n; ++j) step(Yes{}, Yes{}, Yes{});
+    if (n >= 3) step(Yes{}, No{}, Yes{});
+    if (n >= 2) step(No{}, No{}, Yes{});
+    if (n >= 1) step(No{}, No{}, No{});
 
     // ---- the next piece's first stages go in flight before this piece's results are stored
     Piece Q;
@@ -552,7 +600,7 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
       init_loader(Q, qb);
       const int nq = Q.k1 - Q.k0;
       if (nq > 0) load_regs(R0);
-      if (DBUF && nq > 1) load_regs(R1);
+      if (RBUF && nq > 1) load_regs(R1);
     }
 
     // ---- finish the piece that just ran.  Lane constants and kernel arguments of this phase are re-derived from an
@@ -568,14 +616,16 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
       // stream-K hand-off, producer side (cdna_hip_programming.md Guideline 16): plain stores, every wave drains its
       // stores, workgroup barrier, ONE agent-scope release, then the flag
       const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-          a.sk_slab + (size_t)wl * (TN * 16 * 256), 0, TN * 16 * 256 * 4, 0x00020000);
+          a.sk_slab + (size_t)wl * (TM * TN * 16 * 256), 0, TM * TN * 16 * 256 * 4, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-          buf_store(sr, v, (unsigned)tid * 16u, (unsigned)(j * 4 + q) * 4096u);
-        }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            buf_store(sr, v, (unsigned)tid * 16u, (unsigned)((i * TN + j) * 4 + q) * 4096u);
+          }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
@@ -592,16 +642,20 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
         const int col = n0d + (wn * TN + j) * 32 + l31;
         if (col >= Gd.Ncol) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0d + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < a.M) slab[(size_t)m * Gd.Ncol + col] = acc[j][r];
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0d + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < a.M) slab[(size_t)m * Gd.Ncol + col] = acc[i][j][r];
+          }
       }
     } else if ((a.Cout & 3) == 0) {
       // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private LDS slice (the stage
       // ring is idle after the last barrier) so that every lane owns 4 consecutive channels of one pixel: bias /
       // residual / gate operands are read and the output is written with 16-B accesses.
       float* stage = ring + wave * EPW;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j0 = 0; j0 < TN; j0 += 2) {
         const int ct = (TN - j0) >= 2 ? 2 : 1;          // tiles in this chunk
@@ -611,7 +665,7 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
           if (jj < ct) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              stage[((r & 3) + 8 * (r >> 2) + 4 * h) * wfl + jj * 32 + l31] = acc[j0 + jj][r];
+              stage[((r & 3) + 8 * (r >> 2) + 4 * h) * wfl + jj * 32 + l31] = acc[i][j0 + jj][r];
           }
         }
         const int lanes_per_row = wfl >> 2;              // 16 or 8
@@ -631,7 +685,7 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
         const int oxo = (int)((ce >> 16) & 0xff) - 128;
         for (int rp = 0; rp < 32; rp += rows_per_pass) {
           const int rloc = rp + rsub;
-          const int4 ri = rinfo[wm * 32 + rloc];
+          const int4 ri = rinfo[(wm * TM + i) * 32 + rloc];
           const int oy = ri.y * a.sO + oyo;
           const int ox = ri.z * a.sO + oxo;
           if (!col_ok || !ri.w || (unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
@@ -654,15 +708,17 @@ __global__ void __launch_bounds__(256, gg_waves(TN, WM)) gg_kernel(const GGArgs 
         const int oxo = (int)((ce >> 16) & 0xff) - 128;
         const float bv = a.bias ? a.bias[ch] : 0.0f;
 #pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const int4 ri = rinfo[row];
           if (!ri.w) continue;
           const int oy = ri.y * a.sO + oyo;
           const int ox = ri.z * a.sO + oxo;
           if ((unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
           const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
-          a.y[idx] = apply_epilogue1(apply_act(acc[j][r] + bv, a.act), a.epi, a.res, a.aux, idx);
+          a.y[idx] = apply_epilogue1(apply_act(acc[i][j][r] + bv, a.act), a.epi, a.res, a.aux, idx);
         }
       }
     }
@@ -711,31 +767,38 @@ int gg_reduce_launch(const GGArgs& args, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // variants + launch
 // ---------------------------------------------------------------------------------------------
-int gg_variant_bm(int v) { return v == 8 ? 64 : 128; }
-int gg_variant_bn(int v) { return v == 8 ? 64 : 32 * v; }
-size_t gg_sk_slab_floats(int v) { return (size_t)(v == 8 ? 1 : v) * 16 * 256; }
+// variant -> (TM, TN, WM, WN): 1..7 one 32-row tile x v column tiles per wave, four waves stacked (128 x 32v);
+// 8: 64 x 64 (2 x 2 waves of 32 x 32); 9: 128 x 128 as 2 x 2 waves of 64 x 64; 10: 256 x 128 as four waves of 64 x 128
+int gg_variant_bm(int v) { return v == 8 ? 64 : v == 10 ? 256 : 128; }
+int gg_variant_bn(int v) { return v == 8 ? 64 : v >= 9 ? 128 : 32 * v; }
+size_t gg_sk_slab_floats(int v) {
+  const int tiles = v == 8 ? 1 : v == 9 ? 4 : v == 10 ? 8 : v;
+  return (size_t)tiles * 16 * 256;
+}
 
 static size_t lds_bytes(int v) {
   return (size_t)3 * (gg_variant_bm(v) + gg_variant_bn(v)) * kStage * sizeof(float) + 2 * gg_variant_bm(v) * sizeof(int4);
 }
 
-template <int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN>
 static const void* kernel_ptr(bool vec, bool pro) {
-  if (vec && !pro) return reinterpret_cast<const void*>(&gg_kernel<TN, WM, WN, true, false>);
-  if (vec) return reinterpret_cast<const void*>(&gg_kernel<TN, WM, WN, true, true>);
-  return reinterpret_cast<const void*>(&gg_kernel<TN, WM, WN, false, true>);
+  if (vec && !pro) return reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true, false>);
+  if (vec) return reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, true, true>);
+  return reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false, true>);
 }
 
 static const void* variant_kernel(int v, bool vec, bool pro) {
   switch (v) {
-    case 1: return kernel_ptr<1, 4, 1>(vec, pro);
-    case 2: return kernel_ptr<2, 4, 1>(vec, pro);
-    case 3: return kernel_ptr<3, 4, 1>(vec, pro);
-    case 4: return kernel_ptr<4, 4, 1>(vec, pro);
-    case 5: return kernel_ptr<5, 4, 1>(vec, pro);
-    case 6: return kernel_ptr<6, 4, 1>(vec, pro);
-    case 7: return kernel_ptr<7, 4, 1>(vec, pro);
-    case 8: return kernel_ptr<1, 2, 2>(vec, pro);
+    case 1: return kernel_ptr<1, 1, 4, 1>(vec, pro);
+    case 2: return kernel_ptr<1, 2, 4, 1>(vec, pro);
+    case 3: return kernel_ptr<1, 3, 4, 1>(vec, pro);
+    case 4: return kernel_ptr<1, 4, 4, 1>(vec, pro);
+    case 5: return kernel_ptr<1, 5, 4, 1>(vec, pro);
+    case 6: return kernel_ptr<1, 6, 4, 1>(vec, pro);
+    case 7: return kernel_ptr<1, 7, 4, 1>(vec, pro);
+    case 8: return kernel_ptr<1, 1, 2, 2>(vec, pro);
+    case 9: return kernel_ptr<2, 2, 2, 2>(vec, pro);
+    case 10: return kernel_ptr<2, 4, 4, 1>(vec, pro);
     default: return nullptr;
   }
 }

@@ -49,8 +49,8 @@ struct GGGroup {
   size_t slab_off;    // float offset of this group's split-K slabs [ksplit][M][Ncol]
   int q0y, q0x;       // origin of this group's macro-pixel grid (phase groups whose first valid q is 1)
   int steps;          // K / 16: K stages of one tile
-  int tile0;          // stream-K: global id of the group's first tile
-  long long unit0;    // stream-K: first work unit (one unit = one K stage of one tile) of the group
+  int tile0;          // stream-K: tiles of the preceding groups inside one row strip
+  long long unit0;    // stream-K: work units (one unit = one K stage of one tile) of the preceding groups inside one strip
 };
 
 struct GGArgs {
@@ -74,14 +74,15 @@ struct GGArgs {
   int sk;              // 0: static (one K range of one tile per block); 1: stream-K
   int nworkers;
   long long units;     // sum over groups of tiles * steps
+  int tps, ups;        // tiles / units per row strip (all groups): tile order is strip-major, then group, then column tile
   float* sk_slab;      // [nworkers][256 threads * 16 TN floats], raw accumulators in register layout
   int* sk_flags;       // [nworkers], zeroed on the stream before the launch
   int ngroups;
   GGGroup g[kMaxGroups];
 };
 
-// variant ids (BM x BN):  1..7 -> 128 x 32*v ;  8 -> 64 x 64
-constexpr int kNumVariants = 8;
+// variant ids (BM x BN):  1..7 -> 128 x 32*v ;  8 -> 64 x 64 ;  9 -> 128 x 128 (64 x 64 per wave) ;  10 -> 256 x 128
+constexpr int kNumVariants = 10;
 constexpr int kStage = 16;         // K depth of one pipeline stage
 int gg_variant_bm(int v);
 int gg_variant_bn(int v);

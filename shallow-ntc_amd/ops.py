@@ -130,7 +130,7 @@ class ConvPlan:
         if prof is not None:
             e1.record()
             v, nb = self.launch_info(n, h, w)
-            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 32 == 0,
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 16 == 0,
                              kind=self.kind, k=self.k[0], s=self.stride, cin=self.cin, cout=self.cout, n=n, h=h, w=w))
         return y
 

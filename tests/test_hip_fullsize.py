@@ -270,7 +270,7 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
     assert blocks_static > blocks, "the shape was meant to run on the persistent workers"      # stream-K really ran
     assert torch.equal(y_sk, y_static)
     plan.set_stream_k(True)
-    for variant in (1, 2, 3, 4, 5, 8):
+    for variant in (1, 2, 3, 4, 5, 8, 9, 10):
         plan.set_tile(variant)
         assert torch.equal(plan(x, res=res), y_static), variant
     plan.set_tile(0)

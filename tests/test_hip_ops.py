@@ -66,7 +66,7 @@ def test_conv_family(case, dev):
     assert plan.flops(n, h, w) == 2 * n * k * k * cin * cout * (h * w if kind in ("convT", "sigup") else ref.shape[1] * ref.shape[2])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_every_tile_variant(variant, dev):
     """Each gather-GEMM instantiation gives the same answer (tile selection is a speed choice only)."""
     from shallow_ntc_amd import _capi, ops

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Run ONE convolution layer repeatedly (for rocprofv3 --pmc / --kernel-trace passes and variant A/B rounds).
+
+    python tools/one_layer.py --kind convT --k 3 --s 1 --cin 480 --cout 640 --n 18 --hw 32 48 [--variant V] [--static]
+        [--reps 30] [--ab 2,3,4]      # --ab: interleaved rounds of several tile variants in one process
+"""
+import argparse
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+
+import __graft_entry__ as graft
+
+graft.load_package()
+from shallow_ntc_amd import _capi as capi
+from shallow_ntc_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kind", default="convT")
+ap.add_argument("--k", type=int, default=3)
+ap.add_argument("--s", type=int, default=1)
+ap.add_argument("--cin", type=int, default=480)
+ap.add_argument("--cout", type=int, default=640)
+ap.add_argument("--n", type=int, default=18)
+ap.add_argument("--hw", type=int, nargs=2, default=[32, 48])
+ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--static", action="store_true")
+ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--ab", default="")
+ap.add_argument("--epi", action="store_true", help="residual-add epilogue")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+h, w = args.hw
+x = torch.randn((args.n, h, w, args.cin), device=dev, generator=g)
+wshape = (args.k, args.k, args.cout, args.cin) if args.kind == "convT" else (args.k, args.k, args.cin, args.cout)
+wk = torch.randn(wshape, device=dev, generator=g) * 0.05
+b = torch.randn((args.cout,), device=dev, generator=g)
+
+
+def make(variant):
+    p = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE)
+    if variant:
+        p.set_tile(variant)
+    if args.static:
+        p.set_stream_k(False)
+    return p
+
+
+variants = [int(v) for v in args.ab.split(",")] if args.ab else [args.variant]
+plans = {v: make(v) for v in variants}
+ho, wo = plans[variants[0]].out_hw(h, w)
+res = torch.randn((args.n, ho, wo, args.cout), device=dev, generator=g) if args.epi else None
+y = torch.empty((args.n, ho, wo, args.cout), device=dev)
+flops = plans[variants[0]].flops(args.n, h, w)
+times = {v: [] for v in variants}
+for rep in range(args.reps + 3):
+    for v in variants:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plans[v](x, res=res, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        if rep >= 3:
+            times[v].append(e0.elapsed_time(e1))
+for v in variants:
+    t = np.array(times[v])
+    vv, nb = plans[v].launch_info(args.n, h, w)
+    print(f"{args.kind} k{args.k} s{args.s} {args.cin}->{args.cout} {args.n}x{h}x{w} variant {vv} blocks {nb}: "
+          f"median {np.median(t):.4f} ms min {t.min():.4f} ms  {flops / np.median(t) / 1e9:.1f} TFLOP/s (min-time {flops / t.min() / 1e9:.1f})")
