@@ -326,6 +326,19 @@ def main():
             train_step=dict(workload="8 x 256x256 per GPU, unoise, Adam + global_clipnorm, gradient all-reduce when N > 1",
                             ms_per_step=round(1e3 * t_train / e2e_steps, 3),
                             images_per_s=round(world * 8 * e2e_steps / t_train, 1), mpixels_per_s=mpx(8 * 256 * 256, t_train)))
+        # the reference's own call pattern (mshyper/models.py:425-433, eval.py): evaluate() one image at a time -- encode,
+        # rate, decode, PSNR (and MS-SSIM) per image.  "serial" synchronises after every image like the reference's eager
+        # loop; the default keeps 4 images in flight on round-robin streams (same numbers, in order).
+        singles = [x[i:i + 1].contiguous() for _ids, x, _hw in batches for i in range(x.shape[0])]
+        b1 = {}
+        keep_q = model._quality_metrics
+        for label, quality, look in (("psnr_only_serial", False, 1), ("psnr_only", False, 4), ("with_msssim_serial", True, 1),
+                                     ("with_msssim", True, 4)):
+            model._quality_metrics = quality
+            t = timed(lambda: list(model.evaluate(singles, lookahead=look)), 2, 1)
+            b1[label] = dict(ms_per_image=round(1e3 * t / 2 / len(singles), 3), mpixels_per_s=round(world * pixels_per_step * 2 / t / 1e6, 2))
+        model._quality_metrics = keep_q
+        regions["evaluate_b1"] = dict(workload=f"{len(singles)} images per GPU, one at a time through Model.evaluate()", **b1)
         rows = []                          # per-image (bpp, psnr, mse) of the rank's set, then ONE all-gather
         for ids, x, hw in batches:
             for d, i in zip(model.evaluate_batched(x), ids):

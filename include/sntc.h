@@ -140,6 +140,13 @@ int sntc_gdn_small(const float* x, int64_t npix, int c, const float* beta, const
 int sntc_two_layer_tail(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind,
                         const float* beta, const float* gamma, const float* w2, const float* b2,
                         int k2, int s2, int cout, float* x_hat, void* stream);
+/* The same tail with the decoder's last steps fused into the launch: crop to h x w (unpad_images, common/image_utils.py:69-71),
+ * floats_to_pixels + quantize_image (common/data_lib.py:48-52, image_utils.py:22-23: (v + .5) * 255, round half to even,
+ * saturate) -> pixels uint8 [n, h, w, 3]; with ref (float [n, h, w, 3], normalised) also sse[n] = integer squared error
+ * of the two quantised images (mse_psnr, image_utils.py:26-38).  No float reconstruction is written. */
+int sntc_two_layer_tail_pixels(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind,
+                               const float* beta, const float* gamma, const float* w2, const float* b2, int k2, int s2,
+                               int cout, int h, int w, const float* ref, uint8_t* pixels, uint64_t* sse, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pixel domain

@@ -346,6 +346,15 @@ class _TwoLayerBase(Transform):
         return ops.two_layer_tail(t, self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
                                   self._w2, self._b2, self._k[1], self._s[1])
 
+    def forward_pixels(self, x, h, w, reference=None):
+        """Decoder form: the synthesis ends in uint8 pixels cropped to h x w (and the integer SSE against ``reference``)
+        in the same launch as the activation and the output layer -- no float image round trip."""
+        if self._built_on != x.device:
+            self.build(x.shape[-1], x.device)
+        t = self._up(x)
+        return ops.two_layer_tail_pixels(t, self._ch, self._has_res, self._act_kind, self._beta, self._gamma, self._w2, self._b2,
+                                         h, w, reference, self._k[1], self._s[1])
+
 
 class TwoLayerSynthesis(_TwoLayerBase):
     """reference transforms.py:298-317."""

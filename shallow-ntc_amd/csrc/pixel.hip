@@ -139,7 +139,12 @@ template <int CH>
 __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __restrict__ t, int hh, int wh, int has_res,
                                                              int act_kind, const float* __restrict__ beta,
                                                              const float* __restrict__ gamma, const float* __restrict__ w2,
-                                                             const float* __restrict__ b2, float* __restrict__ xhat) {
+                                                             const float* __restrict__ b2, float* __restrict__ xhat,
+                                                             int oh, int ow, const float* __restrict__ ref,
+                                                             uint8_t* __restrict__ pix, unsigned long long* __restrict__ sse) {
+  // xhat != NULL: float reconstruction [n, 2hh, 2wh, 3].  pix != NULL: the decoder's last steps fused in -- crop to oh x ow
+  // (unpad_images), (v + .5) * 255, round half to even, saturate -> uint8 [n, oh, ow, 3]; with ref (float [n, oh, ow, 3])
+  // also the per-image integer squared error of the two quantised images (mse_psnr), one u64 atomic per workgroup.
   constexpr int TQ = 16, TH = TQ + 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sh = reinterpret_cast<float*>(smem);   // [TH][TH][CH]
@@ -203,6 +208,7 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
   const int qy = qy0 + ty, qx = qx0 + tx;
   const int ho = 2 * hh, wo = 2 * wh;
   const float bias0 = b2[0], bias1 = b2[1], bias2 = b2[2];
+  unsigned long long se = 0;
 #pragma unroll
   for (int py = 0; py < 2; ++py) {
 #pragma unroll
@@ -233,11 +239,29 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
           }
         }
       }
-      if ((unsigned)oy < (unsigned)ho && (unsigned)ox < (unsigned)wo) {
+      if (xhat && (unsigned)oy < (unsigned)ho && (unsigned)ox < (unsigned)wo) {
         float* dst = xhat + (((int64_t)img * ho + oy) * wo + ox) * 3;
         dst[0] = a0; dst[1] = a1; dst[2] = a2;
       }
+      if (pix && (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow) {
+        const int64_t o = (((int64_t)img * oh + oy) * ow + ox) * 3;
+        const int q0 = to_pixel(a0), q1 = to_pixel(a1), q2 = to_pixel(a2);
+        pix[o] = (uint8_t)q0; pix[o + 1] = (uint8_t)q1; pix[o + 2] = (uint8_t)q2;
+        if (ref) {
+          const int d0 = to_pixel(ref[o]) - q0, d1 = to_pixel(ref[o + 1]) - q1, d2 = to_pixel(ref[o + 2]) - q2;
+          se += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2);
+        }
+      }
     }
+  }
+  if (pix && ref) {                     // integer sum: exact and order-independent
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_down(se, o, 64);
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(sg);      // the gamma table is dead by now
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sse + img, part[0] + part[1] + part[2] + part[3]);
   }
 }
 
@@ -325,7 +349,8 @@ extern "C" int sntc_gdn_small(const float* x, int64_t npix, int c, const float* 
 
 template <int CH>
 static int launch_tail(const float* t, int n, int hh, int wh, int has_res, int act_kind, const float* beta,
-                       const float* gamma, const float* w2, const float* b2, float* x_hat, hipStream_t s) {
+                       const float* gamma, const float* w2, const float* b2, float* x_hat, int oh, int ow, const float* ref,
+                       uint8_t* px, unsigned long long* sse, hipStream_t s) {
   const size_t lds = sizeof(float) * (18 * 18 * CH + CH * CH + CH);
   static thread_local int attr_dev = -1;
   int dev = 0;
@@ -336,16 +361,17 @@ static int launch_tail(const float* t, int n, int hh, int wh, int has_res, int a
     attr_dev = dev;
   }
   dim3 grid((wh + 1 + 15) / 16, (hh + 1 + 15) / 16, n);
+  if (px && ref && sse) SNTC_HIP(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * n, s));
   hipLaunchKernelGGL((two_layer_tail_kernel<CH>), grid, dim3(256), lds, s, t, hh, wh, has_res, act_kind, beta, gamma, w2,
-                     b2, x_hat);
+                     b2, x_hat, oh, ow, ref, px, sse);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }
 
-extern "C" int sntc_two_layer_tail(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind,
-                                   const float* beta, const float* gamma, const float* w2, const float* b2, int k2,
-                                   int s2, int cout, float* x_hat, void* stream) {
-  if (!t || !w2 || !b2 || !x_hat) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail: null argument");
+static int tail_dispatch(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind, const float* beta,
+                         const float* gamma, const float* w2, const float* b2, int k2, int s2, int cout, float* x_hat, int oh,
+                         int ow, const float* ref, uint8_t* px, unsigned long long* sse, void* stream) {
+  if (!t || !w2 || !b2 || (!x_hat && !px)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail: null argument");
   if (n < 1 || hh < 1 || wh < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail: empty input");
   if (k2 != 5 || s2 != 2 || cout != 3)
     return fail(SNTC_ERR_UNSUPPORTED, "sntc_two_layer_tail: only the 5x5 / stride-2 / 3-channel output layer is fused");
@@ -353,11 +379,31 @@ extern "C" int sntc_two_layer_tail(const float* t, int n, int hh, int wh, int ch
   if ((act_kind == 1 || act_kind == 2) && (!beta || !gamma))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail: GDN parameters missing");
   if (n > 65535) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail: batch too large");
+  if (px && (oh < 1 || ow < 1 || oh > 2 * hh || ow > 2 * wh))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_pixels: crop must lie inside the reconstruction");
+  if (ref && !sse) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_pixels: a reference needs an sse output");
   hipStream_t s = (hipStream_t)stream;
   switch (ch) {
-    case 12: return launch_tail<12>(t, n, hh, wh, has_res, act_kind, beta, gamma, w2, b2, x_hat, s);
-    case 24: return launch_tail<24>(t, n, hh, wh, has_res, act_kind, beta, gamma, w2, b2, x_hat, s);
-    case 48: return launch_tail<48>(t, n, hh, wh, has_res, act_kind, beta, gamma, w2, b2, x_hat, s);
+    case 12: return launch_tail<12>(t, n, hh, wh, has_res, act_kind, beta, gamma, w2, b2, x_hat, oh, ow, ref, px, sse, s);
+    case 24: return launch_tail<24>(t, n, hh, wh, has_res, act_kind, beta, gamma, w2, b2, x_hat, oh, ow, ref, px, sse, s);
+    case 48: return launch_tail<48>(t, n, hh, wh, has_res, act_kind, beta, gamma, w2, b2, x_hat, oh, ow, ref, px, sse, s);
     default: return fail(SNTC_ERR_UNSUPPORTED, "sntc_two_layer_tail: hidden channels must be 12, 24 or 48");
   }
+}
+
+extern "C" int sntc_two_layer_tail(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind,
+                                   const float* beta, const float* gamma, const float* w2, const float* b2, int k2,
+                                   int s2, int cout, float* x_hat, void* stream) {
+  if (!x_hat) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail: null argument");
+  return tail_dispatch(t, n, hh, wh, ch, has_res, act_kind, beta, gamma, w2, b2, k2, s2, cout, x_hat, 0, 0, nullptr, nullptr,
+                       nullptr, stream);
+}
+
+extern "C" int sntc_two_layer_tail_pixels(const float* t, int n, int hh, int wh, int ch, int has_res, int act_kind,
+                                          const float* beta, const float* gamma, const float* w2, const float* b2, int k2,
+                                          int s2, int cout, int h, int w, const float* ref, uint8_t* pixels, uint64_t* sse,
+                                          void* stream) {
+  if (!pixels) return fail(SNTC_ERR_BAD_SHAPE, "sntc_two_layer_tail_pixels: null argument");
+  return tail_dispatch(t, n, hh, wh, ch, has_res, act_kind, beta, gamma, w2, b2, k2, s2, cout, nullptr, h, w, ref, pixels,
+                       reinterpret_cast<unsigned long long*>(sse), stream);
 }

@@ -293,4 +293,4 @@ class Codec:
                 raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents {(n, h, w, c)}")
             sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy, ly)
             y_hat = ops.dequant_scale_normal(sym, hyper)
-            return ops.to_pixels(m._synthesis(y_hat), H, W)
+            return m._pixels(y_hat, (H, W))

@@ -266,24 +266,47 @@ class Model:
     def frame_loss_given_latent_rvs(self, image_batch, latent_rvs, training):
         if training:
             raise NotImplementedError("training=True runs through train_step (noise proxies) / itinf_train_step (SGA)")
+        return self._finish_frame(self._launch_frame(image_batch, latent_rvs))
+
+    def _launch_frame(self, image_batch, latent_rvs=None):
+        """Everything of end_to_end_frame_loss(training=False) that runs on the GPU, launched on the current stream with
+        no host synchronisation: -> the pending device results for ``_finish_frame``."""
         x = self._as_device_images(image_batch)
         with torch.cuda.device(self.device):
+            if latent_rvs is None:
+                latent_rvs = self.infer_latent_rvs(x)
             r = self._rate_and_reconstruction(latent_rvs)
             sse, _ = ops.pixels_sse(x, r["recon"])                    # unpad + floats_to_pixels + mse fused
-            host = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)]).cpu().numpy()
-            msssim = self._msssim(x, r["recon"])
-        rd_loss, metrics = self._finish_metrics(x.shape, host[0], host[1], host[2], msssim)
-        metrics.record_image("reconstruction", r["recon"])
+            dev = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)])
+            quality = None
+            h, w = x.shape[1], x.shape[2]
+            if self._msssim_applies(h, w):
+                quality = ops.image_quality_launch(ops.pixels_float(x, h, w), ops.pixels_float(r["recon"], h, w), 255.0)
+        return dict(shape=tuple(x.shape), dev=dev, quality=quality, recon=r["recon"])
+
+    def _finish_frame(self, pending):
+        """Host side of a launched frame: one device -> host copy, then the reference's float32 metric arithmetic."""
+        host = pending["dev"].cpu().numpy()
+        msssim = None
+        if pending["quality"] is not None:
+            sums, counts, single = pending["quality"]
+            msssim = ops.image_quality_finish(sums.cpu().numpy(), counts, single)
+        rd_loss, metrics = self._finish_metrics(pending["shape"], host[0], host[1], host[2], msssim)
+        metrics.record_image("reconstruction", pending["recon"])
         return rd_loss, metrics
+
+    def _msssim_applies(self, h, w):
+        """reference :321-331: (MS-)SSIM of the uint8-quantised images whenever TensorFlow itself can compute it."""
+        if not self._quality_metrics or min(h, w) < 11:
+            return False
+        # the reference switches to ssim_multiscale once either side reaches 160 (:325-329), which TensorFlow itself
+        # rejects when the fifth scale is smaller than the 11 x 11 window; report no MS-SSIM instead of failing the step
+        return not ((h >= 160 or w >= 160) and min(h, w) < 11 * 16)
 
     def _msssim(self, x, recon):
         """Per-image (MS-)SSIM of the uint8-quantised images (reference :321-331), or None."""
         h, w = x.shape[1], x.shape[2]
-        if not self._quality_metrics or min(h, w) < 11:
-            return None
-        if (h >= 160 or w >= 160) and min(h, w) < 11 * 16:
-            # the reference switches to ssim_multiscale once either side reaches 160 (:325-329), which TensorFlow itself
-            # rejects when the fifth scale is smaller than the 11 x 11 window; report no MS-SSIM instead of failing the step
+        if not self._msssim_applies(h, w):
             return None
         return ops.image_quality(ops.pixels_float(x, h, w), ops.pixels_float(recon, h, w), 255.0)
 
@@ -327,14 +350,50 @@ class Model:
         _, metrics = self.end_to_end_frame_loss(image_batch, training=training)
         return metrics
 
-    def evaluate(self, images):
+    def evaluate(self, images, lookahead=4):
         """Reference :415-433: a [B,H,W,3] tensor is evaluated one [1,H,W,3] image at a time, an
-        iterable is taken as is; yields one Metrics per image."""
+        iterable is taken as is; yields one Metrics per image, in order.
+
+        Same numbers as the reference's loop, but not its stalls: up to ``lookahead`` images are in flight on
+        round-robin HIP streams before the oldest one's results are copied to the host, so image i + 1's encoder
+        overlaps image i's decoder tail and the device never waits for Python.  lookahead=1 is the strictly serial
+        reference behaviour."""
         if isinstance(images, (torch.Tensor, np.ndarray)):
             images = [images[i:i + 1] for i in range(images.shape[0])]
-        for img in images:
-            _, metrics = self.end_to_end_frame_loss(img, training=False)
-            yield metrics
+        lookahead = max(1, int(lookahead))
+        if lookahead == 1:
+            for img in images:
+                _, metrics = self.end_to_end_frame_loss(img, training=False)
+                yield metrics
+            return
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_eval_streams", None) is None or len(self._eval_streams) < lookahead:
+                self._eval_streams = [torch.cuda.Stream(device=self.device) for _ in range(lookahead)]
+            inflight = []
+            it = iter(images)
+            k = 0
+            done = False
+            while True:
+                while not done and len(inflight) < lookahead:
+                    try:
+                        img = next(it)
+                    except StopIteration:
+                        done = True
+                        break
+                    st = self._eval_streams[k % lookahead]
+                    k += 1
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        inflight.append((st, self._launch_frame(img)))
+                if not inflight:
+                    break
+                st, pending = inflight.pop(0)
+                with torch.cuda.stream(st):
+                    _, metrics = self._finish_frame(pending)
+                yield metrics
+            for st in self._eval_streams:
+                cur.wait_stream(st)
 
     def evaluate_batched(self, images):
         """Same numbers as ``evaluate`` for same-shaped images, but one launch sequence for the whole
@@ -369,10 +428,19 @@ class Model:
         with torch.cuda.device(self.device):
             hyper = self._hyper_synthesis(z_hat)
             y_hat = ops.dequant_scale_normal(symbols, hyper)
-            recon = self._synthesis(y_hat)
-            if reference is None:
-                return ops.to_pixels(recon, image_hw[0], image_hw[1])
-            sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
+            return self._pixels(y_hat, image_hw, reference)
+
+    def _pixels(self, y_hat, image_hw, reference=None):
+        """synthesis -> unpad -> floats_to_pixels -> quantize_image (reference :297-317) as uint8 [n, H, W, 3], plus the
+        per-image integer SSE when ``reference`` is given.  The two-layer syntheses emit the pixels from their last
+        launch; the others go through the float reconstruction."""
+        if hasattr(self._synthesis, "forward_pixels"):
+            px, sse = self._synthesis.forward_pixels(y_hat, image_hw[0], image_hw[1], reference)
+            return px if reference is None else (px, sse)
+        recon = self._synthesis(y_hat)
+        if reference is None:
+            return ops.to_pixels(recon, image_hw[0], image_hw[1])
+        sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
         return px, sse
 
     # -- bitstream (SURVEY.md 8 f2; the reference itself only estimates the rate) -----------------------

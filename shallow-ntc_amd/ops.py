@@ -159,6 +159,24 @@ def two_layer_tail(t, ch, has_res, act_kind, beta, gamma, w2, b2, k2=5, s2=2):
     return y
 
 
+def two_layer_tail_pixels(t, ch, has_res, act_kind, beta, gamma, w2, b2, h, w, reference=None, k2=5, s2=2):
+    """The same tail with crop + floats_to_pixels + quantize_image (+ integer SSE against ``reference``) fused into the
+    launch: -> (uint8 [n, h, w, 3], int64 sse[n] or None).  No float reconstruction is written."""
+    _check_nhwc(t, ch * (2 if has_res else 1))
+    n, hh, wh, _ = t.shape
+    cout = int(w2.shape[2])
+    px = torch.empty((n, h, w, cout), dtype=torch.uint8, device=t.device)
+    sse = None
+    if reference is not None:
+        _check_nhwc(reference, cout)
+        if tuple(reference.shape) != (n, h, w, cout):
+            raise ValueError(f"reference {tuple(reference.shape)} does not match the decoded size {(n, h, w, cout)}")
+        sse = torch.empty((n,), dtype=torch.int64, device=t.device)
+    capi.call("sntc_two_layer_tail_pixels", _ptr(t), n, hh, wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma), _ptr(w2),
+              _ptr(b2), k2, s2, cout, h, w, _ptr(reference), _ptr(px), _ptr(sse), _stream())
+    return px, sse
+
+
 def pad_reflect(x, hp, wp):
     _check_nhwc(x)
     n, h, w, c = x.shape
@@ -482,10 +500,9 @@ def _avgpool2(x):
     return y
 
 
-def image_quality(a, b, max_val=255.0):
-    """reference mshyper/models.py:321-331 on pixel-valued float images [n,h,w,c]: tf.image.ssim when both
-    sides are < 160, tf.image.ssim_multiscale otherwise.  -> per-image msssim as a float64 host array.
-    The kernels leave per-(image, channel) sums; the 5-factor geometric mean is finished on the host."""
+def image_quality_launch(a, b, max_val=255.0):
+    """Launch part of ``image_quality``: -> (device sums [scales, 2, n, c] float64, per-scale window counts, single-scale flag).
+    Nothing is copied to the host, so several images can be in flight (Model.evaluate's look-ahead)."""
     _check_nhwc(a)
     _check_nhwc(b, a.shape[-1])
     n, h, w, c = a.shape
@@ -497,9 +514,23 @@ def image_quality(a, b, max_val=255.0):
         if k > 0:
             a, b = _avgpool2(a), _avgpool2(b)
         counts.append(_ssim_scale(a, b, max_val, sums[k]))
-    means = sums.cpu().numpy() / np.asarray(counts).reshape(-1, 1, 1, 1)        # [scales, 2, n, c]
+    return sums, counts, single
+
+
+def image_quality_finish(sums_host, counts, single):
+    """Host part: the per-(image, channel) sums of every scale -> per-image (MS-)SSIM (float64 array)."""
+    means = np.asarray(sums_host) / np.asarray(counts).reshape(-1, 1, 1, 1)        # [scales, 2, n, c]
     if single:
         return means[0, 0].mean(axis=-1)
+    scales = means.shape[0]
     factors = [np.maximum(means[k, 1], 0.0) for k in range(scales - 1)] + [np.maximum(means[-1, 0], 0.0)]
     stack = np.stack(factors, axis=-1)                                          # [n, c, scales]
     return np.prod(stack ** np.asarray(MSSSIM_WEIGHTS), axis=-1).mean(axis=-1)
+
+
+def image_quality(a, b, max_val=255.0):
+    """reference mshyper/models.py:321-331 on pixel-valued float images [n,h,w,c]: tf.image.ssim when both
+    sides are < 160, tf.image.ssim_multiscale otherwise.  -> per-image msssim as a float64 host array.
+    The kernels leave per-(image, channel) sums; the 5-factor geometric mean is finished on the host."""
+    sums, counts, single = image_quality_launch(a, b, max_val)
+    return image_quality_finish(sums.cpu().numpy(), counts, single)

@@ -142,9 +142,14 @@ def test_mshyper_model_parity(synth, dev):
     ref_e2e_s = ref_model.frame_loss(w, x, (rz, ry), force_symbols=sym)
     assert (ref_e2e_s["tie_distance"][flip] < 1e-3).all()
     assert abs(m["bpp"] - ref_e2e_s["bpp"]) <= 1e-4 and abs(m["psnr"] - ref_e2e_s["psnr"]) <= 1e-3
-    # evaluate() yields one Metrics per image with the reference's scalar keys
+    # evaluate() yields one Metrics per image with the reference's scalar keys; images kept in flight on several streams
+    # give exactly the numbers of the strictly serial loop, in the same order
     ms = list(model.evaluate(x))
     assert len(ms) == 2 and {"rd_loss", "bpp", "mse", "psnr", "scheduled_lr", "sched_rd_lambda"} <= set(ms[0].scalars)
+    many = [x[i % 2:i % 2 + 1] for i in range(7)]
+    serial = [mm.scalars_float for mm in model.evaluate(many, lookahead=1)]
+    piped = [mm.scalars_float for mm in model.evaluate(many, lookahead=3)]
+    assert serial == piped and serial[0] == ms[0].scalars_float and serial[1] == ms[1].scalars_float
     # codec regions: decode(encode(x)) reproduces the evaluated reconstruction bit for bit
     z_hat, sym, bz, by = model.encode(x)
     px, sse = model.decode(z_hat, sym, (100, 150), reference=torch.from_numpy(x).to(dev))

@@ -331,3 +331,28 @@ def test_split_k_layers(kind, k, s, cin, cout, h, w, act, dev):
     assert torch.equal(plan(xd), got)                                            # run-to-run deterministic
     with pytest.raises(_capi.SntcError):                                         # workspace is mandatory, never silently skipped
         _capi.call("sntc_conv_forward", plan._h, ops._ptr(xd), 3, h, w, ops._ptr(got), None, None, None, 0, ops._stream())
+
+
+@pytest.mark.parametrize("ch,has_res,act", [(12, True, "igdn"), (24, False, "igdn"), (48, False, "relu")])
+def test_two_layer_tail_with_fused_pixel_output(ch, has_res, act, dev):
+    """The decoder form of the tail (crop + floats_to_pixels + quantize_image + integer SSE in the same launch) gives
+    exactly the uint8 pixels and SSE of the float tail followed by the separate pixel kernel, incl. a cropped size."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(ch)
+    n, hh, wh = 2, 21, 19
+    t = (rng.standard_normal((n, hh, wh, ch * (2 if has_res else 1))) * 0.3).astype(np.float32)
+    beta = (1 + 0.3 * rng.random(ch)).astype(np.float32)
+    gamma = (0.05 * rng.random((ch, ch))).astype(np.float32)
+    w2 = (rng.standard_normal((5, 5, 3, ch)) * 0.15).astype(np.float32)
+    b2 = (rng.standard_normal(3) * 0.1).astype(np.float32)
+    kind = ops.TAIL_ACTS[act]
+    td, bd, gd, wd, b2d = (dev_t(a, dev) for a in (t, beta, gamma, w2, b2))
+    recon = ops.two_layer_tail(td, ch, has_res, kind, bd, gd, wd, b2d)
+    for (h, w) in ((2 * hh, 2 * wh), (2 * hh - 5, 2 * wh - 3)):
+        ref = dev_t(rng.uniform(-0.5, 0.5, (n, h, w, 3)).astype(np.float32), dev)
+        sse_want, px_want = ops.pixels_sse(ref, recon, want_pixels=True)
+        px, sse = ops.two_layer_tail_pixels(td, ch, has_res, kind, bd, gd, wd, b2d, h, w, reference=ref)
+        assert torch.equal(px, px_want) and torch.equal(sse, sse_want)
+        px2, none = ops.two_layer_tail_pixels(td, ch, has_res, kind, bd, gd, wd, b2d, h, w)
+        assert none is None and torch.equal(px2, px_want)
+    assert 0 < int(px.min()) or int(px.max()) <= 255        # exercised, values are pixels
