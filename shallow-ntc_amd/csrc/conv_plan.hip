@@ -15,7 +15,7 @@ namespace sntc {
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                     const int* __restrict__ taps, const unsigned* __restrict__ cols,
                                     int T, int Cin, int Cout, int K, int Ncol, int kind, int kw, int s,
-                                    int pt, int pl, int phase_mode) {
+                                    int pt, int pl, int phase_mode, int slab_major) {
   const size_t total = (size_t)Ncol * K;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -23,8 +23,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int k = (int)(idx - (size_t)col * K);
     float v = 0.0f;
     if (k < T * Cin) {
-      const int t = k / Cin;
-      const int ci = k - t * Cin;
+      // K order (csrc/gather_gemm.hip): Cin % 16 == 0 -> channel slab outermost, k = cc * T * 16 + t * 16 + c;
+      // otherwise (dword gather path) tap-major, k = t * Cin + ci
+      int t, ci;
+      if (slab_major) {
+        const int cc = k / (T * 16);
+        const int r = k - cc * T * 16;
+        t = r >> 4;
+        ci = cc * 16 + (r & 15);
+      } else {
+        t = k / Cin;
+        ci = k - t * Cin;
+      }
       const int tap = taps[t];
       const unsigned ce = cols[col];
       const int ch = ce & 0xffff;
@@ -166,7 +176,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, weight, G.wp, G.taps, G.cols,
-                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0);
+                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) {
@@ -228,7 +238,7 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, weight, G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K,
-                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0);
+                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));

@@ -297,7 +297,6 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   __amdgpu_buffer_rsrc_t ws =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[P.gi].wp), 0, a.g[P.gi].Ncol * a.g[P.gi].K * 4, 0x00020000);
   int m0 = 0, n0 = 0;
-  const int ncc = VEC ? (a.Cin >> 4) : 1;
 
   auto set_tap = [&](int ty, int tx) {
 #pragma unroll
@@ -356,8 +355,8 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     }
     ld_stage = p.k0;
     if (VEC) {
-      ld_t = p.k0 / ncc;
-      ld_cc = p.k0 - ld_t * ncc;
+      ld_cc = p.k0 / g_T;
+      ld_t = p.k0 - ld_cc * g_T;
       ld_ty = ld_t / g_tw;
       ld_tx = ld_t - ld_ty * g_tw;
       set_tap(ld_ty, ld_tx);
@@ -408,11 +407,15 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
       // next stage's channel slab / tap, without a branch (the steady-state loop stays one basic block: the scheduler
       // can then place every load, LDS write and fragment read between MFMAs); the per-row offsets are recomputed every
       // stage -- ~10 VALU per row against 1024 MFMA cycles
-      const int wrap = (ld_cc + 1 == ncc) ? 1 : 0;
-      ld_cc = wrap ? 0 : ld_cc + 1;
-      const int wrap2 = (wrap && ld_tx + 1 == g_tw) ? 1 : 0;
-      ld_tx = wrap2 ? 0 : ld_tx + wrap;
-      ld_ty += wrap2;
+      // K order of the vector path: channel slab OUTERMOST, taps inside (k = cc * T * 16 + t * 16 + c): the taps of one
+      // 16-channel slab re-read the same input pixels (a 5x5 / stride-2 layer touches each ~6 times), so they now do it
+      // within T consecutive stages, from L2, instead of T * Cin / 16 stages apart, from HBM
+      const int row_end = (ld_tx + 1 == g_tw) ? 1 : 0;
+      const int tap_end = (ld_t + 1 == g_T) ? 1 : 0;
+      ld_tx = row_end ? 0 : ld_tx + 1;
+      ld_ty = tap_end ? 0 : ld_ty + row_end;
+      ld_t = tap_end ? 0 : ld_t + 1;
+      ld_cc += tap_end;
       set_tap(ld_ty, ld_tx);
     }
   };
@@ -547,12 +550,12 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     // one step = one stage.  WR: stage j+2 goes from registers into the ring; LD: stage j+3's global loads are issued;
     // PF: the first fragments of stage j+1 are prefetched.  The steady-state steps have all three and no branch.
     auto step = [&](auto WR, auto LD, auto PF) {
-      if (decltype(WR)::value) write_lds(R0, s_n2);        // stage j+2, loaded during step j-1
-      if (decltype(LD)::value) load_regs(R0);              // stage j+3
+      if (decltype(WR)::value && !SNTC_DBG(a, 2)) write_lds(R0, s_n2);        // stage j+2, loaded during step j-1
+      if (decltype(LD)::value && !SNTC_DBG(a, 1)) load_regs(R0);              // stage j+3
       if (DBUF) {
-        read_frag(F1, s_cur, 1);
+        if (!SNTC_DBG(a, 8)) read_frag(F1, s_cur, 1);
         mfma_group(F0);
-        if (decltype(PF)::value) read_frag(F0, s_n1, 0);   // under this stage's remaining MFMAs
+        if (decltype(PF)::value && !SNTC_DBG(a, 8)) read_frag(F0, s_n1, 0);   // under this stage's remaining MFMAs
         mfma_group(F1);
       } else {
         read_frag(F0, s_cur, 0);
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
         __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);                   // every MFMA of the step is issued before the wave waits
-      __syncthreads();
+      if (!SNTC_DBG(a, 4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       const int t = s_cur; s_cur = s_n1; s_n1 = s_n2; s_n2 = t;
     };
@@ -840,6 +843,9 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
   const void* fn = variant_kernel(variant, vec, pro || !vec);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
   GGArgs a = args;
+#ifdef SNTC_DIAG
+  if (const char* e = getenv("SNTC_GG_DBG")) a.dbg = atoi(e);   // diagnostic builds only (make DIAG=1): results are WRONG with it
+#endif
   void* params[] = {&a};
   hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params, lds_bytes(variant), stream);
   if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");

@@ -77,6 +77,8 @@ struct GGArgs {
   int tps, ups;        // tiles / units per row strip (all groups): tile order is strip-major, then group, then column tile
   float* sk_slab;      // [nworkers][256 threads * 16 TN floats], raw accumulators in register layout
   int* sk_flags;       // [nworkers], zeroed on the stream before the launch
+  int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
+                       // 8 skip fragment reads -- to see what the K loop waits on; results are meaningless with any bit set
   int ngroups;
   GGGroup g[kMaxGroups];
 };
