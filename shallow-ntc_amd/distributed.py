@@ -91,11 +91,13 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-def gather_rows(local_rows, indices, num_items, device="cpu"):
+def gather_rows(local_rows, indices, num_items, device="cpu", width=None):
     """All-gather per-image metric rows.  local_rows: float array [len(indices), k] for the image
-    ids in ``indices``.  Returns the full [num_items, k] table on every rank, ordered by image id."""
-    local_rows = np.asarray(local_rows, np.float64).reshape(len(indices), -1)
-    k = local_rows.shape[1] if local_rows.size else 0
+    ids in ``indices``.  Returns the full [num_items, k] table on every rank, ordered by image id.
+    ``width``: k, for a rank that may hold no rows at all."""
+    local_rows = np.asarray(local_rows, np.float64)
+    local_rows = local_rows.reshape(len(indices), -1) if local_rows.size else np.zeros((0, width or 0))
+    k = local_rows.shape[1]
     if not dist.is_initialized():
         out = np.full((num_items, k), np.nan)
         out[np.asarray(indices, int)] = local_rows
@@ -116,6 +118,28 @@ def gather_rows(local_rows, indices, num_items, device="cpu"):
         ok = ~np.isnan(g[:, 0])
         out[g[ok, 0].astype(int)] = g[ok, 1:]
     return out
+
+
+def run_units(num_units, fn, device="cpu", width=None):
+    """The sharding driver of every multi-GPU evaluation in this repository (Kodak R-D sweep = (lambda, image) units,
+    BASELINE.json configs[3], reference launch.py:49-50 + mshyper/configs/jpegl.py get_hyper; SGA on Tecnick in batches
+    of 5 = one unit per batch, configs[4], reference common/itinf_lib.py:187-207): unit u -> rank u mod world
+    (``deal_units``), ``fn(u)`` -> a row of floats on the owning rank, then ONE all-gather of the rows.  Returns the
+    full [num_units, width] table on every rank, ordered by unit id -- identical for any world size, because a unit's row
+    depends on the unit alone."""
+    rank, _, world = env_world()
+    if not dist.is_initialized():
+        rank, world = 0, 1
+    mine = deal_units(num_units, rank, world)
+    rows = [np.asarray(fn(u), np.float64).ravel() for u in mine]
+    if width is None:
+        width = len(rows[0]) if rows else 0
+        if dist.is_initialized():                       # a rank without units must still learn the row width
+            w = torch.tensor([width], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            width = int(w.item())
+    local = np.stack(rows) if rows else np.zeros((0, width))
+    return gather_rows(local, mine, num_units, device=device, width=width)
 
 
 class BucketReducer:

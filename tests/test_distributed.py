@@ -142,3 +142,48 @@ def test_bench_launcher_propagates_a_failing_rank():
     r = _run_bench(dict(SNTC_DIST_BACKEND="gloo", SNTC_LAUNCH_CHECK_FAIL_RANK="1"), "--gpus", "2", "--launch-check")
     assert r.returncode != 0
     assert "rank 1 exited" in r.stderr
+
+
+def _units_worker(rank, world, port, num_units, q):
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as graft
+    graft.load_package()
+    from shallow_ntc_amd import distributed as D
+    if world > 1:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        D.init(backend="gloo")
+    calls = []
+
+    def fn(u):                       # a unit's row depends on the unit alone (as an image's metrics do)
+        calls.append(u)
+        lam, img = divmod(u, 5)
+        return [0.1 * lam + 0.01 * img, 30.0 - img, float(u) ** 0.5, lam]
+
+    table = D.run_units(num_units, fn)
+    q.put((rank, table, calls))
+    D.shutdown()
+
+
+def test_unit_dealing_gives_the_same_table_for_any_world_size():
+    """configs[3] / configs[4] drivers (tools/rd_sweep.py, tools/itinf_sweep.py) are `run_units` + a GPU function per unit:
+    1 rank and 2 ranks must produce the same table, every unit computed exactly once, incl. a world larger than the
+    number of units (a rank with nothing to do still takes part in the gather)."""
+    ctx = mp.get_context("spawn")
+    tables = {}
+    for world, num_units in ((1, 13), (2, 13), (2, 1)):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_units_worker, args=(r, world, port, num_units, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        outs = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        seen = sorted(u for _, _, calls in outs for u in calls)
+        assert seen == list(range(num_units))
+        for _, table, _ in outs:
+            assert table.shape == (num_units, 4) and not np.isnan(table).any()
+            np.testing.assert_array_equal(table, outs[0][1])
+        tables[(world, num_units)] = outs[0][1]
+    np.testing.assert_array_equal(tables[(1, 13)], tables[(2, 13)])

@@ -48,14 +48,15 @@ else:
     shapes = ([(512, 768)] * 18 + [(768, 512)] * 6)[:args.images]
     images = [data_lib.normalize_image(data_lib.synthetic_images(1, h, w, seed=100 + i))[0] for i, (h, w) in enumerate(shapes)]
 units = [(li, ii) for li in range(len(args.lambdas)) for ii in range(len(images))]
-mine = D.shard_indices(len(units), rank, world)
 by_lambda = {}
 for d in args.workdirs:                                               # run names carry rd_lambda=<value>
     lam = eval_lib.parse_runname(Path(d).name, parse_numbers=True).get("rd_lambda")
     if lam is not None:
         by_lambda[float(lam)] = d
-models, rows = {}, []
-for u in mine:
+models = {}
+
+
+def evaluate_unit(u):
     li, ii = units[u]
     lam = args.lambdas[li]
     if li not in models:
@@ -64,8 +65,10 @@ for u in mine:
         else:
             models[li] = Model(device=dev, quality_metrics=False, **configs.CONFIGS[args.config](rd_lambda=lam))
     m = models[li].validation_step(images[ii][None]).scalars_float
-    rows.append([m["bpp"], m["psnr"], m["mse"], m["rd_loss"]])
-table = D.gather_rows(rows, mine, len(units), device=dev)
+    return [m["bpp"], m["psnr"], m["mse"], m["rd_loss"]]
+
+
+table = D.run_units(len(units), evaluate_unit, device=dev, width=4)
 if rank == 0:
     curve = []
     for li, lam in enumerate(args.lambdas):
