@@ -416,6 +416,45 @@ def gdn_parameter_variable(value):
     return np.sqrt(np.maximum(np.asarray(value, np.float64) + GDN_PEDESTAL, GDN_PEDESTAL)).astype(np.float32)
 
 
+def irdft_matrix(shape):
+    """tfc's real-DFT kernel basis (tensorflow_compression spectral_ops.irdft_matrix, the matrix behind
+    ``tfc.layers.RDFTParameter``, the default ``kernel_parameter="rdft"`` of tfc.SignalConv2D; reference call sites
+    common/transforms.py:101-112,123-134,152-155,172-175) [DEP: restated from the published definition, NOT verified
+    against a TF-written checkpoint]: the rows of the identity over the kernel's spatial ``shape`` are taken through
+    ``rfftn``; the bins of the last axis that have a distinct conjugate partner are scaled by sqrt(2), everything by
+    1 / sqrt(size); real and imaginary parts are concatenated along the last axis and flattened.  The result M is
+    [size, 2 * prod(shape[:-1]) * (shape[-1] // 2 + 1)] with M @ M.T = I, so that
+        rdft   = M.T @ kernel.reshape(size, cin * cout)         (what the checkpoint stores)
+        kernel = (M @ rdft).reshape(*shape, cin, cout)          (what the layer convolves with)."""
+    shape = tuple(int(v) for v in shape)
+    size = int(np.prod(shape))
+    rank = len(shape)
+    m = np.identity(size, dtype=np.float64).reshape((size,) + shape)
+    f = np.fft.rfftn(m, axes=tuple(range(1, rank + 1)))
+    n = shape[-1]
+    f[..., 1:(n + 1) // 2] *= np.sqrt(2.0)
+    f /= np.sqrt(size)
+    return np.concatenate([f.real, f.imag], axis=-1).reshape(size, -1)
+
+
+def rdft_to_kernel(rdft, spatial, cin, cout):
+    """RDFTParameter variable -> SignalConv2D kernel [kh, kw, cin, cout] (float32)."""
+    m = irdft_matrix(spatial)
+    r = np.asarray(rdft, np.float64)
+    r = r.reshape(r.shape[0], -1)
+    if r.shape[0] != m.shape[1] or r.shape[1] != cin * cout:
+        raise ValueError(f"rdft variable of shape {np.asarray(rdft).shape} does not fit a {tuple(spatial)} x {cin} x {cout} kernel "
+                         f"(expected {m.shape[1]} x {cin * cout}: the half-spectrum real / imaginary layout of irdft_matrix)")
+    return (m @ r).reshape(tuple(spatial) + (cin, cout)).astype(np.float32)
+
+
+def kernel_to_rdft(kernel):
+    """SignalConv2D kernel [kh, kw, cin, cout] -> the RDFTParameter variable [rows, cin * cout] (float32)."""
+    k = np.asarray(kernel, np.float64)
+    m = irdft_matrix(k.shape[:2])
+    return (m.T @ k.reshape(k.shape[0] * k.shape[1], -1)).astype(np.float32)
+
+
 # ------------------------------------------------------------------------------------------ reference Model mapping
 class CheckpointMapper:
     """Collects {our variable name: ndarray} by walking the object graph the way the reference's classes are
@@ -432,6 +471,27 @@ class CheckpointMapper:
         self.out[f"{name}/kernel"] = self.var(self.g.child(node, "kernel"))
         if bias:
             self.out[f"{name}/bias"] = self.var(self.g.child(node, "bias"))
+
+    def signal_conv(self, node, name, spatial, cin, cout, bias=True):     # tfc.SignalConv2D, kernel_parameter="rdft"
+        kp = self.g.path(node, ("_kernel_parameter", "kernel_parameter", "kernel"), "rdft")
+        self.out[f"{name}/kernel"] = rdft_to_kernel(self.var(kp), spatial, cin, cout)
+        if bias:
+            self.out[f"{name}/bias"] = self.var(self.g.child(node, "_bias_parameter", "bias_parameter", "bias"))
+
+    def signal_stack(self, node, prefix, shapes, gdn_names):
+        """tf.keras.Sequential of tfc.SignalConv2D layers whose ``activation`` is a tfc.GDN layer (MBT2018*, BLS2017*:
+        transforms.py:93-175).  ``shapes``: our parameter shapes, which give every kernel's (kh, kw, cin, cout)."""
+        layers = self.g.layers_with_weights(node)
+        nconv = sum(1 for k in shapes if k.endswith("/kernel"))
+        if len(layers) != nconv:
+            raise KeyError(f"{prefix}: expected {nconv} layers with weights, found {len(layers)}")
+        for i, layer in enumerate(layers):
+            kh, kw, cin, cout = shapes[f"layer_{i}/kernel"]
+            self.signal_conv(layer, f"{prefix}layer_{i}", (kh, kw), cin, cout, bias=f"layer_{i}/bias" in shapes)
+            gname = gdn_names.format(i)
+            if f"{gname}/beta" in shapes:
+                act = self.g.child(layer, "_activation") if self.g.has(layer, "_activation") else self.g.child(layer, "activation")
+                self.gdn1(act, prefix + gname)
 
     def residual_block(self, node, name):                     # elic.py:57-64: self._block = Sequential([...])
         convs = self.g.layers_with_weights(self.g.child(node, "_block"))
@@ -503,6 +563,17 @@ class CheckpointMapper:
                 i += 1
 
 
+SIGNAL_STACKS = ("MBT2018Analysis", "MBT2018Synthesis", "BLS2017Analysis", "BLS2017Synthesis")
+
+
+def _transform_shapes(cfg, cin):
+    """Our parameter shapes of a registered transform (kernel sizes / channel counts of every layer)."""
+    from .transforms import class_builder as transform_builder
+    cfg = dict(cfg)
+    t = transform_builder.build(cfg.pop("cls"), **cfg)
+    return t._graph.shapes(cin)[0]
+
+
 SYNTHESIS_MAPPERS = {"TwoLayerResSynthesis": "two_layer_res", "TwoLayerSynthesis": "two_layer", "JPEGLikeSynthesis": "jpeg_like"}
 
 
@@ -522,12 +593,21 @@ def load_reference_checkpoint(prefix, transform_config):
         m.elic_analysis(ana, "analysis/")
     elif a_cls == "CNNAnalysis":
         m.sequential_convs(ana, "analysis/", [f"layer_{i}" for i in range(4)])
+    elif a_cls in SIGNAL_STACKS:
+        m.signal_stack(ana, "analysis/", _transform_shapes(transform_config["analysis"], 3), "gdn_{}")
     else:
-        raise NotImplementedError(f"checkpoint import for analysis {a_cls} (SignalConv2D stores an RDFT-parameterised kernel)")
+        raise NotImplementedError(f"checkpoint import for analysis {a_cls}")
     s_cls = transform_config["synthesis"]["cls"]
-    if s_cls not in SYNTHESIS_MAPPERS:
+    if s_cls in SIGNAL_STACKS:
+        bott = m.out[[k for k in m.out if k.startswith("analysis/") and k.endswith("/kernel")][-1]].shape[-1]
+        m.signal_stack(g.child(model, "_synthesis"), "synthesis/", _transform_shapes(transform_config["synthesis"], bott), "igdn_{}")
+    elif s_cls in SYNTHESIS_MAPPERS:
+        getattr(m, SYNTHESIS_MAPPERS[s_cls])(g.child(model, "_synthesis"), "synthesis/")
+    else:
         raise NotImplementedError(f"checkpoint import for synthesis {s_cls}")
-    getattr(m, SYNTHESIS_MAPPERS[s_cls])(g.child(model, "_synthesis"), "synthesis/")
+    if not g.has(model, "_hyper_analysis"):                    # factorized prior (factorized/models.py): no hyper transforms
+        m.deep_factorized(g.child(model, "_prior"))
+        return m.out
     m.sequential_convs(g.child(model, "_hyper_analysis"), "hyper_analysis/", ["layer_0", "layer_1", "layer_2"])
     m.sequential_convs(g.child(model, "_hyper_synthesis"), "hyper_synthesis/", ["layer_0", "layer_1", "layer_2"])
     m.deep_factorized(g.child(model, "_prior"))
@@ -596,6 +676,23 @@ class _GraphWriter:
                     self.residual_block(branch, f"layer_with_weights-{j}", f"{path}/{lw}/_attention_branch", f"{ours}/branch/rb{j}")
                 self.conv(branch, "layer_with_weights-3", f"{path}/{lw}/_attention_branch", f"{ours}/branch/conv")
 
+    def signal_stack(self, parent, path, ours_prefix, gdn_names):
+        i = 0
+        while f"{ours_prefix}layer_{i}/kernel" in self.w:
+            n = self.add(parent, f"layer_with_weights-{i}")
+            lp = f"{path}/layer_with_weights-{i}"
+            kp = self.add(n, "_kernel_parameter")
+            self.var(kp, "rdft", f"{lp}/_kernel_parameter", kernel_to_rdft(self.w[f"{ours_prefix}layer_{i}/kernel"]))
+            if f"{ours_prefix}layer_{i}/bias" in self.w:
+                self.var(n, "_bias_parameter", lp, self.w[f"{ours_prefix}layer_{i}/bias"])
+            g = ours_prefix + gdn_names.format(i)
+            if g + "/beta" in self.w:
+                act = self.add(n, "_activation")
+                for pname, leaf in (("beta_parameter", "beta"), ("gamma_parameter", "gamma")):
+                    p = self.add(act, pname)
+                    self.var(p, "variable", f"{lp}/_activation/{pname}", gdn_parameter_variable(self.w[f"{g}/{leaf}"]))
+            i += 1
+
     def sequential(self, parent, path, ours_prefix, count):
         for i in range(count):
             self.conv(parent, f"layer_with_weights-{i}", path, f"{ours_prefix}layer_{i}")
@@ -619,6 +716,8 @@ def save_reference_checkpoint(prefix, weights, transform_config, step=0):
         b.elic_analysis(ana)
     elif a_cls == "CNNAnalysis":
         b.sequential(ana, "model/_analysis", "analysis/", 4)
+    elif a_cls in SIGNAL_STACKS:
+        b.signal_stack(ana, "model/_analysis", "analysis/", "gdn_{}")
     else:
         raise NotImplementedError(f"checkpoint export for analysis {a_cls}")
     syn = b.add(model, "_synthesis")
@@ -635,10 +734,13 @@ def save_reference_checkpoint(prefix, weights, transform_config, step=0):
             b.gdn1(c1, "model/_synthesis/conv1", "synthesis/act")
     elif s_cls == "JPEGLikeSynthesis":
         b.conv(syn, "conv", "model/_synthesis", "synthesis/conv")
+    elif s_cls in SIGNAL_STACKS:
+        b.signal_stack(syn, "model/_synthesis", "synthesis/", "igdn_{}")
     else:
         raise NotImplementedError(f"checkpoint export for synthesis {s_cls}")
-    for tname in ("_hyper_analysis", "_hyper_synthesis"):
-        b.sequential(b.add(model, tname), f"model/{tname}", f"{tname[1:]}/", 3)
+    if "hyper_analysis/layer_0/kernel" in weights:             # the factorized-prior model has no hyper transforms
+        for tname in ("_hyper_analysis", "_hyper_synthesis"):
+            b.sequential(b.add(model, tname), f"model/{tname}", f"{tname[1:]}/", 3)
     base = b.add(b.add(model, "_prior"), "_base")
     for kind, ours in (("_matrices", "matrix"), ("_biases", "bias"), ("_factors", "factor")):
         lst = b.add(base, kind)

@@ -180,8 +180,10 @@ def test_reference_model_mapping(tmp_path):
     # the walk fails loudly, naming what it saw, when the graph differs
     with pytest.raises(KeyError, match="children"):
         ck.load_reference_checkpoint(prefix, dict(tc, synthesis=dict(cls="JPEGLikeSynthesis")))
+    with pytest.raises(KeyError):               # an ELIC graph read as a SignalConv2D stack: wrong layer count / no rdft variable
+        ck.load_reference_checkpoint(prefix, dict(tc, analysis=dict(cls="MBT2018Analysis", channels_base=8)))
     with pytest.raises(NotImplementedError):
-        ck.load_reference_checkpoint(prefix, dict(tc, analysis=dict(cls="MBT2018Analysis")))
+        ck.load_reference_checkpoint(prefix, dict(tc, analysis=dict(cls="NoSuchAnalysis")))
 
 
 @pytest.mark.parametrize("analysis,synthesis", [
@@ -207,3 +209,62 @@ def test_writer_is_the_inverse_of_the_reader(tmp_path, analysis, synthesis):
         hand = ck.read_bundle(_reference_like_checkpoint(tmp_path / "hand", w))
         ours = ck.read_bundle(prefix)
         assert {k for k in hand if k.endswith(ck.VAR_SUFFIX)} == {k for k in ours if k.endswith(ck.VAR_SUFFIX)}
+
+
+def test_rdft_basis_is_a_parseval_frame_and_round_trips_kernels():
+    """tfc.RDFTParameter (default kernel_parameter of tfc.SignalConv2D; reference common/transforms.py:101-175): the basis
+    M satisfies M M^T = I for every kernel shape the reference uses, kernel -> rdft -> kernel is the identity, and the
+    DC coefficient is the kernel sum / sqrt(size).  [Restated from the published definition; unverified against TF.]"""
+    from shallow_ntc_amd.common import tf_checkpoint as tc
+    rng = np.random.default_rng(0)
+    for shape in ((5, 5), (9, 9), (3, 3), (4, 6), (1, 1), (2, 5)):
+        m = tc.irdft_matrix(shape)
+        size = shape[0] * shape[1]
+        assert m.shape == (size, 2 * shape[0] * (shape[1] // 2 + 1))
+        np.testing.assert_allclose(m @ m.T, np.eye(size), atol=1e-12)
+        k = rng.standard_normal(shape + (3, 4)).astype(np.float32)
+        r = tc.kernel_to_rdft(k)
+        assert r.shape == (m.shape[1], 12)
+        np.testing.assert_allclose(tc.rdft_to_kernel(r, shape, 3, 4), k, atol=2e-6)
+        np.testing.assert_allclose(r[0], k.reshape(size, -1).sum(0) / np.sqrt(size), rtol=1e-5, atol=1e-6)   # DC term
+    # a pure cosine along x lives in exactly one real coefficient: the basis really is the DFT, not just any frame
+    yy, xx = np.mgrid[0:5, 0:5]
+    k = np.cos(2 * np.pi * xx / 5.0)[..., None, None].astype(np.float32)
+    r = tc.kernel_to_rdft(k)[:, 0]
+    assert (np.abs(r) > 1e-5).sum() == 1 and abs(np.abs(r).max() - np.sqrt(25 / 2)) < 1e-4
+    with pytest.raises(ValueError):
+        tc.rdft_to_kernel(np.zeros((25, 12), np.float32), (5, 5), 3, 4)          # square layout: not TFC's frame
+
+
+@pytest.mark.parametrize("which", ["mbt2018", "bls2017"])
+def test_signal_conv_checkpoints_round_trip(which, tmp_path):
+    """BASELINE configs 1 and 2: a hand-built TensorBundle whose SignalConv2D kernels are stored as RDFT variables and
+    whose GDN parameters are reparameterised comes back as the effective weights (object-graph walk of the Sequential
+    stacks of reference common/transforms.py:93-175; bls2017 is the factorized-prior model without hyper transforms)."""
+    from oracle import model_np
+    from shallow_ntc_amd.common import tf_checkpoint as tc
+    if which == "mbt2018":
+        tconf = dict(analysis=dict(cls="MBT2018Analysis", channels_base=8, output_channels=12),
+                     synthesis=dict(cls="MBT2018Synthesis", channels_base=8))
+        ref = model_np.Model(tconf)
+    else:
+        tconf = dict(analysis=dict(cls="BLS2017Analysis", num_filters=8), synthesis=dict(cls="BLS2017Synthesis", num_filters=8))
+        ref = model_np.Model(tconf, factorized=True)
+    w = ref.init_params(5)
+    rng = np.random.default_rng(1)
+    for k in w:                                  # non-trivial GDN parameters and biases
+        if k.endswith("/beta"):
+            w[k] = (1 + rng.random(w[k].shape)).astype(np.float32)
+        elif k.endswith("/gamma"):
+            w[k] = (0.1 * rng.random(w[k].shape)).astype(np.float32)
+        elif k.endswith("/bias"):
+            w[k] = rng.standard_normal(w[k].shape).astype(np.float32)
+    prefix = tc.save_reference_checkpoint(tmp_path / "ckpt-7", w, tconf, step=7)
+    raw = tc.read_bundle(prefix)
+    rdft_keys = [k for k in raw if "/rdft/" in k]
+    assert len(rdft_keys) == sum(1 for k in w if k.endswith("/kernel") and k.split("/")[0] in ("analysis", "synthesis"))
+    assert all(raw[k].shape[0] in (30, 90) for k in rdft_keys)          # 5x5 -> 2*5*3 rows, 9x9 -> 2*9*5 rows
+    got = tc.load_reference_checkpoint(prefix, tconf)
+    assert set(got) == set(w)
+    for k in w:
+        np.testing.assert_allclose(got[k], w[k], rtol=2e-6, atol=2e-6, err_msg=k)
