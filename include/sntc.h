@@ -83,7 +83,10 @@ typedef struct sntc_conv_desc {
   int32_t act;         /* SNTC_ACT_*                                       */
   int32_t prologue;    /* SNTC_PRO_*                                       */
   int32_t epilogue;    /* SNTC_EPI_*                                       */
-  int32_t reserved[7];
+  int32_t reserved[7]; /* reserved[0] != 0: the kernel array has its two channel axes swapped with respect to the kind's
+                        * native layout (so that the input-gradient plan of a layer -- the adjoint kind -- packs straight
+                        * from the layer's own kernel array; Keras Conv2D <-> Conv2DTranspose are each other's swap already,
+                        * tfc.SignalConv2D down <-> up need the flag); the rest must be 0 */
 } sntc_conv_desc;
 
 typedef struct sntc_conv_plan sntc_conv_plan;
@@ -344,6 +347,27 @@ int sntc_prior_record_floats(const sntc_prior* prior);
 int sntc_prior_update(sntc_prior* prior, const float* matrices, const float* biases, const float* factors, void* stream);
 int sntc_prior_param_grad(const sntc_prior* prior, const float* matrices, const float* factors, const float* grad_record,
                           float weight, float* g_matrices, float* g_biases, float* g_factors, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training of the GDN / SignalConv2D stacks (MBT2018*, BLS2017*: reference common/transforms.py:93-175 under
+ * Model.train_step, mshyper/models.py:375-383).  GDN with alpha = 1, epsilon = 1 (the reference's GDN1, :8-63):
+ * norm = beta + |x| gamma comes from a 1x1 convolution plan with the |x| prologue; these are the element-wise parts.
+ *   sntc_gdn_apply:            y = x / norm (inverse: x * norm)
+ *   sntc_gdn_backward_prep:    q = d loss / d norm = -g x / norm^2 (inverse: g x);  abs_x = |x|
+ *   sntc_gdn_backward_finish:  dx = g / norm (inverse: g * norm) + sign(x) * t,  t = q gamma^T from the adjoint 1x1 plan
+ * d beta = column sums of q (sntc_bias_grad), d gamma = |x|^T q (sntc_conv_wgrad, 1x1).
+ * ------------------------------------------------------------------------------------------ */
+int sntc_gdn_apply(const float* x, const float* norm, int64_t total, int inverse, float* y, void* stream);
+int sntc_gdn_backward_prep(const float* g, const float* x, const float* norm, int64_t total, int inverse, float* q, float* abs_x,
+                           void* stream);
+int sntc_gdn_backward_finish(const float* g, const float* x, const float* norm, const float* t, int64_t total, int inverse,
+                             float* dx, void* stream);
+/* out[rows, cols] = a[rows, k] b[k, cols] (transpose_a: a is [k, rows]) for a small left matrix (<= 48 KB): the
+ * tfc.RDFTParameter of SignalConv2D kernels (transforms.py:101-112), kernel = M rdft and d rdft = M^T d kernel. */
+int sntc_small_matmul(const float* a, const float* b, int rows, int k, int64_t cols, int transpose_a, float* out, void* stream);
+/* dst[t, b, a] = src[t, a, b]: sntc_conv_wgrad of a SNTC_SIGNAL_UP layer returns [kh, kw, Cout, Cin]; its kernel is
+ * [kh, kw, Cin, Cout] (tfc.SignalConv2D, transforms.py:123-134,172-175). */
+int sntc_transpose_last2(const float* src, int taps, int a, int b, float* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -166,7 +166,8 @@ def gdn_raw(effective, minimum):
 
 
 # ---- the training loss -----------------------------------------------------------------------------
-def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num_filters=(3, 3), gdn_raw_names=(), uq="unoise"):
+def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num_filters=(3, 3), gdn_raw_names=(), uq="unoise",
+                   factorized=False):
     """params: {name: ndarray} (Model.get_weights() naming; entries listed in ``gdn_raw_names`` hold the RAW
     reparameterised GDN variable as ``(array, minimum)``).  x NHWC in [-0.5, 0.5]; noise_* NHWC in (-.5, .5).
     -> dict(loss, bpp, mse, bits_z[n], bits_y[n], recon NHWC, grads {name: ndarray})."""
@@ -189,6 +190,23 @@ def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num
     n, _, h, w = xt.shape
     y = analysis(T.sub_params(eff, "analysis/"), xt, be=_SELF)
     b = y.shape[1]
+    if factorized:        # factorized/models.py:89-183 with training=True: the deep-factorized prior codes y + noise
+        s = dict(transform_config["synthesis"])
+        synthesis = T.build(s.pop("cls"), cin=b, **s)
+        nl = len(num_filters) + 1
+        mats = [eff[f"prior/matrix_{k}"] for k in range(nl)]
+        biases = [eff[f"prior/bias_{k}"] for k in range(nl)]
+        factors = [eff[f"prior/factor_{k}"] for k in range(nl - 1)]
+        y_t = y + as_input(noise_y)
+        bits_y = noisy_deep_factorized_bits(y_t.permute(0, 2, 3, 1), mats, biases, factors).sum(dim=(1, 2, 3))
+        recon = synthesis(T.sub_params(eff, "synthesis/"), y_t, be=_SELF)
+        bpp = bits_y.mean() / (h * w)
+        mse = ((255.0 * (xt - recon)) ** 2).mean(dim=(1, 2, 3)).mean()
+        loss = bpp + rd_lambda * mse
+        grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+        return dict(loss=float(loss.detach()), bpp=float(bpp.detach()), mse=float(mse.detach()), bits_z=np.zeros(n),
+                    bits_y=bits_y.detach().numpy(), recon=to_nhwc(recon), y=to_nhwc(y), z=None,
+                    grads={k: (np.zeros(tuple(leaves[k].shape)) if g is None else g.numpy()) for k, g in zip(leaves, grads)})
     ha = dict(transform_config.get("hyper_analysis", dict(cls="HyperAnalysis", bottleneck_size=b)))
     hs = dict(transform_config.get("hyper_synthesis", dict(cls="HyperSynthesis", bottleneck_size=b)))
     s = dict(transform_config["synthesis"])

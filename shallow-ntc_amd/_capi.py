@@ -103,6 +103,11 @@ SIGNATURES = {
     "sntc_gdn_reparam_backward": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P]),
     "sntc_noisy_normal": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P]),
     "sntc_noisy_factorized": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
+    "sntc_gdn_apply": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
+    "sntc_gdn_backward_prep": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P]),
+    "sntc_gdn_backward_finish": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    "sntc_small_matmul": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "sntc_transpose_last2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_prior_record_floats": (C.c_int, [_P]),
     "sntc_prior_update": (C.c_int, [_P, _P, _P, _P, _P]),
     "sntc_prior_param_grad": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P]),

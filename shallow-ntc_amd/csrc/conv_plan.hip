@@ -15,7 +15,7 @@ namespace sntc {
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                     const int* __restrict__ taps, const unsigned* __restrict__ cols,
                                     int T, int Cin, int Cout, int K, int Ncol, int kind, int kw, int s,
-                                    int pt, int pl, int phase_mode, int slab_major) {
+                                    int pt, int pl, int phase_mode, int slab_major, int out_major) {
   const size_t total = (size_t)Ncol * K;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -44,7 +44,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         kx = ((int)((ce >> 16) & 0xff) - 128 + pl) + kx * s;
       }
       const size_t tapi = (size_t)ky * kw + kx;
-      v = (kind == SNTC_CONV2D_TRANSPOSE) ? w[(tapi * Cout + ch) * Cin + ci] : w[(tapi * Cin + ci) * Cout + ch];
+      v = out_major ? w[(tapi * Cout + ch) * Cin + ci] : w[(tapi * Cin + ci) * Cout + ch];
     }
     wp[idx] = v;
   }
@@ -73,6 +73,7 @@ struct sntc_conv_plan {
   } g[kMaxGroups];
   float* bias = nullptr;
   int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
+  bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
 };
 
@@ -176,7 +177,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, weight, G.wp, G.taps, G.cols,
-                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0);
+                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) {
@@ -216,6 +217,9 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
     p->pl = d.kw / 2;
   }
   p->vec = (d.cin % kStage) == 0;
+  // Keras Conv2DTranspose stores [kh, kw, Cout, Cin]; everything else [kh, kw, Cin, Cout] -- unless the caller says the
+  // array is the channel-transposed one (the adjoint of a SignalConv2D layer runs on the layer's own kernel array)
+  p->out_major = (d.kind == SNTC_CONV2D_TRANSPOSE) != (d.reserved[0] != 0);
   rc = build_plan(p, weight, bias, (hipStream_t)stream);
   if (rc) {
     sntc_conv_plan_destroy(p);
@@ -238,7 +242,7 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, weight, G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K,
-                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0);
+                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));

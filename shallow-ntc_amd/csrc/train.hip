@@ -127,6 +127,67 @@ __global__ void __launch_bounds__(256) reparam_backward_kernel(const float* __re
   }
 }
 
+// ---- GDN / IGDN layers of the analysis / synthesis stacks (tfc.GDN with alpha = 1, epsilon = 1 -- the reference's GDN1,
+// common/transforms.py:8-63): norm_j = beta_j + sum_i |x_i| gamma_ij comes from a 1x1 gather-GEMM plan (|x| prologue);
+// the element-wise rest of forward and backward lives here.
+//   forward:  y = x / norm                 inverse: y = x * norm
+//   backward: q = d loss / d norm = -g x / norm^2   (inverse: g x);   t = q gamma^T (adjoint 1x1 plan);
+//             dx = g / norm (inverse: g norm) + sign(x) t;   d beta = sum_p q;   d gamma_ij = sum_p |x_i| q_j
+__global__ void __launch_bounds__(256) gdn_apply_kernel(const float* __restrict__ x, const float* __restrict__ norm, int64_t total,
+                                                        int inverse, float* __restrict__ y) {
+  SNTC_GRID_STRIDE(i, total) y[i] = inverse ? x[i] * norm[i] : x[i] / norm[i];
+}
+__global__ void __launch_bounds__(256) gdn_bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           const float* __restrict__ norm, int64_t total, int inverse,
+                                                           float* __restrict__ q, float* __restrict__ absx) {
+  SNTC_GRID_STRIDE(i, total) {
+    const float n = norm[i];
+    q[i] = inverse ? g[i] * x[i] : -g[i] * x[i] / (n * n);
+    absx[i] = fabsf(x[i]);
+  }
+}
+__global__ void __launch_bounds__(256) gdn_bwd_finish_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                             const float* __restrict__ norm, const float* __restrict__ t,
+                                                             int64_t total, int inverse, float* __restrict__ dx) {
+  SNTC_GRID_STRIDE(i, total) {
+    const float xv = x[i];
+    const float sgn = xv > 0.0f ? 1.0f : (xv < 0.0f ? -1.0f : 0.0f);
+    dx[i] = (inverse ? g[i] * norm[i] : g[i] / norm[i]) + sgn * t[i];
+  }
+}
+
+// out[r, c] = sum_k A[r, k] B[k, c] (transpose_a: A[k, r]) for a SMALL A (<= 96 x 96, e.g. the real-DFT basis of a 9x9
+// kernel) and a wide B: tfc.RDFTParameter, kernel = M rdft and d rdft = M^T d kernel (tf_checkpoint.irdft_matrix)
+__global__ void __launch_bounds__(256) small_matmul_kernel(const float* __restrict__ A, const float* __restrict__ B, int R, int K,
+                                                           int64_t C, int transpose_a, float* __restrict__ out) {
+  extern __shared__ float sa[];                       // [R][K]
+  for (int i = threadIdx.x; i < R * K; i += blockDim.x) {
+    const int r = i / K, k = i - r * K;
+    sa[i] = transpose_a ? A[(size_t)k * R + r] : A[i];
+  }
+  __syncthreads();
+  SNTC_GRID_STRIDE(c, C) {
+    for (int r = 0; r < R; ++r) {
+      float acc = 0.0f;
+      for (int k = 0; k < K; ++k) acc = fmaf(sa[r * K + k], B[(size_t)k * C + c], acc);
+      out[(size_t)r * C + c] = acc;
+    }
+  }
+}
+
+// dst[t, b, a] = src[t, a, b]  (the weight gradient of an up-sampling SignalConv2D comes out channel-transposed)
+__global__ void __launch_bounds__(256) transpose_last2_kernel(const float* __restrict__ src, int taps, int A, int B,
+                                                              float* __restrict__ dst) {
+  const int64_t total = (int64_t)taps * A * B;
+  SNTC_GRID_STRIDE(i, total) {
+    const int b = (int)(i % B);
+    const int64_t r = i / B;
+    const int a = (int)(r % A);
+    const int t = (int)(r / A);
+    dst[((int64_t)t * B + b) * A + a] = src[i];
+  }
+}
+
 }  // namespace sntc
 
 using namespace sntc;
@@ -216,6 +277,49 @@ extern "C" int sntc_gdn_reparam_forward(const float* raw, int64_t total, float b
 extern "C" int sntc_gdn_reparam_backward(const float* raw, const float* g_eff, int64_t total, float bound, float* g_raw, void* stream) {
   if (!raw || !g_eff || !g_raw || total < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_gdn_reparam_backward: bad argument");
   hipLaunchKernelGGL(reparam_backward_kernel, dim3(tr_grid(total)), dim3(256), 0, (hipStream_t)stream, raw, g_eff, total, bound, g_raw);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_gdn_apply(const float* x, const float* norm, int64_t total, int inverse, float* y, void* stream) {
+  if (!x || !norm || !y || total < 0) return fail(SNTC_ERR_BAD_SHAPE, "sntc_gdn_apply: bad argument");
+  if (total == 0) return SNTC_OK;
+  hipLaunchKernelGGL(gdn_apply_kernel, dim3(tr_grid(total)), dim3(256), 0, (hipStream_t)stream, x, norm, total, inverse, y);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_gdn_backward_prep(const float* g, const float* x, const float* norm, int64_t total, int inverse, float* q,
+                                      float* abs_x, void* stream) {
+  if (!g || !x || !norm || !q || !abs_x || total < 0) return fail(SNTC_ERR_BAD_SHAPE, "sntc_gdn_backward_prep: bad argument");
+  if (total == 0) return SNTC_OK;
+  hipLaunchKernelGGL(gdn_bwd_prep_kernel, dim3(tr_grid(total)), dim3(256), 0, (hipStream_t)stream, g, x, norm, total, inverse, q, abs_x);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_gdn_backward_finish(const float* g, const float* x, const float* norm, const float* t, int64_t total,
+                                        int inverse, float* dx, void* stream) {
+  if (!g || !x || !norm || !t || !dx || total < 0) return fail(SNTC_ERR_BAD_SHAPE, "sntc_gdn_backward_finish: bad argument");
+  if (total == 0) return SNTC_OK;
+  hipLaunchKernelGGL(gdn_bwd_finish_kernel, dim3(tr_grid(total)), dim3(256), 0, (hipStream_t)stream, g, x, norm, t, total, inverse, dx);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_small_matmul(const float* a, const float* b, int rows, int k, int64_t cols, int transpose_a, float* out,
+                                 void* stream) {
+  if (!a || !b || !out || rows < 1 || k < 1 || cols < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_small_matmul: bad argument");
+  if ((size_t)rows * k * sizeof(float) > 48 * 1024) return fail(SNTC_ERR_UNSUPPORTED, "sntc_small_matmul: the left matrix must fit 48 KB of LDS");
+  hipLaunchKernelGGL(small_matmul_kernel, dim3(tr_grid(cols)), dim3(256), (size_t)rows * k * sizeof(float), (hipStream_t)stream, a, b,
+                     rows, k, cols, transpose_a, out);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_transpose_last2(const float* src, int taps, int a, int b, float* dst, void* stream) {
+  if (!src || !dst || taps < 1 || a < 1 || b < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_transpose_last2: bad argument");
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3(tr_grid((int64_t)taps * a * b)), dim3(256), 0, (hipStream_t)stream, src, taps, a, b, dst);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }

@@ -282,7 +282,7 @@ struct WGGeo {
   bool x_is_S;
 };
 
-// kind: SNTC_CONV2D / SNTC_CONV2D_TRANSPOSE; (h, w) = spatial size of the layer INPUT x
+// kind: SNTC_CONV2D / SNTC_CONV2D_TRANSPOSE / SNTC_SIGNAL_DOWN / SNTC_SIGNAL_UP; (h, w) = spatial size of the layer INPUT x
 int wg_geometry(int kind, int kh, int kw, int stride, int cin, int cout, int h, int w, WGGeo* g) {
   if (kh < 1 || kw < 1 || stride < 1 || cin < 1 || cout < 1 || h < 1 || w < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_wgrad: bad sizes");
   if (kind == SNTC_CONV2D) {                       // Keras SAME: out = ceil(in / s), pad_before = pad_total / 2
@@ -290,8 +290,15 @@ int wg_geometry(int kind, int kh, int kw, int stride, int cin, int cout, int h, 
     *g = WGGeo{h, w, cin, ho, wo, cout, std::max((ho - 1) * stride + kh - h, 0) / 2, std::max((wo - 1) * stride + kw - w, 0) / 2, true};
   } else if (kind == SNTC_CONV2D_TRANSPOSE) {      // Keras SAME: out = in * s, pad_before = max(k - s, 0) / 2
     *g = WGGeo{h * stride, w * stride, cout, h, w, cin, std::max(kh - stride, 0) / 2, std::max(kw - stride, 0) / 2, false};
+  } else if (kind == SNTC_SIGNAL_DOWN) {           // tfc same_zeros, corr=True: centred kernel, pad_before = k / 2
+    const int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
+    *g = WGGeo{h, w, cin, ho, wo, cout, kh / 2, kw / 2, true};
+  } else if (kind == SNTC_SIGNAL_UP) {             // tfc same_zeros, corr=False, strides_up: out[s i + j - (k-1)/2] += x[i] w[j]
+    // dW comes out as [kh, kw, Cout, Cin] (high-resolution side first), i.e. channel-transposed with respect to the
+    // SignalConv2D kernel [kh, kw, Cin, Cout]: the caller transposes the last two axes (sntc_transpose_last2)
+    *g = WGGeo{h * stride, w * stride, cout, h, w, cin, (kh - 1) / 2, (kw - 1) / 2, false};
   } else {
-    return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_wgrad: only Conv2D / Conv2DTranspose (Keras SAME) layers are trainable here");
+    return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_wgrad: unknown layer kind");
   }
   if (g->Cd % 4) return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_wgrad: the low-resolution side needs a channel count divisible by 4");
   return SNTC_OK;

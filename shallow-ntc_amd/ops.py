@@ -48,11 +48,14 @@ def to_device(a, device):
 class ConvPlan:
     """One packed convolution (sntc_conv_plan): Conv2D / Conv2DTranspose / SignalConv2D (+GDN pool)."""
 
-    def __init__(self, kind, weight, bias, stride, act=None, prologue=capi.PRO_NONE, epilogue=capi.EPI_STORE):
+    def __init__(self, kind, weight, bias, stride, act=None, prologue=capi.PRO_NONE, epilogue=capi.EPI_STORE,
+                 kernel_io_swapped=False):
+        """``kernel_io_swapped``: ``weight`` has its two channel axes swapped with respect to the kind's own layout -- the
+        input-gradient plan of a tfc.SignalConv2D layer (the adjoint kind) packs straight from the layer's kernel array."""
         capi.require_gpu()
         w = weight
         kh, kw = int(w.shape[0]), int(w.shape[1])
-        if kind == "convT":
+        if (kind == "convT") != bool(kernel_io_swapped):
             cout, cin = int(w.shape[2]), int(w.shape[3])
         else:
             cin, cout = int(w.shape[2]), int(w.shape[3])
@@ -60,6 +63,7 @@ class ConvPlan:
         self.epilogue = epilogue
         desc = capi.ConvDesc(kind=KINDS[kind], kh=kh, kw=kw, stride=int(stride), cin=cin, cout=cout,
                              act=ACTS[act], prologue=prologue, epilogue=epilogue)
+        desc.reserved[0] = 1 if kernel_io_swapped else 0
         w = w.contiguous()
         b = None if bias is None else bias.contiguous()
         self._h = C.c_void_p()
@@ -453,6 +457,40 @@ def sumsq(x):
     out = torch.empty((1,), dtype=torch.float64, device=x.device)
     capi.call("sntc_sumsq", _ptr(x), x.numel(), _ptr(out), _stream())
     return out
+
+
+def gdn_apply(x, norm, inverse):
+    y = torch.empty_like(x)
+    capi.call("sntc_gdn_apply", _ptr(x), _ptr(norm), x.numel(), int(inverse), _ptr(y), _stream())
+    return y
+
+
+def gdn_backward_prep(g, x, norm, inverse):
+    """-> (q = d loss / d norm, |x|)"""
+    q, ax = torch.empty_like(x), torch.empty_like(x)
+    capi.call("sntc_gdn_backward_prep", _ptr(g), _ptr(x), _ptr(norm), x.numel(), int(inverse), _ptr(q), _ptr(ax), _stream())
+    return q, ax
+
+
+def gdn_backward_finish(g, x, norm, t, inverse):
+    dx = torch.empty_like(x)
+    capi.call("sntc_gdn_backward_finish", _ptr(g), _ptr(x), _ptr(norm), _ptr(t), x.numel(), int(inverse), _ptr(dx), _stream())
+    return dx
+
+
+def small_matmul(a, b, out, transpose_a=False):
+    """out[rows, cols] = a @ b (transpose_a: a.T @ b) for a small ``a``; all 2-D contiguous float32 device tensors."""
+    k, cols = int(b.shape[0]), int(b.shape[1])
+    rows = int(a.shape[1] if transpose_a else a.shape[0])
+    capi.call("sntc_small_matmul", _ptr(a), _ptr(b), rows, k, cols, int(transpose_a), _ptr(out), _stream())
+    return out
+
+
+def transpose_last2(src, dst):
+    """dst[t, b, a] = src[t, a, b] for 3-D views of contiguous tensors."""
+    t, a, b = (int(v) for v in src.shape)
+    capi.call("sntc_transpose_last2", _ptr(src), t, a, b, _ptr(dst), _stream())
+    return dst
 
 
 def two_layer_hidden(t, ch, has_res, act_kind, beta, gamma):

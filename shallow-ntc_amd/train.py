@@ -88,24 +88,43 @@ class FlatStore:
 
 
 class TConv:
-    """One trainable convolution: forward plan, adjoint plan, weight / bias gradients."""
+    """One trainable convolution: forward plan, adjoint plan, weight / bias gradients.
 
-    def __init__(self, store, name, kind, k, s, cin, cout, act, bias, add_res=False, adj_epilogue=capi.EPI_STORE):
-        if kind not in ("conv", "convT"):
-            raise NotImplementedError(f"{name}: {kind} layers (tfc.SignalConv2D, RDFT-reparameterised) are not trainable here")
+    Keras Conv2D / Conv2DTranspose train their kernel directly.  tfc.SignalConv2D ("sigdown" / "sigup",
+    common/transforms.py:101-175) trains the real-DFT coefficients of its kernel (tfc.RDFTParameter, the layer's default):
+    the store holds ``<name>/rdft`` [rows, cin * cout]; kernel = M rdft is recomputed at every refresh and the weight
+    gradient is pulled back with M^T (M = tf_checkpoint.irdft_matrix of the kernel's spatial shape), so Adam moves the
+    same variables as in the reference."""
+
+    def __init__(self, store, name, kind, k, s, cin, cout, act, bias, add_res=False, adj_epilogue=capi.EPI_STORE, rdft_basis=None):
         self.name, self.kind, self.k, self.s, self.cin, self.cout, self.act = name, kind, k, s, cin, cout, act
-        self.W, self.gW = store.p(f"{name}/kernel"), store.g(f"{name}/kernel")
+        self.signal = kind in ("sigdown", "sigup")
+        if self.signal:
+            if k % 2 == 0:
+                raise NotImplementedError(f"{name}: even SignalConv2D kernels are not used by the reference")
+            self.M = rdft_basis                                        # [k * k, rows] device tensor
+            self.rdft, self.g_rdft = store.p(f"{name}/rdft"), store.g(f"{name}/rdft")
+            self.W = torch.empty((k, k, cin, cout), dtype=torch.float32, device=self.rdft.device)
+            self.gW = torch.empty_like(self.W)
+            self._gT = torch.empty((k, k, cout, cin), dtype=torch.float32, device=self.rdft.device) if kind == "sigup" else None
+            ops.small_matmul(self.M, self.rdft, self.W.view(k * k, cin * cout))
+        else:
+            self.W, self.gW = store.p(f"{name}/kernel"), store.g(f"{name}/kernel")
         self.b = store.p(f"{name}/bias") if bias else None
         self.gb = store.g(f"{name}/bias") if bias else None
         self.fwd_plan = ops.ConvPlan(kind, self.W, self.b, s, act, capi.PRO_NONE, capi.EPI_ADD if add_res else capi.EPI_STORE)
-        # kernel [kh,kw,Cin,Cout] of a Conv2D == kernel [kh,kw,Cout',Cin'] of its adjoint Conv2DTranspose (and vice versa)
+        # kernel [kh,kw,Cin,Cout] of a Conv2D == kernel [kh,kw,Cout',Cin'] of its adjoint Conv2DTranspose (and vice versa);
+        # SignalConv2D down / up are adjoints of each other on the channel-swapped kernel array
         # adj_epilogue: what the input-gradient launch does on the way out --
         #   EPI_MASK_RELU  multiply by 1[x > 0], x = this layer's input: the producer's relu backward rides along
         #   EPI_ADD        add a second gradient (the skip path of a ResidualBlock)
         self.adj_epilogue = adj_epilogue
-        self.adj_plan = ops.ConvPlan("convT" if kind == "conv" else "conv", self.W, None, s, None, capi.PRO_NONE, adj_epilogue)
+        self.adj_kind = {"conv": "convT", "convT": "conv", "sigdown": "sigup", "sigup": "sigdown"}[kind]
+        self.adj_plan = ops.ConvPlan(self.adj_kind, self.W, None, s, None, capi.PRO_NONE, adj_epilogue, kernel_io_swapped=self.signal)
 
     def refresh(self):
+        if self.signal:
+            ops.small_matmul(self.M, self.rdft, self.W.view(self.k * self.k, self.cin * self.cout))
         self.fwd_plan.update(self.W, self.b)
         self.adj_plan.update(self.W, None)
 
@@ -117,7 +136,13 @@ class TConv:
         x, y = ctx
         if self.act is not None and not act_folded:
             g = ops.act_backward(g, y, self.act)
-        ops.conv_wgrad(self.kind, self.k, self.s, self.cin, self.cout, x, g, self.gW)
+        if self.kind == "sigup":               # comes out [k, k, Cout, Cin]: transpose to the layer's [k, k, Cin, Cout]
+            ops.conv_wgrad(self.kind, self.k, self.s, self.cin, self.cout, x, g, self._gT)
+            ops.transpose_last2(self._gT.view(self.k * self.k, self.cout, self.cin), self.gW)
+        else:
+            ops.conv_wgrad(self.kind, self.k, self.s, self.cin, self.cout, x, g, self.gW)
+        if self.signal:                         # d loss / d rdft = M^T d loss / d kernel
+            ops.small_matmul(self.M, self.gW.view(self.k * self.k, self.cin * self.cout), self.g_rdft, transpose_a=True)
         if self.gb is not None:
             ops.bias_grad(g, self.gb)
         if not need_dx:
@@ -141,7 +166,7 @@ class TSeq:
             a, b = items[i], items[i + 1]
             if isinstance(a, TConv) and isinstance(b, TConv) and a.act == "relu" and b.adj_epilogue == capi.EPI_STORE:
                 b.adj_epilogue = capi.EPI_MASK_RELU
-                b.adj_plan = ops.ConvPlan("convT" if b.kind == "conv" else "conv", b.W, None, b.s, None, capi.PRO_NONE, capi.EPI_MASK_RELU)
+                b.adj_plan = ops.ConvPlan(b.adj_kind, b.W, None, b.s, None, capi.PRO_NONE, capi.EPI_MASK_RELU, kernel_io_swapped=b.signal)
                 self.folded[i] = True
 
     def fwd(self, x):
@@ -161,6 +186,59 @@ class TSeq:
 
     def convs(self):
         return [c for it in self.items for c in it.convs()]
+
+
+class TGDN:
+    """tfc.GDN / the reference's GDN1 inside an analysis / synthesis stack (common/transforms.py:8-63,150,170), alpha = 1,
+    epsilon = 1:  y = x / (beta + |x| gamma)  (inverse: x * (...)), with tfc's non-negative reparameterisation of beta
+    and gamma.  The norm pool and its adjoint are 1x1 gather-GEMM plans on the effective gamma; d gamma = |x|^T q is a
+    1x1 weight gradient, d beta a column sum (q = d loss / d norm)."""
+
+    def __init__(self, store, name, channels, inverse):
+        self.name, self.c, self.inverse = name, channels, bool(inverse)
+        self.beta_raw, self.g_beta_raw = store.p(f"{name}/beta_raw"), store.g(f"{name}/beta_raw")
+        self.gamma_raw, self.g_gamma_raw = store.p(f"{name}/gamma_raw"), store.g(f"{name}/gamma_raw")
+        self.beta, self.gamma = torch.empty_like(self.beta_raw), torch.empty_like(self.gamma_raw)
+        self.g_beta, self.g_gamma = torch.empty_like(self.beta_raw), torch.empty_like(self.gamma_raw)
+        self.pedestal = GDN_OFFSET ** 2
+        self.beta_bound = math.sqrt(GDN_BETA_MIN + self.pedestal)
+        self.gamma_bound = GDN_OFFSET
+        self._effective()
+        g4 = self.gamma.view(1, 1, channels, channels)                   # gamma[in, out] = a 1x1 kernel [1, 1, Cin, Cout]
+        self.norm_plan = ops.ConvPlan("conv", g4, self.beta, 1, None, capi.PRO_ABS, capi.EPI_STORE)
+        self.adj_plan = ops.ConvPlan("conv", g4, None, 1, None, capi.PRO_NONE, capi.EPI_STORE, kernel_io_swapped=True)
+
+    def _effective(self):
+        capi.call("sntc_gdn_reparam_forward", ops._ptr(self.beta_raw), self.beta_raw.numel(), self.beta_bound, self.pedestal,
+                  ops._ptr(self.beta), ops._stream())
+        capi.call("sntc_gdn_reparam_forward", ops._ptr(self.gamma_raw), self.gamma_raw.numel(), self.gamma_bound, self.pedestal,
+                  ops._ptr(self.gamma), ops._stream())
+
+    def refresh(self):
+        self._effective()
+        g4 = self.gamma.view(1, 1, self.c, self.c)
+        self.norm_plan.update(g4, self.beta)
+        self.adj_plan.update(g4, None)
+
+    def fwd(self, x):
+        norm = self.norm_plan(x)
+        return ops.gdn_apply(x, norm, self.inverse), (x, norm)
+
+    def bwd(self, ctx, g, need_dx=True):
+        x, norm = ctx
+        q, ax = ops.gdn_backward_prep(g, x, norm, self.inverse)
+        ops.conv_wgrad("conv", 1, 1, self.c, self.c, ax, q, self.g_gamma)
+        ops.bias_grad(q, self.g_beta)
+        capi.call("sntc_gdn_reparam_backward", ops._ptr(self.beta_raw), ops._ptr(self.g_beta), self.g_beta.numel(), self.beta_bound,
+                  ops._ptr(self.g_beta_raw), ops._stream())
+        capi.call("sntc_gdn_reparam_backward", ops._ptr(self.gamma_raw), ops._ptr(self.g_gamma), self.g_gamma.numel(),
+                  self.gamma_bound, ops._ptr(self.g_gamma_raw), ops._stream())
+        if not need_dx:
+            return None
+        return ops.gdn_backward_finish(g, x, norm, self.adj_plan(q), self.inverse)
+
+    def convs(self):
+        return [self]            # takes part in the refresh sweep
 
 
 class TResidualBlock:
@@ -286,9 +364,12 @@ class Trainer:
     BUCKETS = ("synthesis", "prior", "hyper_synthesis", "hyper_analysis", "analysis")   # backward order
 
     def __init__(self, model, seed=0):
-        if model.factorized:
-            raise NotImplementedError("the training step is implemented for the mean-scale hyperprior model")
+        self.factorized = bool(model.factorized)
+        if self.factorized:                 # factorized/models.py: no hyper transforms, the prior codes y itself
+            self.BUCKETS = ("synthesis", "prior", "analysis")
         uq = model._latent_config["uq"].get("method", "unoise")
+        if self.factorized and uq != "unoise":
+            raise NotImplementedError("the factorized-prior model trains with uniform noise (factorized/configs/bls2017.py)")
         if uq not in ("unoise", "mixedq"):
             raise NotImplementedError(f"training with uq method {uq!r} (the shipped training configs use 'unoise' and 'mixedq')")
         self.uq = uq
@@ -300,8 +381,9 @@ class Trainer:
         w = model.get_weights()
         tr = model._transforms()
         b, hb = model._bottleneck_size, model._hyper_bottleneck_size
-        cins = dict(analysis=3, synthesis=b, hyper_analysis=b, hyper_synthesis=hb)
         self._two_layer = isinstance(tr["synthesis"], _TwoLayerBase)
+        self._rdft = {}                      # kernel size -> real-DFT basis of tfc.RDFTParameter on the device
+        self._reparam = OrderedDict()        # store name -> (weights name, kind) for variables that are not stored as is
         # ---- variable inventory, in backward order (see module docstring) ----
         for bucket in self.BUCKETS:
             if bucket == "prior":
@@ -312,15 +394,27 @@ class Trainer:
             elif bucket == "synthesis" and self._two_layer:
                 self._add_two_layer(tr["synthesis"], w)
             else:
+                special = self._special_variables(tr[bucket]._graph, bucket)
                 names = [k for k in w if k.startswith(bucket + "/")]
                 for k in reversed(names):
-                    self.store.add(k, w[k])
+                    if k in special:                       # SignalConv2D kernel -> rdft, GDN beta / gamma -> raw variable
+                        kind = special[k]
+                        if kind == "rdft":
+                            from .common.tf_checkpoint import kernel_to_rdft
+                            sk, val = k[:-len("kernel")] + "rdft", kernel_to_rdft(w[k])
+                        else:
+                            sk, val = k + "_raw", gdn_raw(w[k], GDN_BETA_MIN if kind == "beta" else 0.0)
+                        self._reparam[sk] = (k, kind)
+                        self.store.add(sk, val)
+                    else:
+                        self.store.add(k, w[k])
             self.store.mark(bucket)
         self.store.finalize()
         with torch.cuda.device(self.device):
             self.analysis = self._build(tr["analysis"]._graph, "analysis", 3)[0]
-            self.hyper_analysis = self._build(tr["hyper_analysis"]._graph, "hyper_analysis", b)[0]
-            self.hyper_synthesis = self._build(tr["hyper_synthesis"]._graph, "hyper_synthesis", hb)[0]
+            if not self.factorized:
+                self.hyper_analysis = self._build(tr["hyper_analysis"]._graph, "hyper_analysis", b)[0]
+                self.hyper_synthesis = self._build(tr["hyper_synthesis"]._graph, "hyper_synthesis", hb)[0]
             if self._two_layer:
                 self.synthesis = TTwoLayer(self.store, "synthesis", tr["synthesis"], b)
             else:
@@ -350,8 +444,34 @@ class Trainer:
         self.store.add("synthesis/up/kernel", k1)
         self.store.add("synthesis/up/bias", b1)
 
+    @staticmethod
+    def _special_variables(graph, bucket):
+        """{weights name: "rdft" | "beta" | "gamma"} of a transform: the variables tfc trains through a reparameterisation."""
+        out = {}
+
+        def walk(node):
+            if isinstance(node, Conv) and node.kind in ("sigdown", "sigup"):
+                out[f"{bucket}/{node.name}/kernel"] = "rdft"
+            elif isinstance(node, GDN):
+                out[f"{bucket}/{node.name}/beta"] = "beta"
+                out[f"{bucket}/{node.name}/gamma"] = "gamma"
+            elif isinstance(node, Seq):
+                for l in node.layers:
+                    walk(l)
+
+        walk(graph)
+        return out
+
+    def _basis(self, k):
+        if k not in self._rdft:
+            from .common.tf_checkpoint import irdft_matrix
+            self._rdft[k] = ops.to_device(irdft_matrix((k, k)), self.device)
+        return self._rdft[k]
+
     def _conv(self, pre, node, cin, add_res=False, adj=capi.EPI_STORE):
-        return TConv(self.store, f"{pre}/{node.name}", node.kind, node.k, node.s, cin, node.cout, node.act, node.bias, add_res, adj)
+        basis = self._basis(node.k) if node.kind in ("sigdown", "sigup") else None
+        return TConv(self.store, f"{pre}/{node.name}", node.kind, node.k, node.s, cin, node.cout, node.act, node.bias, add_res, adj,
+                     rdft_basis=basis)
 
     def _build(self, node, pre, cin):
         if isinstance(node, Conv):
@@ -372,11 +492,15 @@ class Trainer:
             return TAttention([self._build(r, pre, cin)[0] for r in trunk], [self._build(r, pre, cin)[0] for r in branch],
                               self._conv(pre, g, cin)), cin
         if isinstance(node, GDN):
-            raise NotImplementedError("GDN layers inside analysis / synthesis stacks are not trainable here")
+            if node.alpha != 1 or node.epsilon != 1.0:
+                raise NotImplementedError("training implements tfc.GDN with alpha = 1, epsilon = 1 (the reference's GDN1 and the "
+                                          "TFC 2.x constructor default); the classic alpha = 2, epsilon = 0.5 form is inference only")
+            return TGDN(self.store, f"{pre}/{node.name}", cin, node.inverse), cin
         raise NotImplementedError(type(node).__name__)
 
     def _all_convs(self):
-        return self.analysis.convs() + self.hyper_analysis.convs() + self.hyper_synthesis.convs() + self.synthesis.convs()
+        hyper = [] if self.factorized else self.hyper_analysis.convs() + self.hyper_synthesis.convs()
+        return self.analysis.convs() + hyper + self.synthesis.convs()
 
     def _refresh(self):
         """Parameters changed: re-pack every plan, recompute the effective GDN parameters and the prior record.
@@ -418,6 +542,27 @@ class Trainer:
         scale = rd_lambda * 2.0 * 255.0 * 255.0 / (n * h * w * c)     # d(lambda mean (255 d)^2) / d x_hat  (:313-317,343)
         step = self.step_count
         y, k_a = self.analysis.fwd(x)                                                              # :218-222
+        if self.factorized:
+            # factorized/models.py:101-118 with training=True: y~ = y + U(-.5, .5) is coded by the deep-factorized prior
+            # and decoded by the synthesis; no hyper transforms
+            y_t = ops.noise_add(y, noise_y, self.seed, 2 * step + 1)
+            dby = torch.empty_like(y_t)
+            bits_y = torch.empty((n,), dtype=torch.float64, device=x.device)
+            capi.call("sntc_noisy_factorized", self._prior._h, ops._ptr(y_t), n, y_t.shape[1] * y_t.shape[2], ops._ptr(dby),
+                      ops._ptr(self._grad_rec), ops._ptr(bits_y), ops._stream())
+            recon, k_s = self.synthesis.fwd(y_t)
+            g_x, sse = ops.distortion_grad(x, recon, scale)
+            g_y = self.synthesis.bwd(k_s, g_x)
+            notify("synthesis")
+            st, o = self.store, self._prior_names
+            capi.call("sntc_prior_param_grad", self._prior._h, ops._ptr(st.param[o["m"]:]), ops._ptr(st.param[o["f"]:]),
+                      ops._ptr(self._grad_rec), w_bpp, ops._ptr(st.grad[o["m"]:]), ops._ptr(st.grad[o["b"]:]),
+                      ops._ptr(st.grad[o["f"]:]), ops._stream())
+            notify("prior")
+            ops.axpy(g_y, dby, w_bpp)
+            self.analysis.bwd(k_a, g_y, need_dx=False)
+            notify("analysis")
+            return dict(bits_z=torch.zeros_like(bits_y), bits_y=bits_y, sse=sse, recon=recon, y=y, z=None)
         z, k_ha = self.hyper_analysis.fwd(y)
         z_t = ops.noise_add(z, noise_z, self.seed, 2 * step)                                       # :253-256 (training=True)
         dbz = torch.empty_like(z_t)
@@ -523,6 +668,14 @@ class Trainer:
                 out["synthesis/act/beta"] = gdn_effective(v, GDN_BETA_MIN)
             elif k == "synthesis/act/gamma_raw":
                 out["synthesis/act/gamma"] = gdn_effective(v, 0.0)
+            elif k in self._reparam:
+                name, kind = self._reparam[k]
+                if kind == "rdft":
+                    from .common.tf_checkpoint import rdft_to_kernel
+                    shp = tuple(self.m.get_weights()[name].shape)
+                    out[name] = rdft_to_kernel(v, shp[:2], shp[2], shp[3])
+                else:
+                    out[name] = gdn_effective(v, GDN_BETA_MIN if kind == "beta" else 0.0)
             else:
                 out[k] = v
         order = list(self.m.get_weights())                     # Model.get_weights() order (the store is in backward order)

@@ -195,6 +195,83 @@ def test_loss_and_gradients_match_autograd(synthesis, analysis, uq, dev):
     assert worst[0] < 2e-5, worst          # measured: 3e-6
 
 
+@pytest.mark.parametrize("which", ["mbt2018", "bls2017"])
+def test_gdn_and_signal_conv_stacks_train(which, dev):
+    """BASELINE configs 1 and 2 under Model.train_step (reference mshyper/models.py:375-383 applies to every config):
+    tfc.SignalConv2D layers train their real-DFT coefficients, tfc.GDN / GDN1 their reparameterised beta / gamma.  Every
+    d loss / d variable against float64 autograd of the oracle loss (kernel gradients pulled back with M^T, GDN gradients
+    through the reparameterisation), for the mean-scale model with MBT2018 transforms and for the factorized-prior model
+    with BLS2017 transforms; then a few optimizer steps lower the loss and the exported weights evaluate."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.common.tf_checkpoint import irdft_matrix
+    from shallow_ntc_amd.train import GDN_BETA_MIN, Trainer, gdn_raw
+    common = dict(device=dev, rd_lambda=0.02, scheduled_num_steps=1000, latent_config=dict(uq=dict(method="unoise")),
+                  optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
+    if which == "mbt2018":
+        from shallow_ntc_amd.mshyper.models import Model
+        cfg = dict(analysis=dict(cls="MBT2018Analysis", channels_base=32, output_channels=32),
+                   synthesis=dict(cls="MBT2018Synthesis", channels_base=32))
+        factorized = False
+    else:
+        from shallow_ntc_amd.factorized.models import Model
+        cfg = dict(analysis=dict(cls="BLS2017Analysis", num_filters=32), synthesis=dict(cls="BLS2017Synthesis", num_filters=32))
+        factorized = True
+    model = Model(transform_config=cfg, **common)
+    w = dict(model.get_weights())
+    rng = np.random.default_rng(3)
+    for k, v in w.items():
+        if k.endswith("/bias"):
+            w[k] = (0.05 * rng.standard_normal(v.shape)).astype(np.float32)
+        elif k.endswith("/beta"):
+            w[k] = (1.0 + 0.5 * rng.random(v.shape)).astype(np.float32)
+        elif k.endswith("/gamma"):
+            w[k] = (0.1 * np.eye(v.shape[0]) + 0.02 * rng.random(v.shape)).astype(np.float32)
+        elif k.startswith("prior/factor"):
+            w[k] = (0.3 * rng.standard_normal(v.shape)).astype(np.float32)
+    if not factorized:
+        w["hyper_analysis/layer_2/bias"] = (1.5 * rng.standard_normal(w["hyper_analysis/layer_2/bias"].shape)).astype(np.float32)
+    model.set_weights(w)
+    tr = Trainer(model, seed=1)
+    n, h, wd = 2, 64, 128
+    x = data_lib.normalize_image(data_lib.synthetic_images(n, h, wd, seed=5))
+    nz = rng.uniform(-0.5, 0.5, size=(n, h // 64, wd // 64, 32)).astype(np.float32)
+    ny = rng.uniform(-0.5, 0.5, size=(n, h // 16, wd // 16, 32)).astype(np.float32)
+    lam = 0.02
+    xd = torch.from_numpy(x).to(dev)
+    out = tr.loss_and_grads(xd, lam, None if factorized else torch.from_numpy(nz).to(dev), torch.from_numpy(ny).to(dev))
+    got = tr.store.export(tr.store.grad)
+    params, raw_names = dict(w), []
+    for k in w:
+        if k.endswith("/beta") or k.endswith("/gamma"):
+            mn = GDN_BETA_MIN if k.endswith("/beta") else 0.0
+            params[k] = (gdn_raw(w[k], mn), mn)
+            raw_names.append(k)
+    ref = train_ref.loss_and_grads(cfg, params, x, nz, ny, lam, gdn_raw_names=tuple(raw_names), factorized=factorized)
+    assert _rel(out["bits_y"].cpu().numpy(), ref["bits_y"]) < 2e-5 and _rel(out["recon"].cpu().numpy(), ref["recon"]) < 5e-5
+    rg = {}
+    for k, g in ref["grads"].items():
+        if k in raw_names:
+            rg[k + "_raw"] = g
+        elif k.endswith("/kernel") and k.split("/")[0] in ("analysis", "synthesis"):      # SignalConv2D: d rdft = M^T d kernel
+            kh, kw = g.shape[:2]
+            rg[k[:-len("kernel")] + "rdft"] = irdft_matrix((kh, kw)).T @ g.reshape(kh * kw, -1)
+        else:
+            rg[k] = g
+    assert set(rg) == set(got), set(rg) ^ set(got)
+    for k in rg:
+        assert np.abs(rg[k]).max() > 0, f"{k}: reference gradient is identically zero (test would be vacuous)"
+    worst = max(((_rel(got[k], rg[k]), k) for k in rg), key=lambda t: t[0])
+    assert worst[0] < 3e-5, worst
+    # a few real steps: loss goes down, exported weights load into the inference model and evaluate
+    losses = [tr.train_step(x)["rd_loss"] for _ in range(8)]
+    assert losses[-1] < losses[0] and math.isfinite(losses[-1])
+    tr.sync_model()
+    rows = model.evaluate_batched(x)
+    assert all(math.isfinite(r["bpp"]) and math.isfinite(r["psnr"]) for r in rows)
+    new = model.get_weights()
+    assert any(np.abs(new[k] - w[k]).max() > 0 for k in w if k.endswith("/kernel"))
+
+
 def test_train_step_updates_and_export(dev):
     """One full step = clip by global norm + Keras Adam on every variable (checked against the oracle arithmetic), plans
     re-packed: the second step's loss equals a fresh model built from the exported weights; the loss goes down."""
