@@ -339,6 +339,29 @@ def main():
             b1[label] = dict(ms_per_image=round(1e3 * t / 2 / len(singles), 3), mpixels_per_s=round(world * pixels_per_step * 2 / t / 1e6, 2))
         model._quality_metrics = keep_q
         regions["evaluate_b1"] = dict(workload=f"{len(singles)} images per GPU, one at a time through Model.evaluate()", **b1)
+        # EXPERIMENT, fenced: the same decode with the bf16 x 3 split-precision contraction in the hyper-synthesis
+        # and synthesis convolutions.  Reported next to -- never instead of -- the fp32 numbers, with its own parity figures.
+        ops.BF16X3_EXPERIMENT = True
+        model3 = Model(device=dev, **cfg)
+        model3.set_weights(model.get_weights())
+        ops.BF16X3_EXPERIMENT = False
+        t_dec3 = timed(lambda: [model3.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes], args.steps, args.warmup)
+        diff = tot = 0
+        sse32 = sse3 = 0
+        for z_hat, sym, hw, x in codes:
+            p32, s32 = model.decode(z_hat, sym, hw, reference=x)
+            p3, s3 = model3.decode(z_hat, sym, hw, reference=x)
+            d = (p32.to(torch.int16) - p3.to(torch.int16)).abs()
+            diff += int((d != 0).sum()); tot += d.numel()
+            assert int(d.max()) <= 1, "bf16 x 3 decode differs from fp32 by more than one code value"
+            sse32 += int(s32.sum()); sse3 += int(s3.sum())
+        psnr = lambda sse: 10.0 * np.log10(255.0 ** 2 / (sse / tot))
+        regions["decode_bf16x3"] = dict(
+            experiment="split precision: 3 bf16 terms per fp32 operand, 6 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate",
+            ms_per_step=round(1e3 * t_dec3 / args.steps, 4), mpixels_per_s=round(world * pixels_per_step * args.steps / t_dec3 / 1e6, 2),
+            speedup_over_fp32=round(t_dec / t_dec3, 3), pixel_values=tot, pixels_differing_from_fp32=diff,
+            max_code_difference=1 if diff else 0, d_psnr_vs_fp32_db=round(float(psnr(sse3) - psnr(sse32)), 7))
+        del model3
         rows = []                          # per-image (bpp, psnr, mse) of the rank's set, then ONE all-gather
         for ids, x, hw in batches:
             for d, i in zip(model.evaluate_batched(x), ids):

@@ -86,7 +86,11 @@ typedef struct sntc_conv_desc {
   int32_t reserved[7]; /* reserved[0] != 0: the kernel array has its two channel axes swapped with respect to the kind's
                         * native layout (so that the input-gradient plan of a layer -- the adjoint kind -- packs straight
                         * from the layer's own kernel array; Keras Conv2D <-> Conv2DTranspose are each other's swap already,
-                        * tfc.SignalConv2D down <-> up need the flag); the rest must be 0 */
+                        * tfc.SignalConv2D down <-> up need the flag);
+                        * reserved[1] != 0: EXPERIMENT -- bf16 x 3 split-precision contraction (hi + mid + lo bfloat16 terms, six
+                        * cross products on the bf16 matrix cores, fp32 accumulation): ~1e-7 relative like fp32 but NOT
+                        * bit-identical to it; Cin % 16 == 0, no prologue; never used by the default paths;
+                        * the rest must be 0 */
 } sntc_conv_desc;
 
 typedef struct sntc_conv_plan sntc_conv_plan;

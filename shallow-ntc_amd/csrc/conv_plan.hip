@@ -15,7 +15,7 @@ namespace sntc {
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                     const int* __restrict__ taps, const unsigned* __restrict__ cols,
                                     int T, int Cin, int Cout, int K, int Ncol, int kind, int kw, int s,
-                                    int pt, int pl, int phase_mode, int slab_major, int out_major) {
+                                    int pt, int pl, int phase_mode, int slab_major, int out_major, int bf3) {
   const size_t total = (size_t)Ncol * K;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -46,7 +46,16 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
       const size_t tapi = (size_t)ky * kw + kx;
       v = out_major ? w[(tapi * Cout + ch) * Cin + ci] : w[(tapi * Cin + ci) * Cout + ch];
     }
-    wp[idx] = v;
+    if (bf3) {           // three bf16 planes, 96 B per (column, 16-deep stage): [plane][16]
+      __bf16 hi = (__bf16)v;
+      const float r1 = v - (float)hi;
+      __bf16 mid = (__bf16)r1;
+      __bf16 lo = (__bf16)(r1 - (float)mid);
+      __bf16* o = reinterpret_cast<__bf16*>(wp) + ((size_t)col * (K / 16) + (k >> 4)) * 48 + (k & 15);
+      o[0] = hi; o[16] = mid; o[32] = lo;
+    } else {
+      wp[idx] = v;
+    }
   }
 }
 
@@ -73,6 +82,7 @@ struct sntc_conv_plan {
   } g[kMaxGroups];
   float* bias = nullptr;
   int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
+  bool bf3 = false;         // desc.reserved[1]: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
 };
@@ -168,7 +178,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     if ((int64_t)G.Ncol * G.K * 4 >= (1LL << 31)) return fail(SNTC_ERR_UNSUPPORTED, "packed weights of one phase group must be < 2 GiB");
     SNTC_HIP(hipMalloc(&G.taps, sizeof(int) * std::max(1, G.T)));
     SNTC_HIP(hipMalloc(&G.cols, sizeof(unsigned) * G.Ncol));
-    SNTC_HIP(hipMalloc(&G.wp, sizeof(float) * (size_t)G.Ncol * std::max(kStage, G.K)));
+    SNTC_HIP(hipMalloc(&G.wp, (p->bf3 ? 6 : sizeof(float)) * (size_t)G.Ncol * std::max(kStage, G.K)));
     SNTC_HIP(hipMemcpyAsync(G.taps, hg.taps.data(), sizeof(int) * G.T, hipMemcpyHostToDevice, stream));
     SNTC_HIP(hipMemcpyAsync(G.cols, hg.cols.data(), sizeof(unsigned) * G.Ncol, hipMemcpyHostToDevice, stream));
     // the host vectors must outlive the async copies
@@ -177,7 +187,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, weight, G.wp, G.taps, G.cols,
-                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0);
+                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) {
@@ -220,6 +230,11 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
   // Keras Conv2DTranspose stores [kh, kw, Cout, Cin]; everything else [kh, kw, Cin, Cout] -- unless the caller says the
   // array is the channel-transposed one (the adjoint of a SignalConv2D layer runs on the layer's own kernel array)
   p->out_major = (d.kind == SNTC_CONV2D_TRANSPOSE) != (d.reserved[0] != 0);
+  p->bf3 = d.reserved[1] != 0;
+  if (p->bf3 && (!p->vec || d.prologue != SNTC_PRO_NONE)) {
+    delete p;
+    return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 plans need Cin % 16 == 0 and no prologue");
+  }
   rc = build_plan(p, weight, bias, (hipStream_t)stream);
   if (rc) {
     sntc_conv_plan_destroy(p);
@@ -242,7 +257,7 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, weight, G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K,
-                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0);
+                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));
@@ -359,10 +374,11 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   for (int v = 1; v <= kNumVariants; ++v) {
     if (p->tile >= 1 && p->tile <= kNumVariants && v != p->tile) continue;
     if (p->tile == 0 && (v == 6 || v == 7 || v == 10)) continue;   // single-buffered / one wave per SIMD: tests only
+    if (p->bf3 && v != 2 && v != 4) continue;                       // the bf16 x 3 experiment is instantiated for two tile shapes
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
-    const int resident = std::max(1, gg_resident_blocks(v, p->vec, pro));
+    const int resident = std::max(1, p->bf3 ? gg_resident_blocks_bf3(v) : gg_resident_blocks(v, p->vec, pro));
     Sched s;
     s.variant = v;
     s.ksplit = ksplit;
@@ -454,6 +470,7 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   a.act = d.act; a.epi = d.epilogue; a.pro = d.prologue;
   a.ntm = (int)((M + bm - 1) / bm);
   a.ngroups = p->ngroups;
+  a.bf3 = p->bf3 ? 1 : 0;
   a.sk = sc.sk ? 1 : 0;
   a.nworkers = sc.workers;
   a.units = sc.units;

@@ -126,16 +126,35 @@ struct Piece {
 // workgroups per CU the register budget must allow (= waves per SIMD for 256-thread workgroups): what the LDS ring admits
 constexpr int gg_waves(int tiles) { return tiles == 1 ? 4 : (tiles <= 3 ? 3 : 2); }
 
-template <int TM, int TN, int WM, int WN, bool VEC, bool PRO>
+// BF3 (experiment, DESIGN.md 8: "bf16 x 3"): every fp32 operand is split into three bfloat16 terms hi + mid + lo (24
+// mantissa bits together) and the product is accumulated in fp32 from the six significant cross terms on
+// v_mfma_f32_32x32x16_bf16 -- 6 MFMAs of 32 cycles for K = 16 against 8 fp32 MFMAs of 64 cycles.  The weights are split
+// once at pack time, the activations while they are staged into LDS.  Results are NOT bit-identical to the fp32 path
+// (the dropped terms are ~2^-24 relative, and the summation order inside an MFMA differs): a fenced decode experiment.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, __bf16* hi, __bf16* mid, __bf16* lo) {
+  const __bf16 h = (__bf16)x;
+  const float r1 = x - (float)h;               // exact
+  const __bf16 m = (__bf16)r1;
+  const float r2 = r1 - (float)m;              // exact
+  *hi = h; *mid = m; *lo = (__bf16)r2;
+}
+
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false>
 __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
+  static_assert(!BF3 || (VEC && !PRO), "the bf16 x 3 experiment covers the vector path without prologue");
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
-  constexpr int SLOT = (BM + BN) * kStage;            // floats per ring slot: A rows, then B rows, 16 floats each
+  // floats per ring slot.  fp32: A rows, then B rows, 16 floats (64 B) each.  BF3: three bf16 planes of A rows, then three of
+  // B rows, 16 bf16 (32 B) per row and plane = 96 B per row
+  constexpr int SLOT = BF3 ? (BM + BN) * 24 : (BM + BN) * kStage;
   constexpr int A_CH = BM / 64;                       // 16-B chunks per thread per stage (A, vector path)
-  constexpr int B_CH = (BN + 63) / 64;
+  constexpr int B_CH = BF3 ? (BN * 6 + 255) / 256 : (BN + 63) / 64;   // BF3: 6 chunks of 16 B per weight row and stage
   constexpr int A_SC = BM / 16;                       // dwords per thread per stage (A, gather path)
   constexpr int EPW = 32 * (TN >= 2 ? 64 : 32);       // floats of epilogue staging per wave
-  constexpr bool DBUF = TM * TN <= 8 && TN <= 5;      // fragment double buffering (the two widest 32-row tiles, 96+ accumulator
+  constexpr bool DBUF = !BF3 && TM * TN <= 8 && TN <= 5;   // fragment double buffering (the two widest 32-row tiles, 96+ accumulator
                                                       // registers and 7-8 fragment quads, run single-buffered)
   constexpr bool RBUF = DBUF && TM * TN <= 3;         // second staging register set for a tile's first two stages
   static_assert(3 * SLOT >= 4 * EPW, "epilogue staging must fit in the stage ring");
@@ -295,7 +314,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   int g_T = a.g[P.gi].T, g_tw = a.g[P.gi].tw;   // hot fields of the current piece's group: taps form a dense grid, tap t
                                                 // = (t / tw, t % tw), walked incrementally (no table load in the loop)
   __amdgpu_buffer_rsrc_t ws =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[P.gi].wp), 0, a.g[P.gi].Ncol * a.g[P.gi].K * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[P.gi].wp), 0, a.g[P.gi].Ncol * a.g[P.gi].K * (BF3 ? 6 : 4), 0x00020000);
   int m0 = 0, n0 = 0;
 
   auto set_tap = [&](int ty, int tx) {
@@ -337,7 +356,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     const auto& G = a.g[p.gi];
     g_T = G.T;
     g_tw = G.tw;
-    ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 4, 0x00020000);
+    ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * (BF3 ? 6 : 4), 0x00020000);
     m0 = p.mt * BM;
     n0 = p.nt * BN;
 #pragma unroll
@@ -350,8 +369,14 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {   // rows past Ncol re-read the last column (finite, discarded)
-      const int brow = min(n0 + r0 + 64 * i, G.Ncol - 1);
-      b_off[i] = (unsigned)brow * (unsigned)G.K * 4u + (unsigned)c * 16u;
+      if (BF3) {                        // chunk q of the tile's stage: weight row q / 6, 16-B part q % 6 = (plane, half)
+        const int q = tid + 256 * i;
+        const int brow = min(n0 + q / 6, G.Ncol - 1);
+        b_off[i] = (unsigned)brow * (unsigned)(G.K / kStage) * 96u + (unsigned)(q % 6) * 16u;
+      } else {
+        const int brow = min(n0 + r0 + 64 * i, G.Ncol - 1);
+        b_off[i] = (unsigned)brow * (unsigned)G.K * 4u + (unsigned)c * 16u;
+      }
     }
     ld_stage = p.k0;
     if (VEC) {
@@ -398,10 +423,11 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
         if (++g_tx == g_tw) { g_tx = 0; ++g_ty; }
       }
     }
-    const unsigned wsoff = (unsigned)ld_stage * 64u;
+    const unsigned wsoff = (unsigned)ld_stage * (BF3 ? 96u : 64u);
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      if (BN % 64 == 0 || r0 + 64 * i < BN) R.b[i] = buf_load(ws, b_off[i], wsoff);
+      if (BF3 ? ((BN * 6) % 256 == 0 || tid + 256 * i < BN * 6) : (BN % 64 == 0 || r0 + 64 * i < BN))
+        R.b[i] = buf_load(ws, b_off[i], wsoff);
     ++ld_stage;
     if (VEC) {
       // next stage's channel slab / tap, without a branch (the steady-state loop stays one basic block: the scheduler
@@ -422,6 +448,36 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
 
   auto write_lds = [&](const Regs& R, int slot) {
     float* Ab = ring + slot * SLOT;
+    if (BF3) {
+      // A: split the four fp32 values of this thread's chunk into three bf16 quads; plane p of row r lives at
+      // p * BM * 32 + r * 32 bytes, its two 16-B halves swapped by (r >> 3) & 1 (conflict-free fragment reads)
+      char* Ap = reinterpret_cast<char*>(Ab);
+      char* Bp = Ap + 3 * BM * 32;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int r = r0 + 64 * i;
+        bf16x4 hi, mid, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 x0, x1, x2;
+          split3(R.a[i][e], &x0, &x1, &x2);
+          hi[e] = x0; mid[e] = x1; lo[e] = x2;
+        }
+        const int off = r * 32 + (((c >> 1) ^ ((r >> 3) & 1)) << 4) + ((c & 1) << 3);
+        *reinterpret_cast<bf16x4*>(Ap + off) = hi;
+        *reinterpret_cast<bf16x4*>(Ap + BM * 32 + off) = mid;
+        *reinterpret_cast<bf16x4*>(Ap + 2 * BM * 32 + off) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        const int q = tid + 256 * i;
+        if ((BN * 6) % 256 == 0 || q < BN * 6) {
+          const int r = q / 6, part = q % 6, plane = part >> 1, half = part & 1;
+          *reinterpret_cast<f32x4*>(Bp + plane * BN * 32 + r * 32 + ((half ^ ((r >> 3) & 1)) << 4)) = R.b[i];
+        }
+      }
+      return;
+    }
     float* Bb = Ab + BM * kStage;
     if (VEC) {
 #pragma unroll
@@ -472,7 +528,36 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     for (int j = 0; j < TN; ++j) F.b[j] = *reinterpret_cast<const f32x4*>(base + fb_row + j * 32 * kStage + off);
   };
 
+  struct Frag3 {
+    bf16x8 a[BF3 ? 3 : 1][TM];
+    bf16x8 b[BF3 ? 3 : 1][TN];
+  };
+  auto read_frag3 = [&](Frag3& F, int slot) {
+    const char* base = reinterpret_cast<const char*>(ring + slot * SLOT);
+    const int hoff = (h ^ ((l31 >> 3) & 1)) << 4;
+#pragma unroll
+    for (int p = 0; p < (BF3 ? 3 : 1); ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        F.a[p][i] = *reinterpret_cast<const bf16x8*>(base + p * BM * 32 + (wm * TM * 32 + i * 32 + l31) * 32 + hoff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        F.b[p][j] = *reinterpret_cast<const bf16x8*>(base + 3 * BM * 32 + p * BN * 32 + (wn * TN * 32 + j * 32 + l31) * 32 + hoff);
+    }
+  };
+
   f32x16 acc[TM][TN];
+  auto mfma3 = [&](const Frag3& F) {           // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < (BF3 ? 6 : 0); ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[BF3 ? PA[t] : 0][i], F.b[BF3 ? PB[t] : 0][j], acc[i][j], 0, 0, 0);
+  };
   auto mfma_group = [&](const Frag& F) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -552,7 +637,11 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     auto step = [&](auto WR, auto LD, auto PF) {
       if (decltype(WR)::value && !SNTC_DBG(a, 2)) write_lds(R0, s_n2);        // stage j+2, loaded during step j-1
       if (decltype(LD)::value && !SNTC_DBG(a, 1)) load_regs(R0);              // stage j+3
-      if (DBUF) {
+      if (BF3) {
+        Frag3 F3;
+        read_frag3(F3, s_cur);
+        mfma3(F3);
+      } else if (DBUF) {
         if (!SNTC_DBG(a, 8)) read_frag(F1, s_cur, 1);
         mfma_group(F0);
         if (decltype(PF)::value && !SNTC_DBG(a, 8)) read_frag(F0, s_n1, 0);   // under this stage's remaining MFMAs
@@ -790,6 +879,18 @@ static const void* kernel_ptr(bool vec, bool pro) {
   return reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false, true>);
 }
 
+static const void* variant_kernel_bf3(int v) {
+  switch (v) {
+    case 2: return reinterpret_cast<const void*>(&gg_kernel<1, 2, 4, 1, true, false, true>);
+    case 4: return reinterpret_cast<const void*>(&gg_kernel<1, 4, 4, 1, true, false, true>);
+    default: return nullptr;
+  }
+}
+
+static size_t lds_bytes_bf3(int v) {
+  return (size_t)3 * (gg_variant_bm(v) + gg_variant_bn(v)) * 96 + 2 * gg_variant_bm(v) * sizeof(int4);
+}
+
 static const void* variant_kernel(int v, bool vec, bool pro) {
   switch (v) {
     case 1: return kernel_ptr<1, 1, 4, 1>(vec, pro);
@@ -809,6 +910,7 @@ static const void* variant_kernel(int v, bool vec, bool pro) {
 static thread_local int g_init_device = -1;
 static thread_local int g_resident[kNumVariants + 1][3];      // per (variant, {vec, vec+pro, gather}) workgroups per device
 static thread_local int g_num_cus = 0;
+static thread_local int g_resident_bf3[kNumVariants + 1];
 
 int gg_init() {
   int dev = 0;
@@ -829,6 +931,13 @@ int gg_init() {
       g_resident[v][k] = per_cu * g_num_cus;
     }
   }
+  for (int v : {2, 4}) {
+    const void* fn = variant_kernel_bf3(v);
+    SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_bf3(v)));
+    int per_cu = 0;
+    SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_bf3(v)));
+    g_resident_bf3[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_bf3(v))})) * g_num_cus;
+  }
   g_init_device = dev;
   return SNTC_OK;
 }
@@ -838,16 +947,21 @@ int gg_resident_blocks(int variant, bool vec, bool pro) {
   return g_resident[variant][!vec ? 2 : (pro ? 1 : 0)];
 }
 
+int gg_resident_blocks_bf3(int variant) {
+  return (variant == 2 || variant == 4) && g_init_device >= 0 ? g_resident_bf3[variant] : 0;
+}
+
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {
   const bool pro = args.pro != SNTC_PRO_NONE;
-  const void* fn = variant_kernel(variant, vec, pro || !vec);
+  const void* fn = args.bf3 ? variant_kernel_bf3(variant) : variant_kernel(variant, vec, pro || !vec);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
+  if (args.bf3 && (pro || !vec)) return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 mode: vector path without prologue only");
   GGArgs a = args;
 #ifdef SNTC_DIAG
   if (const char* e = getenv("SNTC_GG_DBG")) a.dbg = atoi(e);   // diagnostic builds only (make DIAG=1): results are WRONG with it
 #endif
   void* params[] = {&a};
-  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params, lds_bytes(variant), stream);
+  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params, args.bf3 ? lds_bytes_bf3(variant) : lds_bytes(variant), stream);
   if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
   return SNTC_OK;
 }

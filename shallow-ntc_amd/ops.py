@@ -21,6 +21,8 @@ KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SI
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
 FORCE_TILE = 0   # tools/profile_layers.py --variant: every plan created afterwards is pinned to this tile variant
+BF16X3_EXPERIMENT = False   # bench.py regions.decode_bf16x3 only: plans created while this is set use the split-precision
+                            # contraction wherever it applies (Cin % 16 == 0, no prologue); never set by the product paths
 
 
 def _stream():
@@ -49,7 +51,7 @@ class ConvPlan:
     """One packed convolution (sntc_conv_plan): Conv2D / Conv2DTranspose / SignalConv2D (+GDN pool)."""
 
     def __init__(self, kind, weight, bias, stride, act=None, prologue=capi.PRO_NONE, epilogue=capi.EPI_STORE,
-                 kernel_io_swapped=False):
+                 kernel_io_swapped=False, bf16x3=False):
         """``kernel_io_swapped``: ``weight`` has its two channel axes swapped with respect to the kind's own layout -- the
         input-gradient plan of a tfc.SignalConv2D layer (the adjoint kind) packs straight from the layer's kernel array."""
         capi.require_gpu()
@@ -63,7 +65,11 @@ class ConvPlan:
         self.epilogue = epilogue
         desc = capi.ConvDesc(kind=KINDS[kind], kh=kh, kw=kw, stride=int(stride), cin=cin, cout=cout,
                              act=ACTS[act], prologue=prologue, epilogue=epilogue)
+        if BF16X3_EXPERIMENT and cin % 16 == 0 and prologue == capi.PRO_NONE:
+            bf16x3 = True
+        self.bf16x3 = bool(bf16x3)
         desc.reserved[0] = 1 if kernel_io_swapped else 0
+        desc.reserved[1] = 1 if bf16x3 else 0           # split-precision experiment, never a default
         w = w.contiguous()
         b = None if bias is None else bias.contiguous()
         self._h = C.c_void_p()

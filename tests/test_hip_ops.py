@@ -356,3 +356,28 @@ def test_two_layer_tail_with_fused_pixel_output(ch, has_res, act, dev):
         px2, none = ops.two_layer_tail_pixels(td, ch, has_res, kind, bd, gd, wd, b2d, h, w)
         assert none is None and torch.equal(px2, px_want)
     assert 0 < int(px.min()) or int(px.max()) <= 255        # exercised, values are pixels
+
+
+@pytest.mark.parametrize("kind,k,s,cin,cout", [("convT", 3, 1, 64, 96), ("convT", 5, 2, 32, 48), ("conv", 3, 1, 48, 64)])
+def test_bf16x3_split_precision_plan(kind, k, s, cin, cout, dev):
+    """The fenced experiment of DESIGN.md 8: operands split into three bfloat16 terms, six cross products on the bf16
+    matrix cores, fp32 accumulation.  Against the float64 oracle it must be as accurate as the fp32 path (both ~1e-7
+    relative), but it is NOT required to be bit-identical to it."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(k * 100 + cin)
+    n, h, w = 2, 13, 17
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wk = (rng.standard_normal((k, k, cout, cin) if kind == "convT" else (k, k, cin, cout)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = (O.conv2d_transpose if kind == "convT" else O.conv2d)(x, wk, b, s)
+    p32 = ops.ConvPlan(kind, dev_t(wk, dev), dev_t(b, dev), s)
+    p3 = ops.ConvPlan(kind, dev_t(wk, dev), dev_t(b, dev), s, bf16x3=True)
+    y32 = p32(dev_t(x, dev)).cpu().numpy()
+    e32 = rel_err(y32, ref)
+    for variant in (2, 4):
+        p3.set_tile(variant)
+        y3 = p3(dev_t(x, dev)).cpu().numpy()
+        e3 = rel_err(y3, ref)
+        assert e3 < 3e-6 and e3 < 4 * e32 + 1e-7, (variant, e3, e32)
+    with pytest.raises(Exception):
+        ops.ConvPlan("conv", dev_t(rng.standard_normal((5, 5, 3, 16)).astype(np.float32), dev), None, 2, bf16x3=True)   # Cin % 16 != 0

@@ -32,6 +32,7 @@ ap.add_argument("--static", action="store_true")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--ab", default="")
 ap.add_argument("--epi", action="store_true", help="residual-add epilogue")
+ap.add_argument("--bf16x3", action="store_true", help="split-precision experiment: also run the bf16 x 3 plan and compare with fp32")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
@@ -68,6 +69,25 @@ for rep in range(args.reps + 3):
         torch.cuda.synchronize()
         if rep >= 3:
             times[v].append(e0.elapsed_time(e1))
+if args.bf16x3:
+    p3 = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE, bf16x3=True)
+    y3 = torch.empty_like(y)
+    ref = plans[variants[0]](x, res=res).clone()
+    for v3 in (2, 4):
+        p3.set_tile(v3)
+        ts = []
+        for rep in range(args.reps + 3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            p3(x, res=res, out=y3)
+            e1.record()
+            torch.cuda.synchronize()
+            if rep >= 3:
+                ts.append(e0.elapsed_time(e1))
+        err = float((y3 - ref).abs().max() / ref.abs().max())
+        vv, nb = p3.launch_info(args.n, h, w)
+        print(f"bf16x3 variant {vv} blocks {nb}: median {np.median(ts):.4f} ms  {flops / np.median(ts) / 1e9:.1f} TFLOP/s-equivalent; "
+              f"max |bf16x3 - fp32| / max |fp32| = {err:.2e}")
 for v in variants:
     t = np.array(times[v])
     vv, nb = plans[v].launch_info(args.n, h, w)
