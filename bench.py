@@ -394,16 +394,22 @@ def main():
         per_kernel = kernel_table(decode_eager, 3)
         name, k = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
         achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = None, None       # HBM-side bytes per launch from the committed PMC passes (separate runs)
+        # HBM-side bytes per launch come from committed rocprofv3 --pmc passes (separate runs, never this one); the summary
+        # records the hash of the kernel source it was measured on, so a number from an older kernel is marked stale
+        import hashlib
+        traffic, traffic_src, traffic_stale = None, None, None
+        cur_sha = hashlib.sha256((ROOT / "shallow-ntc_amd/csrc/gather_gemm.hip").read_bytes()).hexdigest()[:16]
         for f in sorted((ROOT / "profiles").glob("*_pmc_summary.json"), reverse=True):
-            for kn, e in json.loads(f.read_text()).items():
-                if name in kn and "hbm_side_bytes_per_launch" in e:
+            summ = json.loads(f.read_text())
+            for kn, e in summ.items():
+                if kn != "_meta" and name in kn and "hbm_side_bytes_per_launch" in e:
                     traffic, traffic_src = e["hbm_side_bytes_per_launch"], f"profiles/{f.name}"
+                    traffic_stale = summ.get("_meta", {}).get("gather_gemm_sha16") != cur_sha
             if traffic is not None:
                 break
         roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        traffic_source=traffic_src,
+                        traffic_source=traffic_src, traffic_stale=traffic_stale,
                         avg_launch_ms=round(k["ms"] / k["launches"], 4), launches_per_step=k["launches"] // 3,
                         precision="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                         all_kernels={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),

@@ -23,6 +23,8 @@ for d in dirs:
                 agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg_ns = {}
 stats = Path(__file__).resolve().parent.parent / "profiles" / f"{tag}_decode_only_kernel_stats.csv"
+if len(sys.argv) > 2 and sys.argv[-1].endswith(".csv"):      # explicit kernel-stats file as the last argument
+    stats, dirs = Path(sys.argv[-1]), dirs[:-1]
 if stats.exists():
     for r in csv.DictReader(open(stats)):
         avg_ns[r["Name"]] = float(r["AverageNs"])
@@ -36,9 +38,17 @@ for k, v in agg.items():
         # SIMD-cycles available in one launch = avg duration x 2.4 GHz x 256 CUs x 4 SIMDs (stats run of the same command)
         e["avg_launch_ns_from_stats"] = round(avg_ns[k])
         e["mfma_busy_over_simd_cycles"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg_ns[k] * 2.4 * 1024), 3)
+    if "GRBM_GUI_ACTIVE" in m and k in avg_ns:
+        # effective shader clock during the (profiled) launch: GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+        e["effective_clock_ghz_profiled"] = round(m["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns[k], 3)
     if m.get("SQ_WAVE_CYCLES"):
         e["wave_cycle_shares"] = {c: round(m[c] / m["SQ_WAVE_CYCLES"], 3) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c in m}
     out[k] = e
+import hashlib
+root = Path(__file__).resolve().parent.parent
+# which kernel source these counters belong to: bench.py marks roofline.traffic stale when the source has changed since
+out["_meta"] = dict(gather_gemm_sha16=hashlib.sha256((root / "shallow-ntc_amd/csrc/gather_gemm.hip").read_bytes()).hexdigest()[:16],
+                    conv_plan_sha16=hashlib.sha256((root / "shallow-ntc_amd/csrc/conv_plan.hip").read_bytes()).hexdigest()[:16])
 p = Path(__file__).resolve().parent.parent / "profiles" / f"{tag}_pmc_summary.json"
 p.write_text(json.dumps(out, indent=1))
 print(p, len(out), "kernels")
