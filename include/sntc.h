@@ -121,10 +121,12 @@ int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int 
 /* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
  * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */
 int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
-/* stream_k = 0 forces the static schedule (one workgroup per tile) for THIS plan, 1 (default) lets large launches run on
- * the persistent stream-K workers.  Both schedules produce bit-identical outputs (every element is the same k-ordered
- * fma chain); the switch exists so that a test can assert exactly that. */
-int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int stream_k);
+/* Schedule switches of THIS plan (tests / profiling).  flags bit 0: 1 (default) lets large launches run on the persistent
+ * stream-K workers, 0 forces the static schedule (one workgroup per tile); bit 2 set: bit 1 selects the stage path --
+ * 1 direct-to-LDS (buffer_load ... lds), 0 register staging; bit 2 clear: the library default.  Every combination
+ * produces bit-identical outputs (each element is the same k-ordered fma chain); the switches exist so that a test can
+ * assert exactly that. */
+int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int flags);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);

@@ -84,6 +84,7 @@ struct sntc_conv_plan {
   int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
   bool bf3 = false;         // desc.reserved[1]: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
+  int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
 };
 
@@ -94,9 +95,20 @@ extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   return SNTC_OK;
 }
 
-extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int stream_k) {
+// Direct-to-LDS staging by default on long contractions only (>= 48 stages per tile: 3x3 and larger kernels): measured
+// +1 ... 3 % there (tools/ab_dma.sh), while its fourth ring slot costs the short-K 1x1 layers a resident workgroup
+// (128 x 96 tile: 57 -> 48 TFLOP/s on 96 -> 192 + skip).  Bit-identical either way.
+static bool plan_dma(const sntc_conv_plan* p) {
+  int steps = 0;
+  for (int gi = 0; gi < p->ngroups; ++gi) steps = std::max(steps, p->g[gi].K / kStage);
+  const bool want = p->dma < 0 ? steps >= 48 : p->dma != 0;
+  return want && p->vec && p->d.prologue == SNTC_PRO_NONE && !p->bf3;
+}
+
+extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int flags) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_schedule: null plan");
-  p->no_stream_k = stream_k == 0;
+  p->no_stream_k = (flags & 1) == 0;
+  p->dma = (flags & 4) ? ((flags & 2) ? 1 : 0) : -1;      // bit 2: "bit 1 is meaningful"; bit 1: direct-to-LDS staging on / off
   return SNTC_OK;
 }
 
@@ -378,7 +390,8 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
-    const int resident = std::max(1, p->bf3 ? gg_resident_blocks_bf3(v) : gg_resident_blocks(v, p->vec, pro));
+    const bool dma = plan_dma(p) && gg_resident_blocks_dma(v) > 0;
+    const int resident = std::max(1, p->bf3 ? gg_resident_blocks_bf3(v) : dma ? gg_resident_blocks_dma(v) : gg_resident_blocks(v, p->vec, pro));
     Sched s;
     s.variant = v;
     s.ksplit = ksplit;
@@ -471,6 +484,7 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   a.ntm = (int)((M + bm - 1) / bm);
   a.ngroups = p->ngroups;
   a.bf3 = p->bf3 ? 1 : 0;
+  a.dma = plan_dma(p) ? 1 : 0;
   a.sk = sc.sk ? 1 : 0;
   a.nworkers = sc.workers;
   a.units = sc.units;

@@ -142,9 +142,16 @@ __device__ __forceinline__ void split3(float x, __bf16* hi, __bf16* mid, __bf16*
   *hi = h; *mid = m; *lo = (__bf16)r2;
 }
 
-template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false>
+// DMA: the stage tiles go from L2 / HBM straight into the LDS ring (buffer_load ... lds): no staging registers, no
+// ds_write, and the data never crosses the vector register file.  The LDS destination of a wave instruction is linear
+// (64 lanes x 16 B = 16 rows), so the XOR swizzle is applied to the SOURCE chunk each lane fetches.  Four ring slots: stage
+// j+3 is issued in step j, stage j+2 is waited for (counted vmcnt) before the barrier of step j, and its first fragments are
+// prefetched in step j+1.
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false>
 __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
   static_assert(!BF3 || (VEC && !PRO), "the bf16 x 3 experiment covers the vector path without prologue");
+  static_assert(!DMA || (VEC && !PRO && !BF3), "direct-to-LDS staging: vector path, no prologue (nothing can touch the data on the way)");
+  constexpr int RING = DMA ? 4 : 3;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   // floats per ring slot.  fp32: A rows, then B rows, 16 floats (64 B) each.  BF3: three bf16 planes of A rows, then three of
@@ -157,10 +164,10 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   constexpr bool DBUF = !BF3 && TM * TN <= 8 && TN <= 5;   // fragment double buffering (the two widest 32-row tiles, 96+ accumulator
                                                       // registers and 7-8 fragment quads, run single-buffered)
   constexpr bool RBUF = DBUF && TM * TN <= 3;         // second staging register set for a tile's first two stages
-  static_assert(3 * SLOT >= 4 * EPW, "epilogue staging must fit in the stage ring");
+  static_assert(RING * SLOT >= 4 * EPW + (DMA ? SLOT : 0), "epilogue staging (and one prefetched stage) must fit in the stage ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ring = reinterpret_cast<float*>(smem);                  // [3][BM + BN][16]
-  int4* rinfo_all = reinterpret_cast<int4*>(ring + 3 * SLOT);    // [2][BM] (n, qy, qx, valid) of the current / next tile
+  float* ring = reinterpret_cast<float*>(smem);                  // [RING][BM + BN][16]
+  int4* rinfo_all = reinterpret_cast<int4*>(ring + RING * SLOT); // [2][BM] (n, qy, qx, valid) of the current / next tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -296,8 +303,11 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   // ------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t xs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const int c = tid & 3;          // vector path: 16-B chunk inside the 64-B K slab
   const int r0 = tid >> 2;        // vector path: row 0..63 (+64 i)
+  // vector path: 16-B chunk inside the 64-B K slab this lane fetches.  Register staging: lane (tid & 3) fetches chunk
+  // tid & 3 and WRITES it to the swizzled LDS position; DMA: the LDS position is the lane's own (linear destination), so
+  // the lane fetches the chunk that belongs there
+  const int c = DMA ? ((tid & 3) ^ ((r0 >> 2) & 3)) : (tid & 3);
   const int wsw = (c ^ ((r0 >> 2) & 3)) << 2;
   const int kk = tid & 15;        // gather path: k column inside the stage
   const int rs = tid >> 4;        // gather path: row 0..15 (+16 i)
@@ -400,6 +410,25 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     f32x4 b[B_CH];
   };
 
+  auto advance_stage = [&]() {
+    ++ld_stage;
+    if (VEC) {
+      // next stage's channel slab / tap, without a branch (the steady-state loop stays one basic block: the scheduler
+      // can then place every load, LDS write and fragment read between MFMAs); the per-row offsets are recomputed every
+      // stage -- ~10 VALU per row against 1024 MFMA cycles
+      // K order of the vector path: channel slab OUTERMOST, taps inside (k = cc * T * 16 + t * 16 + c): the taps of one
+      // 16-channel slab re-read the same input pixels (a 5x5 / stride-2 layer touches each ~6 times), so they now do it
+      // within T consecutive stages, from L2, instead of T * Cin / 16 stages apart, from HBM
+      const int row_end = (ld_tx + 1 == g_tw) ? 1 : 0;
+      const int tap_end = (ld_t + 1 == g_T) ? 1 : 0;
+      ld_tx = row_end ? 0 : ld_tx + 1;
+      ld_ty = tap_end ? 0 : ld_ty + row_end;
+      ld_t = tap_end ? 0 : ld_t + 1;
+      ld_cc += tap_end;
+      set_tap(ld_ty, ld_tx);
+    }
+  };
+
   auto load_regs = [&](Regs& R) {
     if (VEC) {
       const unsigned soff = (unsigned)ld_cc * 64u;
@@ -428,21 +457,42 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     for (int i = 0; i < B_CH; ++i)
       if (BF3 ? ((BN * 6) % 256 == 0 || tid + 256 * i < BN * 6) : (BN % 64 == 0 || r0 + 64 * i < BN))
         R.b[i] = buf_load(ws, b_off[i], wsoff);
-    ++ld_stage;
-    if (VEC) {
-      // next stage's channel slab / tap, without a branch (the steady-state loop stays one basic block: the scheduler
-      // can then place every load, LDS write and fragment read between MFMAs); the per-row offsets are recomputed every
-      // stage -- ~10 VALU per row against 1024 MFMA cycles
-      // K order of the vector path: channel slab OUTERMOST, taps inside (k = cc * T * 16 + t * 16 + c): the taps of one
-      // 16-channel slab re-read the same input pixels (a 5x5 / stride-2 layer touches each ~6 times), so they now do it
-      // within T consecutive stages, from L2, instead of T * Cin / 16 stages apart, from HBM
-      const int row_end = (ld_tx + 1 == g_tw) ? 1 : 0;
-      const int tap_end = (ld_t + 1 == g_T) ? 1 : 0;
-      ld_tx = row_end ? 0 : ld_tx + 1;
-      ld_ty = tap_end ? 0 : ld_ty + row_end;
-      ld_t = tap_end ? 0 : ld_t + 1;
-      ld_cc += tap_end;
-      set_tap(ld_ty, ld_tx);
+    advance_stage();
+  };
+
+  // DMA: this wave's share of one stage, HBM / L2 -> LDS slot.  Instruction i of wave w lands on rows 16 w + 64 i ... + 15
+  // (64 lanes x 16 B, linear); the per-lane source offsets are the register path's (with the source-side swizzle in c)
+  const int my_nb = [&]() {                    // B instructions this wave issues per stage (rows 16 w + 64 i < BN)
+    int nb = 0;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) nb += ((tid >> 6) * 16 + 64 * i < BN) ? 1 : 0;
+    return nb;
+  }();
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: the LDS destination (M0) and the
+                                                                    // scalar offsets must not make the compiler build waterfall loops
+  auto dma_stage = [&](int slot) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    float* Ab = ring + __builtin_amdgcn_readfirstlane(slot) * SLOT + wave_u * 16 * kStage;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(ld_cc) * 64u;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(Ab + 64 * i * kStage), 16, (int)a_off[i], (int)soff, 0, 0);
+    float* Bb = Ab + BM * kStage;
+    const unsigned wsoff = (unsigned)__builtin_amdgcn_readfirstlane(ld_stage) * 64u;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      if (BN % 64 == 0 || wave_u * 16 + 64 * i < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(Bb + 64 * i * kStage), 16, (int)b_off[i], (int)wsoff, 0, 0);
+    advance_stage();
+  };
+  // wait until at most `stages_in_flight` of this wave's DMA stages are outstanding (vmcnt counts instructions, in order)
+  auto dma_wait = [&](int stages_in_flight) {
+    if (stages_in_flight == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (my_nb == B_CH) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH + B_CH) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH + B_CH - 1) : "memory");
     }
   };
 
@@ -576,7 +626,11 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   write_rinfo(P, rb);
   __syncthreads();
   init_loader(P, rb);
-  {
+  int dma_issued = 0;                          // DMA: stages of the current piece already on their way (slots 0 ...)
+  if (DMA) {
+    const int n = P.k1 - P.k0;
+    for (; dma_issued < 3 && dma_issued < n; ++dma_issued) dma_stage(dma_issued);
+  } else {
     const int n = P.k1 - P.k0;
     if (n > 0) load_regs(R0);
     if (RBUF && n > 1) load_regs(R1);
@@ -618,6 +672,46 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
 
+    Frag F0, F1;
+    if (DMA) {
+      // ---- direct-to-LDS pipeline: stages 0 .. 2 are (being) issued; slot of stage j is j & 3
+      for (; dma_issued < 3 && dma_issued < n; ++dma_issued) dma_stage(dma_issued);
+      // stages 0 and 1 must have landed before the first step (stage 1's fragments are prefetched in step 0)
+      dma_wait(n >= 3 ? 1 : 0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (n > 0) read_frag(F0, 0, 0);
+      auto dstep = [&](int j, auto LD, auto PF) {
+        if (decltype(LD)::value) dma_stage((j + 3) & 3);             // slot of stage j - 1, free since the last barrier
+        read_frag(F1, j & 3, 1);
+        mfma_group(F0);
+        if (decltype(PF)::value) read_frag(F0, (j + 1) & 3, 0);
+        mfma_group(F1);
+        if (decltype(LD)::value) {
+          constexpr int NW = A_CH + B_CH, NR = TM + TN, NM = 4 * TM * TN;
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, NW, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NM - 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait(decltype(LD)::value ? 1 : 0);                        // stage j + 2 has landed (stage j + 3 may still fly)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using Yes = std::integral_constant<bool, true>;
+      using No = std::integral_constant<bool, false>;
+      int j = 0;
+      for (; j + 3 < n; ++j) dstep(j, Yes{}, Yes{});
+      for (; j + 1 < n; ++j) dstep(j, No{}, Yes{});
+      if (j < n) dstep(j, No{}, No{});
+      dma_issued = 0;
+    } else {
     // ---- prologue: stages k0, k0+1 -> ring slots 0, 1; stage k0+2 in flight
     int s_cur = 0, s_n1 = 1, s_n2 = 2;
     if (n > 0) write_lds(R0, 0);
@@ -629,7 +723,6 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     }
     if (n > 2) load_regs(R0);
     __syncthreads();
-    Frag F0, F1;
     if (DBUF && n > 0) read_frag(F0, 0, 0);
 
     // one step = one stage.  WR: stage j+2 goes from registers into the ring; LD: stage j+3's global loads are issued;
@@ -679,6 +772,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
     if (n >= 3) step(Yes{}, No{}, Yes{});
     if (n >= 2) step(No{}, No{}, Yes{});
     if (n >= 1) step(No{}, No{}, No{});
+    }   // register-staged pipeline
 
     // ---- the next piece's first stages go in flight before this piece's results are stored
     Piece Q;
@@ -691,8 +785,14 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
       __syncthreads();
       init_loader(Q, qb);
       const int nq = Q.k1 - Q.k0;
-      if (nq > 0) load_regs(R0);
-      if (RBUF && nq > 1) load_regs(R1);
+      if (DMA) {
+        // the epilogue stages through the TOP of the ring; the slots below it take the next piece's first stages now
+        constexpr int NPF = (RING * SLOT - 4 * EPW) / SLOT < 2 ? (RING * SLOT - 4 * EPW) / SLOT : 2;
+        for (dma_issued = 0; dma_issued < NPF && dma_issued < nq; ++dma_issued) dma_stage(dma_issued);
+      } else {
+        if (nq > 0) load_regs(R0);
+        if (RBUF && nq > 1) load_regs(R1);
+      }
     }
 
     // ---- finish the piece that just ran.  Lane constants and kernel arguments of this phase are re-derived from an
@@ -745,7 +845,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
       // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private LDS slice (the stage
       // ring is idle after the last barrier) so that every lane owns 4 consecutive channels of one pixel: bias /
       // residual / gate operands are read and the output is written with 16-B accesses.
-      float* stage = ring + wave * EPW;
+      float* stage = ring + (DMA ? RING * SLOT - 4 * EPW : 0) + wave * EPW;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -879,6 +979,23 @@ static const void* kernel_ptr(bool vec, bool pro) {
   return reinterpret_cast<const void*>(&gg_kernel<TM, TN, WM, WN, false, true>);
 }
 
+static const void* variant_kernel_dma(int v) {
+  switch (v) {
+    case 1: return reinterpret_cast<const void*>(&gg_kernel<1, 1, 4, 1, true, false, false, true>);
+    case 2: return reinterpret_cast<const void*>(&gg_kernel<1, 2, 4, 1, true, false, false, true>);
+    case 3: return reinterpret_cast<const void*>(&gg_kernel<1, 3, 4, 1, true, false, false, true>);
+    case 4: return reinterpret_cast<const void*>(&gg_kernel<1, 4, 4, 1, true, false, false, true>);
+    case 5: return reinterpret_cast<const void*>(&gg_kernel<1, 5, 4, 1, true, false, false, true>);
+    case 8: return reinterpret_cast<const void*>(&gg_kernel<1, 1, 2, 2, true, false, false, true>);
+    case 9: return reinterpret_cast<const void*>(&gg_kernel<2, 2, 2, 2, true, false, false, true>);
+    default: return nullptr;
+  }
+}
+
+static size_t lds_bytes_dma(int v) {
+  return (size_t)4 * (gg_variant_bm(v) + gg_variant_bn(v)) * kStage * sizeof(float) + 2 * gg_variant_bm(v) * sizeof(int4);
+}
+
 static const void* variant_kernel_bf3(int v) {
   switch (v) {
     case 2: return reinterpret_cast<const void*>(&gg_kernel<1, 2, 4, 1, true, false, true>);
@@ -911,6 +1028,7 @@ static thread_local int g_init_device = -1;
 static thread_local int g_resident[kNumVariants + 1][3];      // per (variant, {vec, vec+pro, gather}) workgroups per device
 static thread_local int g_num_cus = 0;
 static thread_local int g_resident_bf3[kNumVariants + 1];
+static thread_local int g_resident_dma[kNumVariants + 1];
 
 int gg_init() {
   int dev = 0;
@@ -931,6 +1049,13 @@ int gg_init() {
       g_resident[v][k] = per_cu * g_num_cus;
     }
   }
+  for (int v : {1, 2, 3, 4, 5, 8, 9}) {
+    const void* fn = variant_kernel_dma(v);
+    SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_dma(v)));
+    int per_cu = 0;
+    SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_dma(v)));
+    g_resident_dma[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_dma(v))})) * g_num_cus;
+  }
   for (int v : {2, 4}) {
     const void* fn = variant_kernel_bf3(v);
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_bf3(v)));
@@ -947,13 +1072,18 @@ int gg_resident_blocks(int variant, bool vec, bool pro) {
   return g_resident[variant][!vec ? 2 : (pro ? 1 : 0)];
 }
 
+int gg_resident_blocks_dma(int variant) {
+  return variant >= 1 && variant <= kNumVariants && variant_kernel_dma(variant) && g_init_device >= 0 ? g_resident_dma[variant] : 0;
+}
+
 int gg_resident_blocks_bf3(int variant) {
   return (variant == 2 || variant == 4) && g_init_device >= 0 ? g_resident_bf3[variant] : 0;
 }
 
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {
   const bool pro = args.pro != SNTC_PRO_NONE;
-  const void* fn = args.bf3 ? variant_kernel_bf3(variant) : variant_kernel(variant, vec, pro || !vec);
+  const bool dma = args.dma && vec && !pro && !args.bf3 && variant_kernel_dma(variant);
+  const void* fn = args.bf3 ? variant_kernel_bf3(variant) : dma ? variant_kernel_dma(variant) : variant_kernel(variant, vec, pro || !vec);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
   if (args.bf3 && (pro || !vec)) return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 mode: vector path without prologue only");
   GGArgs a = args;
@@ -961,7 +1091,8 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
   if (const char* e = getenv("SNTC_GG_DBG")) a.dbg = atoi(e);   // diagnostic builds only (make DIAG=1): results are WRONG with it
 #endif
   void* params[] = {&a};
-  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params, args.bf3 ? lds_bytes_bf3(variant) : lds_bytes(variant), stream);
+  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params,
+                                 args.bf3 ? lds_bytes_bf3(variant) : dma ? lds_bytes_dma(variant) : lds_bytes(variant), stream);
   if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
   return SNTC_OK;
 }

@@ -77,6 +77,7 @@ struct GGArgs {
   int tps, ups;        // tiles / units per row strip (all groups): tile order is strip-major, then group, then column tile
   float* sk_slab;      // [nworkers][256 threads * 16 TN floats], raw accumulators in register layout
   int* sk_flags;       // [nworkers], zeroed on the stream before the launch
+  int dma;             // 1: direct-to-LDS staging (buffer_load ... lds, four ring slots) where the instantiation exists
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
                        // 8 skip fragment reads -- to see what the K loop waits on; results are meaningless with any bit set
@@ -93,6 +94,7 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
 int gg_reduce_launch(const GGArgs& args, hipStream_t stream);
 int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent), measures occupancy
 int gg_resident_blocks(int variant, bool vec, bool pro);   // workgroups of this instantiation the device keeps resident
+int gg_resident_blocks_dma(int variant);                    // same for the direct-to-LDS instantiations
 int gg_resident_blocks_bf3(int variant);                    // same for the bf16 x 3 instantiations (variants 2 and 4)
 size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off
 

@@ -95,9 +95,11 @@ class ConvPlan:
         """Force this plan's gather-GEMM tile variant (0 = heuristic); profiling / tests."""
         capi.call("sntc_conv_plan_set_tile", self._h, int(variant))
 
-    def set_stream_k(self, enabled):
-        """False forces the static one-workgroup-per-tile schedule for this plan (tests: identical bits either way)."""
-        capi.call("sntc_conv_plan_set_schedule", self._h, int(bool(enabled)))
+    def set_stream_k(self, enabled, dma=None):
+        """``enabled`` False forces the static one-workgroup-per-tile schedule for this plan; ``dma`` True / False forces the
+        direct-to-LDS / register stage path (None: library default).  Tests: identical bits every way."""
+        flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0)))
+        capi.call("sntc_conv_plan_set_schedule", self._h, flags)
 
     def out_hw(self, h, w):
         ho, wo = C.c_int(), C.c_int()

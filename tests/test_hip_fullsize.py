@@ -273,6 +273,15 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
     for variant in (1, 2, 3, 4, 5, 8, 9, 10):
         plan.set_tile(variant)
         assert torch.equal(plan(x, res=res), y_static), variant
+    # the two stage paths (registers + ds_write / direct-to-LDS buffer loads), under both schedules
+    for variant in (1, 2, 3, 4, 5, 8, 9):
+        plan.set_tile(variant)
+        for sk in (True, False):
+            plan.set_stream_k(sk, dma=True)
+            assert torch.equal(plan(x, res=res), y_static), (variant, sk, "dma")
+            plan.set_stream_k(sk, dma=False)
+            assert torch.equal(plan(x, res=res), y_static), (variant, sk, "registers")
+    plan.set_stream_k(True)
     plan.set_tile(0)
     one = plan(x[2:3].contiguous(), res=None if res is None else res[2:3].contiguous())
     assert torch.equal(one, y_static[2:3])

@@ -32,6 +32,7 @@ ap.add_argument("--static", action="store_true")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--ab", default="")
 ap.add_argument("--epi", action="store_true", help="residual-add epilogue")
+ap.add_argument("--dma", type=int, default=-1, help="1 / 0: force the direct-to-LDS / register stage path (default: library default)")
 ap.add_argument("--bf16x3", action="store_true", help="split-precision experiment: also run the bf16 x 3 plan and compare with fp32")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -48,8 +49,8 @@ def make(variant):
     p = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE)
     if variant:
         p.set_tile(variant)
-    if args.static:
-        p.set_stream_k(False)
+    if args.static or args.dma >= 0:
+        p.set_stream_k(not args.static, dma=None if args.dma < 0 else bool(args.dma))
     return p
 
 
