@@ -95,14 +95,13 @@ extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   return SNTC_OK;
 }
 
-// Direct-to-LDS staging by default on long contractions only (>= 48 stages per tile: 3x3 and larger kernels): measured
-// +1 ... 3 % there (tools/ab_dma.sh), while its fourth ring slot costs the short-K 1x1 layers a resident workgroup
-// (128 x 96 tile: 57 -> 48 TFLOP/s on 96 -> 192 + skip).  Bit-identical either way.
+// Direct-to-LDS staging is OFF by default.  Alone on the device it is worth +1 ... 3 % on long contractions (3x3 and larger
+// kernels, tools/ab_dma.sh) and costs the short-K 1x1 layers a resident workgroup (fourth ring slot: 57 -> 48 TFLOP/s on
+// 96 -> 192 + skip); but with two batch shapes of the Kodak set in flight on two streams (bench.py's default) its larger LDS
+// footprint leaves no room for the other stream's workgroups and the decode step went from 3.43 to 3.75 ms.  Bit-identical
+// either way (tests/test_hip_fullsize.py); kept selectable per plan.
 static bool plan_dma(const sntc_conv_plan* p) {
-  int steps = 0;
-  for (int gi = 0; gi < p->ngroups; ++gi) steps = std::max(steps, p->g[gi].K / kStage);
-  const bool want = p->dma < 0 ? steps >= 48 : p->dma != 0;
-  return want && p->vec && p->d.prologue == SNTC_PRO_NONE && !p->bf3;
+  return p->dma > 0 && p->vec && p->d.prologue == SNTC_PRO_NONE && !p->bf3;
 }
 
 extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int flags) {
