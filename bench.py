@@ -328,8 +328,12 @@ def main():
                             images_per_s=round(world * 8 * e2e_steps / t_train, 1), mpixels_per_s=mpx(8 * 256 * 256, t_train)))
         # the reference's own call pattern (mshyper/models.py:425-433, eval.py): evaluate() one image at a time -- encode,
         # rate, decode, PSNR (and MS-SSIM) per image.  "serial" synchronises after every image like the reference's eager
-        # loop; the default keeps 4 images in flight on round-robin streams (same numbers, in order).
+        # loop; the default launches same-shaped images among the next 16 four at a time and keeps 4 launches in flight on
+        # round-robin streams (each image's own numbers, in input order).
         singles = [x[i:i + 1].contiguous() for _ids, x, _hw in batches for i in range(x.shape[0])]
+        if len(singles) == 24:             # Kodak's own order: kodim04, 09, 10, 17, 18, 19 are the portrait images
+            land, port = singles[:18], singles[18:]
+            singles = [port.pop(0) if i in (3, 8, 9, 16, 17, 18) else land.pop(0) for i in range(24)]
         b1 = {}
         keep_q = model._quality_metrics
         for label, quality, look in (("psnr_only_serial", False, 1), ("psnr_only", False, 4), ("with_msssim_serial", True, 1),

@@ -334,6 +334,7 @@ struct Sched {
   int workers = 0;        // stream-K: resident workgroups
   int64_t units = 0;      // sum over groups of tiles * stages
   int64_t blocks = 0;     // workgroups launched
+  bool deep = false;      // the deep-ring direct-to-LDS instance (small launches)
 };
 
 static int max_steps(const sntc_conv_plan* p) {
@@ -375,6 +376,9 @@ static void count_work(const sntc_conv_plan* p, int v, int64_t M, int64_t* tiles
 // Tile variant: least padded multiply-adds x (rounds of resident workgroups actually run / rounds of work) -- the second
 // factor is 1 under stream-K, where every worker gets the same number of stages -- divided by the measured relative MFMA
 // rate of the tile shape.
+constexpr int kDeepBlocksPerCU = 2;
+constexpr double kDeepCost = 0.6;      // relative cost of a deep-ring launch against the rounds model below (measured, tools/b1_layers.py)
+
 static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   Sched best;
   const int64_t M = n * g.Qh * g.Qw;
@@ -405,8 +409,15 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles * ksplit;
     double cost = macs;
+    // a launch of about one workgroup per CU or fewer has nothing but its own pipeline to hide the memory latency behind:
+    // one image alone (Model.evaluate's reference flow), the hyper transforms.  Such a launch runs the deep-ring instance
+    // (six stages in flight per workgroup instead of two) where the plan allows direct-to-LDS staging at all.  Same bits.
+    s.deep = !s.sk && p->dma != 0 && p->vec && !pro && !p->bf3 && gg_resident_blocks_deep(v) > 0 &&
+             tiles * ksplit <= (int64_t)kDeepBlocksPerCU * gg_num_cus();
     if (s.sk) {
       cost *= (double)resident / workers;
+    } else if (s.deep) {
+      cost *= std::max(1.0, (double)gg_num_cus() / (double)(tiles * ksplit)) * kDeepCost;
     } else {
       const double rounds = (double)(tiles * ksplit) / resident;
       cost *= rounds < 1.0 ? 1.0 / rounds : std::ceil(rounds) / rounds;
@@ -483,7 +494,7 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   a.ntm = (int)((M + bm - 1) / bm);
   a.ngroups = p->ngroups;
   a.bf3 = p->bf3 ? 1 : 0;
-  a.dma = plan_dma(p) ? 1 : 0;
+  a.dma = sc.deep ? 2 : plan_dma(p) ? 1 : 0;
   a.sk = sc.sk ? 1 : 0;
   a.nworkers = sc.workers;
   a.units = sc.units;

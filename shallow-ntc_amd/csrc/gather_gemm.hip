@@ -147,11 +147,12 @@ __device__ __forceinline__ void split3(float x, __bf16* hi, __bf16* mid, __bf16*
 // (64 lanes x 16 B = 16 rows), so the XOR swizzle is applied to the SOURCE chunk each lane fetches.  Four ring slots: stage
 // j+3 is issued in step j, stage j+2 is waited for (counted vmcnt) before the barrier of step j, and its first fragments are
 // prefetched in step j+1.
-template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false>
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false, int DEEP = 0>
 __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
   static_assert(!BF3 || (VEC && !PRO), "the bf16 x 3 experiment covers the vector path without prologue");
   static_assert(!DMA || (VEC && !PRO && !BF3), "direct-to-LDS staging: vector path, no prologue (nothing can touch the data on the way)");
-  constexpr int RING = DMA ? 4 : 3;
+  static_assert(DEEP == 0 || (DMA && (DEEP & (DEEP - 1)) == 0 && DEEP >= 4), "DEEP: ring slots of the direct-to-LDS pipeline, a power of two");
+  constexpr int RING = DMA ? (DEEP ? DEEP : 4) : 3;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   // floats per ring slot.  fp32: A rows, then B rows, 16 floats (64 B) each.  BF3: three bf16 planes of A rows, then three of
@@ -485,17 +486,18 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(Bb + 64 * i * kStage), 16, (int)b_off[i], (int)wsoff, 0, 0);
     advance_stage();
   };
-  // wait until at most `stages_in_flight` of this wave's DMA stages are outstanding (vmcnt counts instructions, in order)
-  auto dma_wait = [&](int stages_in_flight) {
-    if (stages_in_flight == 0) {
+  // wait until at most K of this wave's DMA stages are outstanding (vmcnt counts instructions, in order); K is a compile-time
+  // constant because s_waitcnt takes an immediate
+  auto dma_wait = [&](auto K) {
+    constexpr int k = decltype(K)::value < 0 ? 0 : decltype(K)::value;
+    if (k == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (my_nb == B_CH) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH + B_CH) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k * (A_CH + B_CH)) : "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH + B_CH - 1) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k * (A_CH + B_CH - 1)) : "memory");
     }
   };
-
   auto write_lds = [&](const Regs& R, int slot) {
     float* Ab = ring + slot * SLOT;
     if (BF3) {
@@ -629,7 +631,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   int dma_issued = 0;                          // DMA: stages of the current piece already on their way (slots 0 ...)
   if (DMA) {
     const int n = P.k1 - P.k0;
-    for (; dma_issued < 3 && dma_issued < n; ++dma_issued) dma_stage(dma_issued);
+    for (; dma_issued < RING - 1 && dma_issued < n; ++dma_issued) dma_stage(dma_issued);
   } else {
     const int n = P.k1 - P.k0;
     if (n > 0) load_regs(R0);
@@ -674,18 +676,34 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
 
     Frag F0, F1;
     if (DMA) {
-      // ---- direct-to-LDS pipeline: stages 0 .. 2 are (being) issued; slot of stage j is j & 3
-      for (; dma_issued < 3 && dma_issued < n; ++dma_issued) dma_stage(dma_issued);
+      // ---- direct-to-LDS pipeline: stages 0 .. RING-2 are (being) issued; slot of stage j is j & (RING-1).  Step j issues
+      // stage j + RING - 1 into the slot stage j - 1 left at the last barrier and ends once stage j + 2 has landed, so
+      // RING - 3 younger stages stay in flight across the barrier (1 with the 4-slot ring; 5 with the 8-slot ring of
+      // the DEEP instances, which launches too small to hide the memory latency behind other workgroups are given)
+      for (; dma_issued < RING - 1 && dma_issued < n; ++dma_issued) dma_stage(dma_issued);
       // stages 0 and 1 must have landed before the first step (stage 1's fragments are prefetched in step 0)
-      dma_wait(n >= 3 ? 1 : 0);
+      using Yes = std::integral_constant<bool, true>;
+      using No = std::integral_constant<bool, false>;
+      auto wait_first = [&](auto I) {           // issued = min(n, RING - 1) stages; all but the first two may still fly
+        constexpr int i = decltype(I)::value;
+        if constexpr (i > 2) {
+          if (n >= i) { dma_wait(std::integral_constant<int, i - 2>{}); return true; }
+        }
+        return false;
+      };
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        if (!(wait_first(std::integral_constant<int, RING - 1 - I>{}) || ...)) dma_wait(std::integral_constant<int, 0>{});
+      }(std::make_integer_sequence<int, RING - 3>{});
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (n > 0) read_frag(F0, 0, 0);
-      auto dstep = [&](int j, auto LD, auto PF) {
-        if (decltype(LD)::value) dma_stage((j + 3) & 3);             // slot of stage j - 1, free since the last barrier
-        read_frag(F1, j & 3, 1);
+      // REM: steps left including this one when no stage is left to issue (compile-time, for the counted wait); -1 in the
+      // steady state
+      auto dstep = [&](int j, auto LD, auto PF, auto REM) {
+        if (decltype(LD)::value) dma_stage((j + RING - 1) & (RING - 1));   // slot of stage j - 1, free since the last barrier
+        read_frag(F1, j & (RING - 1), 1);
         mfma_group(F0);
-        if (decltype(PF)::value) read_frag(F0, (j + 1) & 3, 0);
+        if (decltype(PF)::value) read_frag(F0, (j + 1) & (RING - 1), 0);
         mfma_group(F1);
         if (decltype(LD)::value) {
           constexpr int NW = A_CH + B_CH, NR = TM + TN, NM = 4 * TM * TN;
@@ -699,17 +717,27 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
           __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        dma_wait(decltype(LD)::value ? 1 : 0);                        // stage j + 2 has landed (stage j + 3 may still fly)
+        // stage j + 2 has landed; the younger ones may still fly
+        if constexpr (decltype(LD)::value) dma_wait(std::integral_constant<int, RING - 3>{});
+        else dma_wait(std::integral_constant<int, decltype(REM)::value - 3>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
-      using Yes = std::integral_constant<bool, true>;
-      using No = std::integral_constant<bool, false>;
       int j = 0;
-      for (; j + 3 < n; ++j) dstep(j, Yes{}, Yes{});
-      for (; j + 1 < n; ++j) dstep(j, No{}, Yes{});
-      if (j < n) dstep(j, No{}, No{});
+      for (; j + RING - 1 < n; ++j) dstep(j, Yes{}, Yes{}, std::integral_constant<int, -1>{});
+      // the last RING - 1 (or fewer) steps: everything is issued, the counted wait shrinks with the steps left
+      auto tail = [&](auto REM) {
+        constexpr int rem = decltype(REM)::value;
+        if (n - j == rem) {
+          if constexpr (rem > 1) dstep(j, No{}, Yes{}, REM);
+          else dstep(j, No{}, No{}, REM);
+          ++j;
+        }
+      };
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (tail(std::integral_constant<int, RING - 1 - I>{}), ...);
+      }(std::make_integer_sequence<int, RING - 1>{});
       dma_issued = 0;
     } else {
     // ---- prologue: stages k0, k0+1 -> ring slots 0, 1; stage k0+2 in flight
@@ -787,7 +815,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
       const int nq = Q.k1 - Q.k0;
       if (DMA) {
         // the epilogue stages through the TOP of the ring; the slots below it take the next piece's first stages now
-        constexpr int NPF = (RING * SLOT - 4 * EPW) / SLOT < 2 ? (RING * SLOT - 4 * EPW) / SLOT : 2;
+        constexpr int NPF = (RING * SLOT - 4 * EPW) / SLOT < RING - 1 ? (RING * SLOT - 4 * EPW) / SLOT : RING - 1;
         for (dma_issued = 0; dma_issued < NPF && dma_issued < nq; ++dma_issued) dma_stage(dma_issued);
       } else {
         if (nq > 0) load_regs(R0);
@@ -996,6 +1024,20 @@ static size_t lds_bytes_dma(int v) {
   return (size_t)4 * (gg_variant_bm(v) + gg_variant_bn(v)) * kStage * sizeof(float) + 2 * gg_variant_bm(v) * sizeof(int4);
 }
 
+// 8-slot ring (six stages in flight per workgroup) for launches of about one workgroup per CU or fewer, where nothing else
+// hides the memory latency: the 64 x 64 tile, which is what such launches are cut into
+constexpr int kDeepRing = 8;
+static const void* variant_kernel_deep(int v) {
+  switch (v) {
+    case 8: return reinterpret_cast<const void*>(&gg_kernel<1, 1, 2, 2, true, false, false, true, kDeepRing>);
+    default: return nullptr;
+  }
+}
+
+static size_t lds_bytes_deep(int v) {
+  return (size_t)kDeepRing * (gg_variant_bm(v) + gg_variant_bn(v)) * kStage * sizeof(float) + 2 * gg_variant_bm(v) * sizeof(int4);
+}
+
 static const void* variant_kernel_bf3(int v) {
   switch (v) {
     case 2: return reinterpret_cast<const void*>(&gg_kernel<1, 2, 4, 1, true, false, true>);
@@ -1029,6 +1071,7 @@ static thread_local int g_resident[kNumVariants + 1][3];      // per (variant, {
 static thread_local int g_num_cus = 0;
 static thread_local int g_resident_bf3[kNumVariants + 1];
 static thread_local int g_resident_dma[kNumVariants + 1];
+static thread_local int g_resident_deep[kNumVariants + 1];
 
 int gg_init() {
   int dev = 0;
@@ -1056,6 +1099,13 @@ int gg_init() {
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_dma(v)));
     g_resident_dma[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_dma(v))})) * g_num_cus;
   }
+  for (int v : {8}) {
+    const void* fn = variant_kernel_deep(v);
+    SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_deep(v)));
+    int per_cu = 0;
+    SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_deep(v)));
+    g_resident_deep[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_deep(v))})) * g_num_cus;
+  }
   for (int v : {2, 4}) {
     const void* fn = variant_kernel_bf3(v);
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_bf3(v)));
@@ -1076,14 +1126,22 @@ int gg_resident_blocks_dma(int variant) {
   return variant >= 1 && variant <= kNumVariants && variant_kernel_dma(variant) && g_init_device >= 0 ? g_resident_dma[variant] : 0;
 }
 
+int gg_resident_blocks_deep(int variant) {
+  return variant >= 1 && variant <= kNumVariants && variant_kernel_deep(variant) && g_init_device >= 0 ? g_resident_deep[variant] : 0;
+}
+
+int gg_num_cus() { return g_init_device >= 0 ? g_num_cus : 0; }
+
 int gg_resident_blocks_bf3(int variant) {
   return (variant == 2 || variant == 4) && g_init_device >= 0 ? g_resident_bf3[variant] : 0;
 }
 
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {
   const bool pro = args.pro != SNTC_PRO_NONE;
-  const bool dma = args.dma && vec && !pro && !args.bf3 && variant_kernel_dma(variant);
-  const void* fn = args.bf3 ? variant_kernel_bf3(variant) : dma ? variant_kernel_dma(variant) : variant_kernel(variant, vec, pro || !vec);
+  const bool deep = args.dma == 2 && vec && !pro && !args.bf3 && variant_kernel_deep(variant);
+  const bool dma = !deep && args.dma && vec && !pro && !args.bf3 && variant_kernel_dma(variant);
+  const void* fn = args.bf3 ? variant_kernel_bf3(variant) : deep ? variant_kernel_deep(variant) : dma ? variant_kernel_dma(variant)
+                            : variant_kernel(variant, vec, pro || !vec);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
   if (args.bf3 && (pro || !vec)) return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 mode: vector path without prologue only");
   GGArgs a = args;
@@ -1092,7 +1150,7 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
 #endif
   void* params[] = {&a};
   hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(256), params,
-                                 args.bf3 ? lds_bytes_bf3(variant) : dma ? lds_bytes_dma(variant) : lds_bytes(variant), stream);
+                                 args.bf3 ? lds_bytes_bf3(variant) : deep ? lds_bytes_deep(variant) : dma ? lds_bytes_dma(variant) : lds_bytes(variant), stream);
   if (e != hipSuccess) return hip_fail(e, "gather-GEMM launch");
   return SNTC_OK;
 }

@@ -94,6 +94,8 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
 int gg_reduce_launch(const GGArgs& args, hipStream_t stream);
 int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idempotent), measures occupancy
 int gg_resident_blocks(int variant, bool vec, bool pro);   // workgroups of this instantiation the device keeps resident
+int gg_resident_blocks_deep(int variant);                   // same for the deep-ring (8-slot) direct-to-LDS instances; 0 if none
+int gg_num_cus();
 int gg_resident_blocks_dma(int variant);                    // same for the direct-to-LDS instantiations
 int gg_resident_blocks_bf3(int variant);                    // same for the bf16 x 3 instantiations (variants 2 and 4)
 size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off

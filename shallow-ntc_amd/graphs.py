@@ -35,3 +35,4 @@ class DecodeGraph:
             self.symbols.copy_(symbols)
         self.graph.replay()
         return self.out
+

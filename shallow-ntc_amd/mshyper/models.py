@@ -350,50 +350,85 @@ class Model:
         _, metrics = self.end_to_end_frame_loss(image_batch, training=training)
         return metrics
 
-    def evaluate(self, images, lookahead=4):
+    def evaluate(self, images, lookahead=4, group=4):
         """Reference :415-433: a [B,H,W,3] tensor is evaluated one [1,H,W,3] image at a time, an
         iterable is taken as is; yields one Metrics per image, in order.
 
-        Same numbers as the reference's loop, but not its stalls: up to ``lookahead`` images are in flight on
-        round-robin HIP streams before the oldest one's results are copied to the host, so image i + 1's encoder
-        overlaps image i's decoder tail and the device never waits for Python.  lookahead=1 is the strictly serial
-        reference behaviour."""
-        if isinstance(images, (torch.Tensor, np.ndarray)):
+        Same numbers as the reference's loop, image by image and in order, but not its stalls.  One image alone leaves most
+        of the GPU idle (a 512 x 768 image is 72 ... 288 workgroups per layer on 256 CUs), so up to ``group`` images OF THE
+        SAME SHAPE among the next ``lookahead * group`` are launched as one batch -- every kernel on this path gives an
+        image bit-identical results alone or inside any batch -- and up to ``lookahead`` such launches are
+        in flight on round-robin HIP streams before the oldest one's results are copied to the host, so the device never
+        waits for Python.  lookahead=1 is the strictly serial one-image-per-pass reference behaviour."""
+        tensor_input = isinstance(images, (torch.Tensor, np.ndarray))
+        if tensor_input:
             images = [images[i:i + 1] for i in range(images.shape[0])]
-        lookahead = max(1, int(lookahead))
+        lookahead, group = max(1, int(lookahead)), max(1, int(group))
         if lookahead == 1:
             for img in images:
                 _, metrics = self.end_to_end_frame_loss(img, training=False)
                 yield metrics
             return
+        if self._profile:
+            group = 1                                                 # per-transform times are per pass
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
             if getattr(self, "_eval_streams", None) is None or len(self._eval_streams) < lookahead:
                 self._eval_streams = [torch.cuda.Stream(device=self.device) for _ in range(lookahead)]
-            inflight = []
+            window = []                  # entries in input order: [x, metrics or None, launched]
+            inflight = []                # (stream, pending, entries)
             it = iter(images)
             k = 0
             done = False
             while True:
-                while not done and len(inflight) < lookahead:
+                while not done and len(window) < lookahead * group:
                     try:
-                        img = next(it)
+                        window.append([self._as_device_images(next(it)), None, False])
                     except StopIteration:
                         done = True
+                while len(inflight) < lookahead:
+                    first = next((e for e in window if not e[2]), None)
+                    if first is None:
                         break
+                    members = [e for e in window if not e[2] and e[0].shape == first[0].shape][:group]
+                    if first[0].shape[0] != 1:
+                        members = [first]                             # an iterable of batches: each is taken as it is
+                    for e in members:
+                        e[2] = True
                     st = self._eval_streams[k % lookahead]
                     k += 1
                     st.wait_stream(cur)
                     with torch.cuda.stream(st):
-                        inflight.append((st, self._launch_frame(img)))
+                        x = members[0][0] if len(members) == 1 else torch.cat([e[0] for e in members])
+                        inflight.append((st, self._launch_frame(x), members))
                 if not inflight:
                     break
-                st, pending = inflight.pop(0)
+                st, pending, members = inflight.pop(0)
                 with torch.cuda.stream(st):
-                    _, metrics = self._finish_frame(pending)
-                yield metrics
+                    for e, (_, metrics) in zip(members, self._finish_frames(pending, len(members))):
+                        e[1] = metrics
+                while window and window[0][1] is not None:
+                    yield window.pop(0)[1]
             for st in self._eval_streams:
                 cur.wait_stream(st)
+
+    def _finish_frames(self, pending, count):
+        """``_finish_frame`` for a launch that holds ``count`` one-image frames: one host copy, then each image's own
+        metrics exactly as if it had been launched alone."""
+        if count == 1:
+            return [self._finish_frame(pending)]
+        host = pending["dev"].cpu().numpy()
+        msssim = None
+        if pending["quality"] is not None:
+            sums, counts, single = pending["quality"]
+            msssim = ops.image_quality_finish(sums.cpu().numpy(), counts, single)
+        out = []
+        for i in range(count):
+            rd_loss, metrics = self._finish_metrics((1,) + tuple(pending["shape"][1:]), host[0][i:i + 1], host[1][i:i + 1],
+                                                    host[2][i:i + 1], None if msssim is None else msssim[i:i + 1])
+            metrics.record_image("reconstruction", pending["recon"][i:i + 1])
+            out.append((rd_loss, metrics))
+        return out
 
     def evaluate_batched(self, images):
         """Same numbers as ``evaluate`` for same-shaped images, but one launch sequence for the whole

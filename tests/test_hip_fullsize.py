@@ -75,6 +75,28 @@ def test_portrait_and_padded_sizes(kodak_model, dev):
     assert np.isfinite(met["bpp"]) and np.isfinite(met["psnr"])
 
 
+def test_evaluate_groups_same_shaped_images_without_changing_a_number(kodak_model, dev):
+    """Model.evaluate() launches same-shaped images of its look-ahead window together (Kodak: landscape and portrait
+    interleaved); every image's metrics -- bpp, PSNR, MS-SSIM, rd_loss -- and its reconstruction are those of the strictly
+    serial one-image-per-pass loop of the reference (mshyper/models.py:415-433), in input order."""
+    from shallow_ntc_amd.common import data_lib
+    m = kodak_model
+    shapes = [(512, 768), (512, 768), (768, 512), (512, 768), (768, 512), (512, 768), (512, 768)]
+    imgs = [t(data_lib.normalize_image(data_lib.synthetic_images(1, h, w, seed=20 + i)), dev) for i, (h, w) in enumerate(shapes)]
+    keep = m._quality_metrics
+    m._quality_metrics = True
+    try:
+        serial = list(m.evaluate(imgs, lookahead=1))
+        grouped = list(m.evaluate(iter(imgs), lookahead=2, group=4))
+    finally:
+        m._quality_metrics = keep
+    assert len(grouped) == len(imgs) and "msssim" in serial[0].scalars_float
+    for a, b, (h, w) in zip(serial, grouped, shapes):
+        assert a.scalars_float == b.scalars_float
+        assert tuple(b.images["reconstruction"].shape) == (1, h, w, 3)
+        assert torch.equal(a.images["reconstruction"], b.images["reconstruction"])
+
+
 @pytest.mark.parametrize("kind,k,s,cin,cout,h,w", [("convT", 13, 8, 320, 24, 32, 48), ("convT", 5, 2, 320, 480, 16, 24),
                                                    ("convT", 3, 1, 480, 640, 32, 48), ("convT", 18, 16, 320, 3, 32, 48),
                                                    ("conv", 5, 2, 192, 192, 128, 192), ("conv", 3, 1, 96, 96, 64, 96)])

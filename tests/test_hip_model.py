@@ -150,6 +150,18 @@ def test_mshyper_model_parity(synth, dev):
     serial = [mm.scalars_float for mm in model.evaluate(many, lookahead=1)]
     piped = [mm.scalars_float for mm in model.evaluate(many, lookahead=3)]
     assert serial == piped and serial[0] == ms[0].scalars_float and serial[1] == ms[1].scalars_float
+    # images of the same shape among the next few are launched together: still each image's own numbers, in input order,
+    # whatever the grouping; the recorded reconstructions are each image's own
+    other = data_lib.normalize_image(data_lib.synthetic_images(2, 150, 100, seed=8))
+    solo = [mm.scalars_float for mm in model.evaluate(other, lookahead=1)]
+    mixed = [x[0:1], other[0:1], x[1:2], x[0:1], other[1:2], x[1:2], x[0:1]]
+    want = [serial[0], solo[0], serial[1], serial[0], solo[1], serial[1], serial[0]]
+    for look, group in ((2, 2), (4, 4), (3, 1)):
+        out = list(model.evaluate(iter(mixed), lookahead=look, group=group))
+        assert [mm.scalars_float for mm in out] == want, (look, group)
+        rec = [mm.images["reconstruction"] for mm in out]
+        assert all(r.shape[0] == 1 for r in rec) and rec[1].shape[1] > rec[1].shape[2] and rec[0].shape[1] < rec[0].shape[2]
+        assert torch.equal(rec[0], rec[3]) and torch.equal(rec[2], rec[5]) and not torch.equal(rec[0], rec[2])
     # codec regions: decode(encode(x)) reproduces the evaluated reconstruction bit for bit
     z_hat, sym, bz, by = model.encode(x)
     px, sse = model.decode(z_hat, sym, (100, 150), reference=torch.from_numpy(x).to(dev))
