@@ -386,7 +386,7 @@ def main():
             for e in ops.PROFILE:
                 vec = "true, false" if e["vec"] else "false, true"      # <TM,TN,WM,WN,VEC,PRO> as rocprof prints it
                 shape = {8: "1, 1, 2, 2", 9: "2, 2, 2, 2", 10: "2, 4, 4, 1"}.get(e["variant"], f"1, {e['variant']}, 4, 1")
-                name = f"gg_kernel<{shape}, {vec}, false>"        # trailing false: not the bf16 x 3 experiment
+                name = f"gg_kernel<{shape}, {vec}, false, false, 0>"   # <..., BF3, DMA, DEEP>: the default fp32 register-staged instance
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
                 k["flops"] += e["flops"]
