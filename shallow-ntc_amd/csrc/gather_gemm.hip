@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[BF3 ? PA[t] : 0][i], F.b[BF3 ? PB[t] : 0][j], acc[i][j], 0, 0, 0);
   };
   auto mfma_group = [&](const Frag& F) {
+    if (SNTC_DBG(a, 64)) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -913,8 +914,9 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
           f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * wfl + c4) + bv;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
-          if (a.epi != SNTC_EPI_STORE) v = apply_epilogue(v, a.epi, *reinterpret_cast<const f32x4*>(a.res + idx), a.aux, idx);
-          *reinterpret_cast<f32x4*>(a.y + idx) = v;
+          if (a.epi != SNTC_EPI_STORE)
+            v = apply_epilogue(v, a.epi, SNTC_DBG(a, 32) ? v : *reinterpret_cast<const f32x4*>(a.res + idx), a.aux, idx);
+          if (!SNTC_DBG(a, 16) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(a.y + idx) = v;
         }
       }
     } else {
