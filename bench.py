@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
                          "the host already runs ahead of the GPU)")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="A/B: run the ResidualBlock tails as two launches instead of the fused one (same bits)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous the ranks and run the path's collectives (no kernels); prints a dry-run line")
     args = ap.parse_args()
@@ -152,6 +154,8 @@ def main():
         return launch_check(args)
     from shallow_ntc_amd import distributed as D
     from shallow_ntc_amd import ops
+    if args.no_fuse:
+        ops.FUSE_RESIDUAL_TAIL = False
     from shallow_ntc_amd.mshyper import configs
     from shallow_ntc_amd.mshyper.models import Model
 
@@ -386,7 +390,8 @@ def main():
             for e in ops.PROFILE:
                 vec = "true, false" if e["vec"] else "false, true"      # <TM,TN,WM,WN,VEC,PRO> as rocprof prints it
                 shape = {8: "1, 1, 2, 2", 9: "2, 2, 2, 2", 10: "2, 4, 4, 1"}.get(e["variant"], f"1, {e['variant']}, 4, 1")
-                name = f"gg_kernel<{shape}, {vec}, false, false, 0>"   # <..., BF3, DMA, DEEP>: the default fp32 register-staged instance
+                # <..., BF3, DMA, DEEP, FUSE2>: the default fp32 register-staged instance, or the fused ResidualBlock tail
+                name = f"gg_kernel<{shape}, {vec}, false, false, 0, {'true' if '+1x1' in e['kind'] else 'false'}>"
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
                 k["flops"] += e["flops"]

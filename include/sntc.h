@@ -118,6 +118,16 @@ int sntc_conv_forward(const sntc_conv_plan* plan, const float* x, int n, int h, 
  * convolutions) are split along K into slabs that a second kernel adds in a fixed order; the split depends on the
  * layer and the image shape only.  Either way results are bit-identical for any batch size. */
 int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int w);
+/* The tail of a ResidualBlock (reference common/elic.py:57-68: conv3x3(c/2 -> c/2, relu) -> conv1x1(c/2 -> c), + x) in ONE
+ * launch for c = 192: `first` is the 3x3 plan (stride-1 forward convolution, 96 output channels, plain store), `second` the
+ * 1x1 plan 96 -> 192 (no activation; its epilogue -- SNTC_EPI_ADD for the skip -- and `res` / `aux` apply to the final output
+ * y[n,ho,wo,192]).  The 96-channel intermediate stays in registers; the result is bit-identical to sntc_conv_forward(first)
+ * followed by sntc_conv_forward(second).  sntc_conv_fusable() says whether a pair qualifies (1) or not (0);
+ * sntc_conv_fused_workspace_bytes() is the scratch this call needs (as sntc_conv_workspace_bytes). */
+int sntc_conv_fusable(const sntc_conv_plan* first, const sntc_conv_plan* second);
+int64_t sntc_conv_fused_workspace_bytes(const sntc_conv_plan* first, int n, int h, int w);
+int sntc_conv_forward_fused(const sntc_conv_plan* first, sntc_conv_plan* second, const float* x, int n, int h, int w, float* y,
+                            const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream);
 /* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
  * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */
 int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);

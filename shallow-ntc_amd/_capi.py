@@ -50,6 +50,9 @@ SIGNATURES = {
     "sntc_conv_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_conv_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "sntc_conv_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
+    "sntc_conv_fusable": (C.c_int, [_P, _P]),
+    "sntc_conv_fused_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
+    "sntc_conv_forward_fused": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "sntc_conv_plan_set_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "sntc_conv_plan_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "sntc_conv_launch_info": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -59,6 +59,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// W2 of a fused ResidualBlock tail, from the 1x1 plan's packed [Ncol = 192][K = 96] rows into the order the FUSE2 instance
+// copies to LDS and reads as MFMA B fragments: [half hf][column tile t][k-quad pair Q][lane][e] = W2[k = 8 Q + 4 (lane / 32) + e]
+// [n = 96 hf + 32 t + lane % 32]
+__global__ void pack_fused_w2_kernel(const float* __restrict__ wp, float* __restrict__ w2f, int K, int Ncol) {
+  const int total = 2 * 3 * 12 * 64 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63, Q = (i >> 8) % 12, t = ((i >> 8) / 12) % 3, hf = (i >> 8) / 36;
+    const int k = 8 * Q + 4 * (lane >> 5) + e, n = 96 * hf + 32 * t + (lane & 31);
+    w2f[i] = (k < K && n < Ncol) ? wp[(size_t)n * K + k] : 0.0f;
+  }
+}
+
 }  // namespace sntc
 
 using namespace sntc;
@@ -86,6 +98,8 @@ struct sntc_conv_plan {
   bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
   int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
+  float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (built on first fused use)
+  bool w2f_stale = true;
 };
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
@@ -119,6 +133,7 @@ extern "C" void sntc_conv_plan_destroy(sntc_conv_plan* p) {
     if (p->g[i].cols) (void)hipFree(p->g[i].cols);
   }
   if (p->bias) (void)hipFree(p->bias);
+  if (p->w2f) (void)hipFree(p->w2f);
   delete p;
 }
 
@@ -272,6 +287,7 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
     SNTC_HIP(hipGetLastError());
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));
+  p->w2f_stale = true;
   return SNTC_OK;
 }
 
@@ -379,22 +395,22 @@ static void count_work(const sntc_conv_plan* p, int v, int64_t M, int64_t* tiles
 constexpr int kDeepBlocksPerCU = 2;
 constexpr double kDeepCost = 0.6;      // relative cost of a deep-ring launch against the rounds model below (measured, tools/b1_layers.py)
 
-static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
+static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fused = false) {
   Sched best;
   const int64_t M = n * g.Qh * g.Qw;
-  const int ksplit = pick_ksplit(p, g);
+  const int ksplit = fused ? 1 : pick_ksplit(p, g);
   const int msteps = max_steps(p);
   const bool pro = p->d.prologue != SNTC_PRO_NONE;
   double best_cost = 1e300;
   for (int v = 1; v <= kNumVariants; ++v) {
-    if (p->tile >= 1 && p->tile <= kNumVariants && v != p->tile) continue;
+    if (fused ? v != 3 : (p->tile >= 1 && p->tile <= kNumVariants && v != p->tile)) continue;
     if (p->tile == 0 && (v == 6 || v == 7 || v == 10)) continue;   // single-buffered / one wave per SIMD: tests only
     if (p->bf3 && v != 2 && v != 4) continue;                       // the bf16 x 3 experiment is instantiated for two tile shapes
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
-    const bool dma = plan_dma(p) && gg_resident_blocks_dma(v) > 0;
-    const int resident = std::max(1, p->bf3 ? gg_resident_blocks_bf3(v) : dma ? gg_resident_blocks_dma(v) : gg_resident_blocks(v, p->vec, pro));
+    const bool dma = !fused && plan_dma(p) && gg_resident_blocks_dma(v) > 0;
+    const int resident = std::max(1, fused ? gg_resident_blocks_fused() : p->bf3 ? gg_resident_blocks_bf3(v) : dma ? gg_resident_blocks_dma(v) : gg_resident_blocks(v, p->vec, pro));
     Sched s;
     s.variant = v;
     s.ksplit = ksplit;
@@ -412,7 +428,7 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     // a launch of about one workgroup per CU or fewer has nothing but its own pipeline to hide the memory latency behind:
     // one image alone (Model.evaluate's reference flow), the hyper transforms.  Such a launch runs the deep-ring instance
     // (six stages in flight per workgroup instead of two) where the plan allows direct-to-LDS staging at all.  Same bits.
-    s.deep = !s.sk && p->dma != 0 && p->vec && !pro && !p->bf3 && gg_resident_blocks_deep(v) > 0 &&
+    s.deep = !fused && !s.sk && p->dma != 0 && p->vec && !pro && !p->bf3 && gg_resident_blocks_deep(v) > 0 &&
              tiles * ksplit <= (int64_t)kDeepBlocksPerCU * gg_num_cus();
     if (s.sk) {
       cost *= (double)resident / workers;
@@ -459,14 +475,15 @@ extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int 
   return SNTC_OK;
 }
 
-extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n, int h, int w, float* y,
-                                 const float* res, const float* aux, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+// One launch of plan p; with p2 (validated by sntc_conv_forward_fused) the 1x1 plan p2 runs behind p inside the same launch.
+static int conv_forward_impl(const sntc_conv_plan* p, sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
+                             const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream) {
   if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: null argument");
   if (n < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: empty batch");
   const sntc_conv_desc& d = p->d;
-  if (d.epilogue != SNTC_EPI_STORE && !res) return fail(SNTC_ERR_BAD_SHAPE, "epilogue needs `res`");
-  if (d.epilogue == SNTC_EPI_GATE && !aux) return fail(SNTC_ERR_BAD_SHAPE, "gate epilogue needs `aux`");
+  const int epilogue = p2 ? p2->d.epilogue : d.epilogue;
+  if (epilogue != SNTC_EPI_STORE && !res) return fail(SNTC_ERR_BAD_SHAPE, "epilogue needs `res`");
+  if (epilogue == SNTC_EPI_GATE && !aux) return fail(SNTC_ERR_BAD_SHAPE, "gate epilogue needs `aux`");
   Geo g;
   int rc = geometry(p, h, w, &g);
   if (rc) return rc;
@@ -474,7 +491,8 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   const int64_t x_bytes = (int64_t)n * h * w * d.cin * 4;
   if (M > 0x7fffffffLL || x_bytes >= (1LL << 31))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: input tensor must be < 2 GiB (32-bit buffer offsets); split the batch");
-  const Sched sc = schedule(p, g, n);
+  if (p2 && M * p2->d.cout >= (1LL << 32)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward_fused: output too large; split the batch");
+  const Sched sc = schedule(p, g, n, p2 != nullptr);
   const int64_t ws_floats = workspace_floats(p, M, sc);
   if (ws_floats > 0 && (!workspace || workspace_bytes < (size_t)ws_floats * 4))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: this call needs sntc_conv_workspace_bytes() of workspace "
@@ -490,11 +508,20 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   a.Qh = g.Qh; a.Qw = g.Qw; a.M = (int)M;
   a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = d.cout;
   a.sA = g.sA; a.tstep = g.tstep; a.offy = g.offy; a.offx = g.offx; a.sO = g.sO;
-  a.act = d.act; a.epi = d.epilogue; a.pro = d.prologue;
+  a.act = d.act; a.epi = epilogue; a.pro = d.prologue;
   a.ntm = (int)((M + bm - 1) / bm);
   a.ngroups = p->ngroups;
   a.bf3 = p->bf3 ? 1 : 0;
-  a.dma = sc.deep ? 2 : plan_dma(p) ? 1 : 0;
+  a.dma = p2 ? 0 : sc.deep ? 2 : plan_dma(p) ? 1 : 0;
+  if (p2) {
+    if (!p2->w2f) SNTC_HIP(hipMalloc(&p2->w2f, sizeof(float) * 2 * 3 * 12 * 64 * 4));
+    if (p2->w2f_stale) {
+      hipLaunchKernelGGL(pack_fused_w2_kernel, dim3(72), dim3(256), 0, (hipStream_t)stream, p2->g[0].wp, p2->w2f, p2->g[0].K, p2->g[0].Ncol);
+      SNTC_HIP(hipGetLastError());
+      p2->w2f_stale = false;
+    }
+    a.w2f = p2->w2f; a.bias2 = p2->bias; a.Cout2 = p2->d.cout;
+  }
   a.sk = sc.sk ? 1 : 0;
   a.nworkers = sc.workers;
   a.units = sc.units;
@@ -528,4 +555,40 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
   rc = gg_launch(v, p->vec, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
   if (rc || sc.sk || sc.ksplit <= 1) return rc;
   return gg_reduce_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n, int h, int w, float* y,
+                                 const float* res, const float* aux, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  return conv_forward_impl(p, nullptr, x, n, h, w, y, res, aux, workspace, workspace_bytes, stream);
+}
+
+// ResidualBlock tail (reference common/elic.py:41-68): y = epilogue2(conv1x1_p2(act1(conv3x3_p1(x) + b1)) + b2, res) in ONE
+// launch -- the 96-channel intermediate never leaves the registers.  Bit-identical to the two launches.
+static const char* fused_pair_error(const sntc_conv_plan* p, const sntc_conv_plan* p2) {
+  if (!p || !p2) return "null plan";
+  const sntc_conv_desc &a = p->d, &b = p2->d;
+  if (p->up || p2->up || p->bf3 || p2->bf3) return "forward convolutions in fp32 only";
+  if (!p->vec || a.cout != 96 || a.stride != 1 || a.prologue != SNTC_PRO_NONE || a.epilogue != SNTC_EPI_STORE || p->ngroups != 1)
+    return "first plan: stride-1 convolution with Cin % 16 == 0 and 96 output channels, plain store";
+  if (b.kh != 1 || b.kw != 1 || b.stride != 1 || b.cin != 96 || b.cout != 192 || b.prologue != SNTC_PRO_NONE ||
+      b.act != SNTC_ACT_NONE || p2->ngroups != 1 || p2->g[0].K != 96)
+    return "second plan: 1x1 convolution 96 -> 192 without activation";
+  return nullptr;
+}
+
+extern "C" int sntc_conv_fusable(const sntc_conv_plan* p, const sntc_conv_plan* p2) { return fused_pair_error(p, p2) ? 0 : 1; }
+
+extern "C" int64_t sntc_conv_fused_workspace_bytes(const sntc_conv_plan* p, int n, int h, int w) {
+  if (!p) return 0;
+  Geo g;
+  if (geometry(p, h, w, &g)) return 0;
+  return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, schedule(p, g, n, true));
+}
+
+extern "C" int sntc_conv_forward_fused(const sntc_conv_plan* p, sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
+                                       const float* res, const float* aux, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  if (const char* why = fused_pair_error(p, p2)) return fail(SNTC_ERR_UNSUPPORTED, why);
+  return conv_forward_impl(p, p2, x, n, h, w, y, res, aux, workspace, workspace_bytes, stream);
 }

@@ -147,10 +147,12 @@ __device__ __forceinline__ void split3(float x, __bf16* hi, __bf16* mid, __bf16*
 // (64 lanes x 16 B = 16 rows), so the XOR swizzle is applied to the SOURCE chunk each lane fetches.  Four ring slots: stage
 // j+3 is issued in step j, stage j+2 is waited for (counted vmcnt) before the barrier of step j, and its first fragments are
 // prefetched in step j+1.
-template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false, int DEEP = 0>
-__global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false, int DEEP = 0, bool FUSE2 = false>
+__global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
   static_assert(!BF3 || (VEC && !PRO), "the bf16 x 3 experiment covers the vector path without prologue");
   static_assert(!DMA || (VEC && !PRO && !BF3), "direct-to-LDS staging: vector path, no prologue (nothing can touch the data on the way)");
+  static_assert(!FUSE2 || (TM == 1 && TN == 3 && WM == 4 && WN == 1 && VEC && !PRO && !BF3 && !DMA),
+                "FUSE2: 3x3 (N = 96) -> 1x1 (96 -> 192) of a ResidualBlock, the 128 x 96 register-staged instance only");
   static_assert(DEEP == 0 || (DMA && (DEEP & (DEEP - 1)) == 0 && DEEP >= 4), "DEEP: ring slots of the direct-to-LDS pipeline, a power of two");
   constexpr int RING = DMA ? (DEEP ? DEEP : 4) : 3;
   constexpr int BM = WM * TM * 32;
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
   constexpr int EPW = 32 * (TN >= 2 ? 64 : 32);       // floats of epilogue staging per wave
   constexpr bool DBUF = !BF3 && TM * TN <= 8 && TN <= 5;   // fragment double buffering (the two widest 32-row tiles, 96+ accumulator
                                                       // registers and 7-8 fragment quads, run single-buffered)
-  constexpr bool RBUF = DBUF && TM * TN <= 3;         // second staging register set for a tile's first two stages
+  constexpr bool RBUF = DBUF && TM * TN <= 3 && !FUSE2;         // second staging register set for a tile's first two stages
   static_assert(RING * SLOT >= 4 * EPW + (DMA ? SLOT : 0), "epilogue staging (and one prefetched stage) must fit in the stage ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ring = reinterpret_cast<float*>(smem);                  // [RING][BM + BN][16]
@@ -618,7 +620,8 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[i][e], F.b[j][e], acc[i][j], 0, 0, 0);
+          acc[i][j] = FUSE2 ? __builtin_amdgcn_mfma_f32_32x32x2f32(F.b[j][e], F.a[i][e], acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[i][e], F.b[j][e], acc[i][j], 0, 0, 0);
   };
 
   // ------------------------------------------------------------------------------------------------------
@@ -870,6 +873,79 @@ __global__ void __launch_bounds__(256, gg_waves(TM * TN)) gg_kernel(const GGArgs
             if (m < a.M) slab[(size_t)m * Gd.Ncol + col] = acc[i][j][r];
           }
       }
+    } else if constexpr (FUSE2) {
+      // ---- ResidualBlock tail in the same launch: y = res + W2 . relu(W1 * x + b1) + b2 (reference common/elic.py:41-68).
+      // Phase 1 above accumulated the 3x3 convolution TRANSPOSED (weights as the MFMA's A operand): lane l holds pixel
+      // l % 32 of the wave's 32 rows, register r of tile j the channel 32 j + (r & 3) + 8 (r >> 2) + 4 (l / 32) -- which
+      // is exactly how a lane feeds the A operand of v_mfma_f32_32x32x2_f32 (row = l % 32, k = l / 32), in exactly the k
+      // order of the stand-alone 1x1 kernel's fragments (quad 2 g + h of a 16-deep stage).  So relu(acc + b1) goes into
+      // the second contraction straight from the registers: no round trip through HBM or LDS, the same fma chains.
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 b1 = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias) b1 = *reinterpret_cast<const f32x4*>(a.bias + 32 * j + 8 * q + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[0][j][4 * q + e] = apply_act(acc[0][j][4 * q + e] + b1[e], a.act);
+        }
+      // One 32-wide column tile of the output at a time (16 accumulator registers next to the 48 that hold the A operand).
+      // Its slice of W2 -- packed by the host in fragment order [Q][lane][4], 12 KB -- goes through one of two buffers in the
+      // idle stage ring; the next slice and this tile's residual operand are loaded while the 48 MFMAs of the tile run, and
+      // the tile leaves through a wave-private 4 KB staging slice behind the two buffers.
+      float* stage = ring + 2 * 3072 + wave * 1024;
+      const f32x4* w2src = reinterpret_cast<const f32x4*>(a.w2f);
+      f32x4 wreg[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) wreg[u] = w2src[te + 256 * u];
+      const int c4 = (lane & 7) << 2;                // epilogue: 8 lanes x 16 B per row, 8 rows per pass, 4 passes
+      const int rsub = lane >> 3;
+      const int mrow = m0d + wave * 32 + rsub;       // + 8 p: this lane's output row in pass p
+      __syncthreads();                               // the K loop's last fragment reads are done: the ring is free
+#pragma unroll 1
+      for (int ct = 0; ct < 6; ++ct) {               // output channels 32 ct ... 32 ct + 31
+        float* w2s = ring + (ct & 1) * 3072;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) reinterpret_cast<f32x4*>(w2s)[te + 256 * u] = wreg[u];
+        __syncthreads();                             // (the other buffer's readers are a tile behind this barrier)
+        if (ct < 5) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) wreg[u] = w2src[(ct + 1) * 768 + te + 256 * u];
+        }
+        const int ch = 32 * ct + c4;
+        f32x4 rv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          rv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (a.epi != SNTC_EPI_STORE && mrow + 8 * p < a.M)
+            rv[p] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(mrow + 8 * p) * a.Cout2 + ch);
+        }
+        f32x16 acc2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(w2s + ((4 * j + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[0][j][4 * q + e], bq[e], acc2, 0, 0, 0);
+          }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc2[r];
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias2) bv = *reinterpret_cast<const f32x4*>(a.bias2 + ch);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = mrow + 8 * p;
+          if (m >= a.M) continue;
+          const size_t idx = (size_t)m * a.Cout2 + ch;         // forward convolution: the output pixel index is the row index
+          f32x4 v = *reinterpret_cast<const f32x4*>(stage + (rsub + 8 * p) * 32 + c4) + bv;
+          if (a.epi != SNTC_EPI_STORE) v = apply_epilogue(v, a.epi, rv[p], a.aux, idx);
+          *reinterpret_cast<f32x4*>(a.y + idx) = v;
+        }
+      }
     } else if ((a.Cout & 3) == 0) {
       // Wide path (Cout % 4 == 0): each wave transposes its accumulators through a private LDS slice (the stage
       // ring is idle after the last barrier) so that every lane owns 4 consecutive channels of one pixel: bias /
@@ -1040,6 +1116,11 @@ static size_t lds_bytes_deep(int v) {
   return (size_t)kDeepRing * (gg_variant_bm(v) + gg_variant_bn(v)) * kStage * sizeof(float) + 2 * gg_variant_bm(v) * sizeof(int4);
 }
 
+// the ResidualBlock tail fused behind the 128 x 96 tile (3x3, N = 96 -> 1x1, 96 -> 192)
+static const void* kernel_fused() {
+  return reinterpret_cast<const void*>(&gg_kernel<1, 3, 4, 1, true, false, false, false, 0, true>);
+}
+
 static const void* variant_kernel_bf3(int v) {
   switch (v) {
     case 2: return reinterpret_cast<const void*>(&gg_kernel<1, 2, 4, 1, true, false, true>);
@@ -1074,6 +1155,7 @@ static thread_local int g_num_cus = 0;
 static thread_local int g_resident_bf3[kNumVariants + 1];
 static thread_local int g_resident_dma[kNumVariants + 1];
 static thread_local int g_resident_deep[kNumVariants + 1];
+static thread_local int g_resident_fused = 0;
 
 int gg_init() {
   int dev = 0;
@@ -1108,6 +1190,13 @@ int gg_init() {
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_deep(v)));
     g_resident_deep[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_deep(v))})) * g_num_cus;
   }
+  {
+    const void* fn = kernel_fused();
+    SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(3)));
+    int per_cu = 0;
+    SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes(3)));
+    g_resident_fused = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(3))})) * g_num_cus;
+  }
   for (int v : {2, 4}) {
     const void* fn = variant_kernel_bf3(v);
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_bf3(v)));
@@ -1134,6 +1223,8 @@ int gg_resident_blocks_deep(int variant) {
 
 int gg_num_cus() { return g_init_device >= 0 ? g_num_cus : 0; }
 
+int gg_resident_blocks_fused() { return g_init_device >= 0 ? g_resident_fused : 0; }
+
 int gg_resident_blocks_bf3(int variant) {
   return (variant == 2 || variant == 4) && g_init_device >= 0 ? g_resident_bf3[variant] : 0;
 }
@@ -1142,8 +1233,11 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
   const bool pro = args.pro != SNTC_PRO_NONE;
   const bool deep = args.dma == 2 && vec && !pro && !args.bf3 && variant_kernel_deep(variant);
   const bool dma = !deep && args.dma && vec && !pro && !args.bf3 && variant_kernel_dma(variant);
-  const void* fn = args.bf3 ? variant_kernel_bf3(variant) : deep ? variant_kernel_deep(variant) : dma ? variant_kernel_dma(variant)
-                            : variant_kernel(variant, vec, pro || !vec);
+  const bool fused = args.w2f != nullptr;
+  if (fused && (variant != 3 || !vec || pro || args.bf3 || args.ksplit != 1))
+    return fail(SNTC_ERR_UNSUPPORTED, "fused ResidualBlock tail: 128 x 96 vector instance, no prologue, no split-K");
+  const void* fn = fused ? kernel_fused() : args.bf3 ? variant_kernel_bf3(variant) : deep ? variant_kernel_deep(variant)
+                   : dma ? variant_kernel_dma(variant) : variant_kernel(variant, vec, pro || !vec);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
   if (args.bf3 && (pro || !vec)) return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 mode: vector path without prologue only");
   GGArgs a = args;

@@ -77,6 +77,11 @@ struct GGArgs {
   int tps, ups;        // tiles / units per row strip (all groups): tile order is strip-major, then group, then column tile
   float* sk_slab;      // [nworkers][256 threads * 16 TN floats], raw accumulators in register layout
   int* sk_flags;       // [nworkers], zeroed on the stream before the launch
+  // Fused ResidualBlock tail (FUSE2 instance): after the 3x3 (this launch's groups, Cout = 96, bias / act above) the 1x1
+  // 96 -> Cout2 = 192 with bias2, then `epi` with res / aux, into y [M][Cout2]
+  const float* w2f;    // W2 in fragment order [2 halves][3 column tiles][12 k-quads pairs][64 lanes][4], or nullptr
+  const float* bias2;
+  int Cout2;
   int dma;             // 1: direct-to-LDS staging (buffer_load ... lds, four ring slots) where the instantiation exists
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
@@ -97,6 +102,7 @@ int gg_resident_blocks(int variant, bool vec, bool pro);   // workgroups of this
 int gg_resident_blocks_deep(int variant);                   // same for the deep-ring (8-slot) direct-to-LDS instances; 0 if none
 int gg_num_cus();
 int gg_resident_blocks_dma(int variant);                    // same for the direct-to-LDS instantiations
+int gg_resident_blocks_fused();                             // the FUSE2 instance (variant 3)
 int gg_resident_blocks_bf3(int variant);                    // same for the bf16 x 3 instantiations (variants 2 and 4)
 size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off
 

@@ -18,6 +18,7 @@ ACTS = {None: capi.ACT_NONE, "none": capi.ACT_NONE, "relu": capi.ACT_RELU, "leak
 KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SIGNAL_DOWN, "sigup": capi.SIGNAL_UP}
 
 
+FUSE_RESIDUAL_TAIL = True   # ResidualBlock (c = 192): 3x3 and 1x1 + skip in one launch (bit-identical; False: two launches)
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
 FORCE_TILE = 0   # tools/profile_layers.py --variant: every plan created afterwards is pinned to this tile variant
@@ -100,6 +101,40 @@ class ConvPlan:
         direct-to-LDS / register stage path (None: library default).  Tests: identical bits every way."""
         flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0)))
         capi.call("sntc_conv_plan_set_schedule", self._h, flags)
+
+    def fusable_with(self, second):
+        """True if ``second`` (a 1x1 plan) can run behind this plan inside one launch (sntc_conv_forward_fused)."""
+        return FUSE_RESIDUAL_TAIL and bool(capi.load().sntc_conv_fusable(self._h, second._h))
+
+    def fused(self, second, x, res=None, aux=None):
+        """second(self(x), res, aux) in ONE launch (the tail of a c = 192 ResidualBlock): the intermediate never leaves the
+        registers; bit-identical to the two calls."""
+        _check_nhwc(x, self.cin)
+        n, h, w, _ = x.shape
+        ho, wo = self.out_hw(h, w)
+        y = torch.empty((n, ho, wo, second.cout), dtype=torch.float32, device=x.device)
+        for t in (res, aux):
+            if t is not None and tuple(t.shape) != tuple(y.shape):
+                raise ValueError(f"epilogue operand shape {tuple(t.shape)} != output shape {tuple(y.shape)}")
+        if (x.numel() * 4 >= MAX_INPUT_BYTES or y.numel() >= (1 << 32)) and n > 1:
+            half = n // 2
+            cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+            return torch.cat([self.fused(second, x[:half], cut(res, 0, half), cut(aux, 0, half)),
+                              self.fused(second, x[half:], cut(res, half, n), cut(aux, half, n))])
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ws_bytes = int(capi.load().sntc_conv_fused_workspace_bytes(self._h, n, h, w))
+        ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=x.device) if ws_bytes else None
+        capi.call("sntc_conv_forward_fused", self._h, second._h, _ptr(x), n, h, w, _ptr(y), _ptr(res), _ptr(aux), _ptr(ws),
+                  ws_bytes, _stream())
+        if prof is not None:
+            e1.record()
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w) + second.flops(n, ho, wo), variant=3, nblocks=0,
+                             vec=True, kind=self.kind + "+1x1", k=self.k[0], s=self.stride, cin=self.cin, cout=second.cout,
+                             n=n, h=h, w=w))
+        return y
 
     def out_hw(self, h, w):
         ho, wo = C.c_int(), C.c_int()

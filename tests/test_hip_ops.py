@@ -82,6 +82,44 @@ def test_every_tile_variant(variant, dev):
     assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("n,h,w,stream_k", [(1, 9, 13, True), (2, 40, 56, True), (18, 64, 96, True), (18, 64, 96, False),
+                                            (3, 37, 29, False)])
+def test_fused_residual_block_tail_is_bit_identical(n, h, w, stream_k, dev):
+    """conv3x3(96 -> 96, relu) -> conv1x1(96 -> 192) + skip in ONE launch (sntc_conv_forward_fused; reference
+    common/elic.py:57-68) gives exactly the bits of the two launches -- ragged row counts, stream-K and static schedules,
+    with and without the skip -- and matches the float64 oracle; weights updated in place are picked up."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(n * 100 + h)
+    x = dev_t(rng.standard_normal((n, h, w, 96)).astype(np.float32), dev)
+    w1 = (rng.standard_normal((3, 3, 96, 96)) * 0.05).astype(np.float32)
+    b1 = rng.standard_normal(96).astype(np.float32)
+    w2 = (rng.standard_normal((1, 1, 96, 192)) * 0.1).astype(np.float32)
+    b2 = rng.standard_normal(192).astype(np.float32)
+    res = dev_t(rng.standard_normal((n, h, w, 192)).astype(np.float32), dev)
+    first = ops.ConvPlan("conv", dev_t(w1, dev), dev_t(b1, dev), 1, "relu")
+    for epi in (capi.EPI_ADD, capi.EPI_STORE):
+        second = ops.ConvPlan("conv", dev_t(w2, dev), dev_t(b2, dev), 1, None, capi.PRO_NONE, epi)
+        assert first.fusable_with(second)
+        first.set_stream_k(stream_k)
+        r = res if epi == capi.EPI_ADD else None
+        two = second(first(x), res=r)
+        one = first.fused(second, x, res=r)
+        assert torch.equal(one, two)
+    if n <= 2:
+        ref = O.conv2d(np.maximum(O.conv2d(x.cpu().numpy(), w1, b1, 1), 0.0), w2, b2, 1)
+        assert rel_err(one.cpu().numpy(), ref) < TOL
+    # a weight update of the 1x1 plan reaches the fused path (its fragment-order copy is rebuilt)
+    w2b = dev_t((w2 * 0.5).astype(np.float32), dev)
+    second.update(w2b, dev_t(b2, dev))
+    assert torch.equal(first.fused(second, x), second(first(x)))
+    # pairs that do not qualify are refused, not mis-computed
+    other = ops.ConvPlan("conv", dev_t(w2, dev), dev_t(b2, dev), 1, "relu")
+    assert not first.fusable_with(other)
+    with pytest.raises(capi.SntcError):
+        first.fused(other, x)
+
+
 def test_epilogues(dev):
     from shallow_ntc_amd import _capi as capi
     from shallow_ntc_amd import ops
