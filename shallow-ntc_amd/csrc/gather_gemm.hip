@@ -52,6 +52,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// f(integral_constant<int, HI>), f(HI - 1), ..., f(LO): stops after the first call that returns true; says whether one did
+template <int HI, int LO, class F>
+__device__ __forceinline__ bool first_of_desc(F&& f) {
+  if constexpr (HI < LO) {
+    return false;
+  } else {
+    if (f(std::integral_constant<int, HI>{})) return true;
+    return first_of_desc<HI - 1, LO>(f);
+  }
+}
+
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
   return __builtin_bit_cast(f32x4, v);
@@ -695,9 +706,7 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
         }
         return false;
       };
-      [&]<int... I>(std::integer_sequence<int, I...>) {
-        if (!(wait_first(std::integral_constant<int, RING - 1 - I>{}) || ...)) dma_wait(std::integral_constant<int, 0>{});
-      }(std::make_integer_sequence<int, RING - 3>{});
+      if (!first_of_desc<RING - 1, 3>(wait_first)) dma_wait(std::integral_constant<int, 0>{});
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (n > 0) read_frag(F0, 0, 0);
@@ -739,9 +748,7 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
           ++j;
         }
       };
-      [&]<int... I>(std::integer_sequence<int, I...>) {
-        (tail(std::integral_constant<int, RING - 1 - I>{}), ...);
-      }(std::make_integer_sequence<int, RING - 1>{});
+      first_of_desc<RING - 1, 1>([&](auto REM) { tail(REM); return false; });
       dma_issued = 0;
     } else {
     // ---- prologue: stages k0, k0+1 -> ring slots 0, 1; stage k0+2 in flight
