@@ -404,10 +404,10 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
   double best_cost = 1e300;
   for (int v = 1; v <= kNumVariants; ++v) {
     if (fused ? v != 3 : (p->tile >= 1 && p->tile <= kNumVariants && v != p->tile)) continue;
-    // single-buffered fragments / one wave per SIMD: forced only -- except 128 x 192 on long vector contractions, where its
-    // six accumulator tiles per wave beat 128 x 96 (5x5 / 2, 192 -> 192 at 18 x 256 x 384: 128.6 vs 119.8 TFLOP/s)
-    const bool wide6 = v == 6 && p->vec && !pro && msteps >= 64;
-    if (p->tile == 0 && !wide6 && (v == 6 || v == 7 || v == 10)) continue;
+    // single-buffered fragments / one wave per SIMD: forced only.  (128 x 192 does beat 128 x 96 on the long N = 192
+    // contractions when it has the device to itself -- 5x5 / 2, 192 -> 192: 130.9 vs 119.8 TFLOP/s -- but at two workgroups per
+    // CU and 61 KB of LDS it shuts out the other stream's kernels: bench.py's two-stream encode went from 48.5 to 49.2 ms.)
+    if (p->tile == 0 && (v == 6 || v == 7 || v == 10)) continue;
     if (p->bf3 && v != 2 && v != 4) continue;                       // the bf16 x 3 experiment is instantiated for two tile shapes
     int64_t tiles, units;
     double macs;
@@ -446,7 +446,7 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // that owns more accumulators reads fewer LDS bytes and stages fewer global bytes per MFMA, and the chip holds a
     // higher clock for it; 256 x 128 leaves one wave per SIMD and stalls on every barrier
     static const double kRate[kNumVariants + 1] = {0, 0.86, 0.93, 0.97, 1.00, 0.97, 0.90, 0.85, 0.90, 1.02, 0.40};
-    cost /= wide6 ? 1.04 : kRate[v];
+    cost /= kRate[v];
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
