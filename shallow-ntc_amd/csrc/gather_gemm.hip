@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
       const int mrow = m0d + wave * 32 + rsub;       // + 8 p: this lane's output row in pass p
       __syncthreads();                               // the K loop's last fragment reads are done: the ring is free
 #pragma unroll 1
-      for (int ct = 0; ct < 6; ++ct) {               // output channels 32 ct ... 32 ct + 31
+      for (int ct = 0; ct < (SNTC_DBG(a, 128) ? 0 : 6); ++ct) {   // output channels 32 ct ... 32 ct + 31
         float* w2s = ring + (ct & 1) * 3072;
 #pragma unroll
         for (int u = 0; u < 3; ++u) reinterpret_cast<f32x4*>(w2s)[te + 256 * u] = wreg[u];

@@ -85,7 +85,8 @@ struct GGArgs {
   int dma;             // 1: direct-to-LDS staging (buffer_load ... lds, four ring slots) where the instantiation exists
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
-                       // 8 skip fragment reads -- to see what the K loop waits on; results are meaningless with any bit set
+                       // 8 skip fragment reads, 16 skip the epilogue's stores, 32 its residual loads, 64 the MFMAs, 128 the fused
+                       // ResidualBlock tail's second contraction -- to see what a launch waits on; results are meaningless with any bit set
   int ngroups;
   GGGroup g[kMaxGroups];
 };
