@@ -126,7 +126,7 @@ int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int 
  * sntc_conv_fused_workspace_bytes() is the scratch this call needs (as sntc_conv_workspace_bytes). */
 int sntc_conv_fusable(const sntc_conv_plan* first, const sntc_conv_plan* second);
 int64_t sntc_conv_fused_workspace_bytes(const sntc_conv_plan* first, int n, int h, int w);
-int sntc_conv_forward_fused(const sntc_conv_plan* first, sntc_conv_plan* second, const float* x, int n, int h, int w, float* y,
+int sntc_conv_forward_fused(const sntc_conv_plan* first, const sntc_conv_plan* second, const float* x, int n, int h, int w, float* y,
                             const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream);
 /* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
  * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */

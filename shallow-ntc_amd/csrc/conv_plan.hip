@@ -98,8 +98,7 @@ struct sntc_conv_plan {
   bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
   int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
-  float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (built on first fused use)
-  bool w2f_stale = true;
+  float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (fusable_second plans only)
 };
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
@@ -135,6 +134,23 @@ extern "C" void sntc_conv_plan_destroy(sntc_conv_plan* p) {
   if (p->bias) (void)hipFree(p->bias);
   if (p->w2f) (void)hipFree(p->w2f);
   delete p;
+}
+
+// A plan that can be the SECOND half of a fused ResidualBlock tail (1x1, 96 -> 192, no activation, fp32) keeps its weights
+// in the fused kernel's fragment order as well.  Packed here -- at creation and at every update, on the caller's stream,
+// like the plan's own weights -- so that the forward calls never write to a plan (plans are shared by concurrent streams).
+static bool fusable_second(const sntc_conv_plan* p) {
+  const sntc_conv_desc& b = p->d;
+  return !p->up && !p->bf3 && b.kh == 1 && b.kw == 1 && b.stride == 1 && b.cin == 96 && b.cout == 192 &&
+         b.prologue == SNTC_PRO_NONE && b.act == SNTC_ACT_NONE && p->ngroups == 1 && p->g[0].K == 96;
+}
+
+static int pack_fused_second(sntc_conv_plan* p, hipStream_t stream) {
+  if (!fusable_second(p)) return SNTC_OK;
+  if (!p->w2f) SNTC_HIP(hipMalloc(&p->w2f, sizeof(float) * 2 * 3 * 12 * 64 * 4));
+  hipLaunchKernelGGL(pack_fused_w2_kernel, dim3(72), dim3(256), 0, stream, p->g[0].wp, p->w2f, p->g[0].K, p->g[0].Ncol);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
 }
 
 static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias, hipStream_t stream) {
@@ -221,7 +237,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, stream));
   }
   (void)k;
-  return SNTC_OK;
+  return pack_fused_second(p, stream);
 }
 
 extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* weight, const float* bias,
@@ -287,8 +303,7 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
     SNTC_HIP(hipGetLastError());
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));
-  p->w2f_stale = true;
-  return SNTC_OK;
+  return pack_fused_second(p, s);
 }
 
 struct Geo {
@@ -479,7 +494,7 @@ extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int 
 }
 
 // One launch of plan p; with p2 (validated by sntc_conv_forward_fused) the 1x1 plan p2 runs behind p inside the same launch.
-static int conv_forward_impl(const sntc_conv_plan* p, sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
+static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
                              const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream) {
   if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: null argument");
   if (n < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: empty batch");
@@ -516,15 +531,7 @@ static int conv_forward_impl(const sntc_conv_plan* p, sntc_conv_plan* p2, const 
   a.ngroups = p->ngroups;
   a.bf3 = p->bf3 ? 1 : 0;
   a.dma = p2 ? 0 : sc.deep ? 2 : plan_dma(p) ? 1 : 0;
-  if (p2) {
-    if (!p2->w2f) SNTC_HIP(hipMalloc(&p2->w2f, sizeof(float) * 2 * 3 * 12 * 64 * 4));
-    if (p2->w2f_stale) {
-      hipLaunchKernelGGL(pack_fused_w2_kernel, dim3(72), dim3(256), 0, (hipStream_t)stream, p2->g[0].wp, p2->w2f, p2->g[0].K, p2->g[0].Ncol);
-      SNTC_HIP(hipGetLastError());
-      p2->w2f_stale = false;
-    }
-    a.w2f = p2->w2f; a.bias2 = p2->bias; a.Cout2 = p2->d.cout;
-  }
+  if (p2) { a.w2f = p2->w2f; a.bias2 = p2->bias; a.Cout2 = p2->d.cout; }
   a.sk = sc.sk ? 1 : 0;
   a.nworkers = sc.workers;
   a.units = sc.units;
@@ -570,13 +577,11 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
 // launch -- the 96-channel intermediate never leaves the registers.  Bit-identical to the two launches.
 static const char* fused_pair_error(const sntc_conv_plan* p, const sntc_conv_plan* p2) {
   if (!p || !p2) return "null plan";
-  const sntc_conv_desc &a = p->d, &b = p2->d;
+  const sntc_conv_desc& a = p->d;
   if (p->up || p2->up || p->bf3 || p2->bf3) return "forward convolutions in fp32 only";
   if (!p->vec || a.cout != 96 || a.stride != 1 || a.prologue != SNTC_PRO_NONE || a.epilogue != SNTC_EPI_STORE || p->ngroups != 1)
     return "first plan: stride-1 convolution with Cin % 16 == 0 and 96 output channels, plain store";
-  if (b.kh != 1 || b.kw != 1 || b.stride != 1 || b.cin != 96 || b.cout != 192 || b.prologue != SNTC_PRO_NONE ||
-      b.act != SNTC_ACT_NONE || p2->ngroups != 1 || p2->g[0].K != 96)
-    return "second plan: 1x1 convolution 96 -> 192 without activation";
+  if (!fusable_second(p2) || !p2->w2f) return "second plan: 1x1 convolution 96 -> 192 without activation";
   return nullptr;
 }
 
@@ -589,7 +594,7 @@ extern "C" int64_t sntc_conv_fused_workspace_bytes(const sntc_conv_plan* p, int 
   return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, schedule(p, g, n, true));
 }
 
-extern "C" int sntc_conv_forward_fused(const sntc_conv_plan* p, sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
+extern "C" int sntc_conv_forward_fused(const sntc_conv_plan* p, const sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
                                        const float* res, const float* aux, void* workspace, size_t workspace_bytes,
                                        void* stream) {
   if (const char* why = fused_pair_error(p, p2)) return fail(SNTC_ERR_UNSUPPORTED, why);
