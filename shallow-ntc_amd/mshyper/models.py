@@ -357,7 +357,7 @@ class Model:
         Same numbers as the reference's loop, image by image and in order, but not its stalls.  One image alone leaves most
         of the GPU idle (a 512 x 768 image is 72 ... 288 workgroups per layer on 256 CUs), so up to ``group`` images OF THE
         SAME SHAPE among the next ``lookahead * group`` are launched as one batch -- every kernel on this path gives an
-        image bit-identical results alone or inside any batch (DESIGN.md 4.2) -- and up to ``lookahead`` such launches are
+        image bit-identical results alone or inside any batch (DESIGN.md 4.1) -- and up to ``lookahead`` such launches are
         in flight on round-robin HIP streams before the oldest one's results are copied to the host, so the device never
         waits for Python.  lookahead=1 is the strictly serial one-image-per-pass reference behaviour."""
         tensor_input = isinstance(images, (torch.Tensor, np.ndarray))
