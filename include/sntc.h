@@ -104,6 +104,17 @@ void sntc_conv_plan_destroy(sntc_conv_plan* plan);
 /* Re-pack an existing plan from new device weights (and bias: present iff the plan has one); tables and tile
  * choices are kept.  The training step calls this after every optimizer update. */
 int sntc_conv_plan_update(sntc_conv_plan* plan, const float* weight, const float* bias, void* stream);
+/* Every plan of a model re-packed by ONE launch: the training step (reference common/train_lib.py:185-215, one
+ * optimizer.apply_gradients per step over all variables) changes every kernel at once, and ~170 plans x (pack + bias copy)
+ * is ~400 tiny launches otherwise.  The group remembers, per plan, the device arrays its weights (and bias; NULL iff the
+ * plan has none) are read from -- views of the trainer's flat variable store, which never move -- and
+ * sntc_plan_group_update() does what sntc_conv_plan_update() would do for each of them, bit for bit.  The plans must
+ * outlive the group. */
+typedef struct sntc_plan_group sntc_plan_group;
+int sntc_plan_group_create(sntc_conv_plan* const* plans, const float* const* weights, const float* const* biases, int count,
+                           void* stream, sntc_plan_group** group);
+int sntc_plan_group_update(const sntc_plan_group* group, void* stream);
+void sntc_plan_group_destroy(sntc_plan_group* group);
 /* Output spatial size for an input of h x w. */
 int sntc_conv_out_shape(const sntc_conv_plan* plan, int h, int w, int* ho, int* wo);
 /* Algorithmic 2*MAC FLOPs of one forward call (dense count, as tf.profiler counts them). */

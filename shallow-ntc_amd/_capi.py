@@ -46,6 +46,9 @@ SIGNATURES = {
     "sntc_conv_plan_create": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(_P)]),
     "sntc_conv_plan_destroy": (None, [_P]),
     "sntc_conv_plan_update": (C.c_int, [_P, _P, _P, _P]),
+    "sntc_plan_group_create": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "sntc_plan_group_update": (C.c_int, [_P, _P]),
+    "sntc_plan_group_destroy": (None, [_P]),
     "sntc_conv_out_shape": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sntc_conv_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_conv_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),

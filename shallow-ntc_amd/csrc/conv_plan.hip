@@ -12,50 +12,91 @@
 
 namespace sntc {
 
+// One packed element: column `col`, position `k` of a group's [Ncol][K] weight rows (K order and kernel layouts below).
+struct PackDesc {
+  const float* w;
+  float* wp;
+  const int* taps;
+  const unsigned* cols;
+  int T, Cin, Cout, K, Ncol, kw, s, pt, pl, phase_mode, slab_major, out_major, bf3;
+};
+
+__device__ __forceinline__ void pack_element(const PackDesc& d, size_t idx) {
+  const int col = (int)(idx / d.K);
+  const int k = (int)(idx - (size_t)col * d.K);
+  float v = 0.0f;
+  if (k < d.T * d.Cin) {
+    // K order (csrc/gather_gemm.hip): Cin % 16 == 0 -> channel slab outermost, k = cc * T * 16 + t * 16 + c;
+    // otherwise (dword gather path) tap-major, k = t * Cin + ci
+    int t, ci;
+    if (d.slab_major) {
+      const int cc = k / (d.T * 16);
+      const int r = k - cc * d.T * 16;
+      t = r >> 4;
+      ci = cc * 16 + (r & 15);
+    } else {
+      t = k / d.Cin;
+      ci = k - t * d.Cin;
+    }
+    const int tap = d.taps[t];
+    const unsigned ce = d.cols[col];
+    const int ch = ce & 0xffff;
+    int ky = tap >> 16, kx = tap & 0xffff;
+    if (d.phase_mode) {
+      ky = ((int)((ce >> 24) & 0xff) - 128 + d.pt) + ky * d.s;
+      kx = ((int)((ce >> 16) & 0xff) - 128 + d.pl) + kx * d.s;
+    }
+    const size_t tapi = (size_t)ky * d.kw + kx;
+    v = d.out_major ? d.w[(tapi * d.Cout + ch) * d.Cin + ci] : d.w[(tapi * d.Cin + ci) * d.Cout + ch];
+  }
+  if (d.bf3) {           // three bf16 planes, 96 B per (column, 16-deep stage): [plane][16]
+    __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    __bf16 mid = (__bf16)r1;
+    __bf16 lo = (__bf16)(r1 - (float)mid);
+    __bf16* o = reinterpret_cast<__bf16*>(d.wp) + ((size_t)col * (d.K / 16) + (k >> 4)) * 48 + (k & 15);
+    o[0] = hi; o[16] = mid; o[32] = lo;
+  } else {
+    d.wp[idx] = v;
+  }
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                     const int* __restrict__ taps, const unsigned* __restrict__ cols,
                                     int T, int Cin, int Cout, int K, int Ncol, int kind, int kw, int s,
                                     int pt, int pl, int phase_mode, int slab_major, int out_major, int bf3) {
+  const PackDesc d{w, wp, taps, cols, T, Cin, Cout, K, Ncol, kw, s, pt, pl, phase_mode, slab_major, out_major, bf3};
   const size_t total = (size_t)Ncol * K;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(idx / K);
-    const int k = (int)(idx - (size_t)col * K);
-    float v = 0.0f;
-    if (k < T * Cin) {
-      // K order (csrc/gather_gemm.hip): Cin % 16 == 0 -> channel slab outermost, k = cc * T * 16 + t * 16 + c;
-      // otherwise (dword gather path) tap-major, k = t * Cin + ci
-      int t, ci;
-      if (slab_major) {
-        const int cc = k / (T * 16);
-        const int r = k - cc * T * 16;
-        t = r >> 4;
-        ci = cc * 16 + (r & 15);
-      } else {
-        t = k / Cin;
-        ci = k - t * Cin;
-      }
-      const int tap = taps[t];
-      const unsigned ce = cols[col];
-      const int ch = ce & 0xffff;
-      int ky = tap >> 16, kx = tap & 0xffff;
-      if (phase_mode) {
-        ky = ((int)((ce >> 24) & 0xff) - 128 + pt) + ky * s;
-        kx = ((int)((ce >> 16) & 0xff) - 128 + pl) + kx * s;
-      }
-      const size_t tapi = (size_t)ky * kw + kx;
-      v = out_major ? w[(tapi * Cout + ch) * Cin + ci] : w[(tapi * Cin + ci) * Cout + ch];
-    }
-    if (bf3) {           // three bf16 planes, 96 B per (column, 16-deep stage): [plane][16]
-      __bf16 hi = (__bf16)v;
-      const float r1 = v - (float)hi;
-      __bf16 mid = (__bf16)r1;
-      __bf16 lo = (__bf16)(r1 - (float)mid);
-      __bf16* o = reinterpret_cast<__bf16*>(wp) + ((size_t)col * (K / 16) + (k >> 4)) * 48 + (k & 15);
-      o[0] = hi; o[16] = mid; o[32] = lo;
-    } else {
-      wp[idx] = v;
-    }
+       idx += (size_t)gridDim.x * blockDim.x)
+    pack_element(d, idx);
+}
+
+__device__ __forceinline__ void pack_fused_w2_element(const float* wp, float* w2f, int K, int Ncol, int i) {
+  const int e = i & 3, lane = (i >> 2) & 63, Q = (i >> 8) % 12, t = ((i >> 8) / 12) % 3, hf = (i >> 8) / 36;
+  const int k = 8 * Q + 4 * (lane >> 5) + e, n = 96 * hf + 32 * t + (lane & 31);
+  w2f[i] = (k < K && n < Ncol) ? wp[(size_t)n * K + k] : 0.0f;
+}
+
+// Every plan of a training step re-packed by ONE launch (sntc_plan_group_update): job j is a weight group of a plan
+// (kind 0), a bias copy (kind 1: wp[i] = w[i], Ncol floats) or a fused-tail fragment copy (kind 2, runs in a second
+// launch because it reads what kind 0 wrote); block b works on elements [first[b], first[b] + kPackChunk) of job[b].
+constexpr int kPackChunk = 4096;
+struct PackJob {
+  PackDesc d;
+  int kind;
+};
+
+__global__ void __launch_bounds__(256) pack_group_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ blk_job,
+                                                         const long long* __restrict__ blk_first) {
+  const PackJob& J = jobs[blk_job[blockIdx.x]];
+  const size_t total = J.kind == 0 ? (size_t)J.d.Ncol * J.d.K : J.kind == 1 ? (size_t)J.d.Ncol : (size_t)(2 * 3 * 12 * 64 * 4);
+  const size_t lo = (size_t)blk_first[blockIdx.x];
+  const size_t hi = lo + kPackChunk < total ? lo + kPackChunk : total;
+  for (size_t idx = lo + threadIdx.x; idx < hi; idx += 256) {
+    if (J.kind == 0) pack_element(J.d, idx);
+    else if (J.kind == 1) J.d.wp[idx] = J.d.w[idx];
+    else pack_fused_w2_element(J.d.w, J.d.wp, J.d.K, J.d.Ncol, (int)idx);
   }
 }
 
@@ -64,11 +105,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // [n = 96 hf + 32 t + lane % 32]
 __global__ void pack_fused_w2_kernel(const float* __restrict__ wp, float* __restrict__ w2f, int K, int Ncol) {
   const int total = 2 * 3 * 12 * 64 * 4;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int e = i & 3, lane = (i >> 2) & 63, Q = (i >> 8) % 12, t = ((i >> 8) / 12) % 3, hf = (i >> 8) / 36;
-    const int k = 8 * Q + 4 * (lane >> 5) + e, n = 96 * hf + 32 * t + (lane & 31);
-    w2f[i] = (k < K && n < Ncol) ? wp[(size_t)n * K + k] : 0.0f;
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+    pack_fused_w2_element(wp, w2f, K, Ncol, i);
 }
 
 }  // namespace sntc
@@ -304,6 +342,93 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));
   return pack_fused_second(p, s);
+}
+
+// ---- plan group: every plan of a model re-packed by one launch (training step) ----
+struct sntc_plan_group {
+  PackJob* jobs = nullptr;          // device
+  int* blk_job = nullptr;
+  long long* blk_first = nullptr;
+  int nblocks = 0;                  // blocks of the weight / bias jobs
+  int nblocks2 = 0;                 // blocks of the fused-tail fragment jobs (second launch: they read the first one's output)
+};
+
+extern "C" void sntc_plan_group_destroy(sntc_plan_group* g) {
+  if (!g) return;
+  if (g->jobs) (void)hipFree(g->jobs);
+  if (g->blk_job) (void)hipFree(g->blk_job);
+  if (g->blk_first) (void)hipFree(g->blk_first);
+  delete g;
+}
+
+extern "C" int sntc_plan_group_create(sntc_conv_plan* const* plans, const float* const* weights, const float* const* biases,
+                                      int count, void* stream, sntc_plan_group** out) {
+  if (!plans || !weights || !biases || !out || count < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_plan_group_create: null argument");
+  std::vector<PackJob> jobs, jobs2;
+  for (int i = 0; i < count; ++i) {
+    sntc_conv_plan* p = plans[i];
+    if (!p || !weights[i]) return fail(SNTC_ERR_BAD_SHAPE, "sntc_plan_group_create: null plan or weight array");
+    if ((biases[i] != nullptr) != (p->bias != nullptr))
+      return fail(SNTC_ERR_BAD_SHAPE, "sntc_plan_group_create: bias presence differs from the plan");
+    const sntc_conv_desc& d = p->d;
+    for (int gi = 0; gi < p->ngroups; ++gi) {
+      auto& G = p->g[gi];
+      PackJob j{};
+      j.d = PackDesc{weights[i], G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K, G.Ncol, d.kw, d.stride, p->pt, p->pl,
+                     p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0};
+      j.kind = 0;
+      if ((size_t)G.Ncol * G.K > 0) jobs.push_back(j);
+    }
+    if (biases[i]) {
+      PackJob j{};
+      j.d.w = biases[i]; j.d.wp = p->bias; j.d.Ncol = d.cout;
+      j.kind = 1;
+      jobs.push_back(j);
+    }
+    if (fusable_second(p) && p->w2f) {
+      PackJob j{};
+      j.d.w = p->g[0].wp; j.d.wp = p->w2f; j.d.K = p->g[0].K; j.d.Ncol = p->g[0].Ncol;
+      j.kind = 2;
+      jobs2.push_back(j);
+    }
+  }
+  std::vector<int> blk_job;
+  std::vector<long long> blk_first;
+  auto add_blocks = [&](const std::vector<PackJob>& js, int base) {
+    for (size_t j = 0; j < js.size(); ++j) {
+      const size_t total = js[j].kind == 0 ? (size_t)js[j].d.Ncol * js[j].d.K : js[j].kind == 1 ? (size_t)js[j].d.Ncol : (size_t)(2 * 3 * 12 * 64 * 4);
+      for (size_t f = 0; f < total; f += kPackChunk) { blk_job.push_back(base + (int)j); blk_first.push_back((long long)f); }
+    }
+  };
+  add_blocks(jobs, 0);
+  const int nb1 = (int)blk_job.size();
+  add_blocks(jobs2, (int)jobs.size());
+  const int nb2 = (int)blk_job.size() - nb1;
+  jobs.insert(jobs.end(), jobs2.begin(), jobs2.end());
+  auto* g = new sntc_plan_group();
+  g->nblocks = nb1;
+  g->nblocks2 = nb2;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMalloc(&g->jobs, sizeof(PackJob) * jobs.size());
+  if (e == hipSuccess) e = hipMalloc(&g->blk_job, sizeof(int) * blk_job.size());
+  if (e == hipSuccess) e = hipMalloc(&g->blk_first, sizeof(long long) * blk_first.size());
+  if (e == hipSuccess) e = hipMemcpyAsync(g->jobs, jobs.data(), sizeof(PackJob) * jobs.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(g->blk_job, blk_job.data(), sizeof(int) * blk_job.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(g->blk_first, blk_first.data(), sizeof(long long) * blk_first.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);      // the host vectors go out of scope
+  if (e != hipSuccess) { sntc_plan_group_destroy(g); return hip_fail(e, "sntc_plan_group_create"); }
+  *out = g;
+  return SNTC_OK;
+}
+
+extern "C" int sntc_plan_group_update(const sntc_plan_group* g, void* stream) {
+  if (!g) return fail(SNTC_ERR_BAD_SHAPE, "sntc_plan_group_update: null group");
+  hipStream_t s = (hipStream_t)stream;
+  if (g->nblocks > 0) hipLaunchKernelGGL(pack_group_kernel, dim3(g->nblocks), dim3(256), 0, s, g->jobs, g->blk_job, g->blk_first);
+  if (g->nblocks2 > 0)
+    hipLaunchKernelGGL(pack_group_kernel, dim3(g->nblocks2), dim3(256), 0, s, g->jobs, g->blk_job + g->nblocks, g->blk_first + g->nblocks);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
 }
 
 struct Geo {

@@ -43,6 +43,33 @@ def _check_nhwc(x, c=None):
         raise ValueError(f"expected {c} channels, got {x.shape[-1]}")
 
 
+class PlanGroup:
+    """Plans re-packed together by one launch (sntc_plan_group): ``entries`` = [(ConvPlan, weight tensor, bias tensor or None)].
+    The tensors must stay where they are (views of the trainer's flat store); ``update()`` re-reads them."""
+
+    def __init__(self, entries):
+        capi.require_gpu()
+        self._keep = list(entries)
+        n = len(self._keep)
+        plans = (C.c_void_p * n)(*[e[0]._h.value for e in self._keep])
+        ws = (C.c_void_p * n)(*[e[1].data_ptr() for e in self._keep])
+        bs = (C.c_void_p * n)(*[(e[2].data_ptr() if e[2] is not None else None) for e in self._keep])
+        self._h = C.c_void_p()
+        capi.call("sntc_plan_group_create", plans, ws, bs, n, _stream(), C.byref(self._h))
+
+    def update(self):
+        capi.call("sntc_plan_group_update", self._h, _stream())
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_plan_group_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
 def to_device(a, device):
     """Host array -> float32 device tensor (weights, images)."""
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)

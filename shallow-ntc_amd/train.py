@@ -122,9 +122,17 @@ class TConv:
         self.adj_kind = {"conv": "convT", "convT": "conv", "sigdown": "sigup", "sigup": "sigdown"}[kind]
         self.adj_plan = ops.ConvPlan(self.adj_kind, self.W, None, s, None, capi.PRO_NONE, adj_epilogue, kernel_io_swapped=self.signal)
 
-    def refresh(self):
+    def prepare(self):
+        """What must be recomputed from the variables before the plans are re-packed (tfc's RDFT-stored kernels)."""
         if self.signal:
             ops.small_matmul(self.M, self.rdft, self.W.view(self.k * self.k, self.cin * self.cout))
+
+    def plan_entries(self):
+        """(plan, weight array, bias array) of every plan that follows this layer's variables (ops.PlanGroup)."""
+        return [(self.fwd_plan, self.W, self.b), (self.adj_plan, self.W, None)]
+
+    def refresh(self):
+        self.prepare()
         self.fwd_plan.update(self.W, self.b)
         self.adj_plan.update(self.W, None)
 
@@ -213,6 +221,13 @@ class TGDN:
                   ops._ptr(self.beta), ops._stream())
         capi.call("sntc_gdn_reparam_forward", ops._ptr(self.gamma_raw), self.gamma_raw.numel(), self.gamma_bound, self.pedestal,
                   ops._ptr(self.gamma), ops._stream())
+
+    def prepare(self):
+        self._effective()
+
+    def plan_entries(self):
+        g4 = self.gamma.view(1, 1, self.c, self.c)
+        return [(self.norm_plan, g4, self.beta), (self.adj_plan, g4, None)]
 
     def refresh(self):
         self._effective()
@@ -520,8 +535,14 @@ class Trainer:
         self._refresh_warm = getattr(self, "_refresh_warm", 0) + 1
 
     def _refresh_eager(self):
-        for c in self._all_convs():
-            c.refresh()
+        """Every plan follows its variables: the per-layer preparations (RDFT kernels, GDN reparameterisation), then ONE
+        re-pack launch for all plans (ops.PlanGroup) instead of ~400 pack / copy launches."""
+        layers = self._all_convs()
+        for c in layers:
+            c.prepare()
+        if getattr(self, "_plan_group", None) is None:
+            self._plan_group = ops.PlanGroup([e for c in layers for e in c.plan_entries()])
+        self._plan_group.update()
         if self._two_layer:
             self.synthesis.refresh()
         p = self.store.param

@@ -120,6 +120,39 @@ def test_fused_residual_block_tail_is_bit_identical(n, h, w, stream_k, dev):
         first.fused(other, x)
 
 
+def test_plan_group_update_equals_per_plan_update(dev):
+    """sntc_plan_group_update re-packs every plan of the group in one launch exactly as sntc_conv_plan_update does one by
+    one: forward convolution, phase-grouped transpose (four weight groups), input-gradient plan on the swapped kernel,
+    dword-gather first layer, and the fused-tail fragment copy of a 1x1 96 -> 192 plan."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(21)
+    mk = lambda *shape: dev_t((rng.standard_normal(shape) * 0.1).astype(np.float32), dev)
+    specs = [("conv", (3, 3, 96, 96), 96, 1, "relu", capi.EPI_STORE, False), ("convT", (5, 5, 48, 32), 48, 2, None, capi.EPI_STORE, False),
+             ("convT", (3, 3, 96, 96), None, 1, None, capi.EPI_STORE, True), ("conv", (5, 5, 3, 64), 64, 2, None, capi.EPI_STORE, False),
+             ("conv", (1, 1, 96, 192), 192, 1, None, capi.EPI_ADD, False)]
+    entries, fresh_args = [], []
+    for kind, wshape, nb, s, act, epi, swapped in specs:
+        w, b = mk(*wshape), (mk(nb) if nb else None)
+        entries.append((ops.ConvPlan(kind, w, b, s, act, capi.PRO_NONE, epi, kernel_io_swapped=swapped), w, b))
+        fresh_args.append((kind, s, act, epi, swapped))
+    group = ops.PlanGroup(entries)
+    for _p, w, b in entries:                       # new values in the SAME arrays, as the optimizer leaves them
+        w.copy_(mk(*w.shape))
+        if b is not None:
+            b.copy_(mk(*b.shape))
+    group.update()
+    x96, x32, x3 = mk(2, 9, 11, 96), mk(2, 9, 11, 32), mk(2, 20, 22, 3)
+    res = mk(2, 9, 11, 192)
+    inputs = [x96, x32, x96, x3, x96]
+    for (plan, w, b), (kind, s, act, epi, swapped), x in zip(entries, fresh_args, inputs):
+        fresh = ops.ConvPlan(kind, w, b, s, act, capi.PRO_NONE, epi, kernel_io_swapped=swapped)
+        r = res if epi == capi.EPI_ADD else None
+        assert torch.equal(plan(x, res=r), fresh(x, res=r)), kind
+    first, second = entries[0][0], entries[4][0]
+    assert torch.equal(first.fused(second, x96, res=res), second(first(x96), res=res))
+
+
 def test_epilogues(dev):
     from shallow_ntc_amd import _capi as capi
     from shallow_ntc_amd import ops
