@@ -18,6 +18,7 @@ ACTS = {None: capi.ACT_NONE, "none": capi.ACT_NONE, "relu": capi.ACT_RELU, "leak
 KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SIGNAL_DOWN, "sigup": capi.SIGNAL_UP}
 
 
+WGRAD_STREAM = None         # training: the side stream the weight / bias gradients of TConv layers are launched on (Trainer sets it)
 FUSE_RESIDUAL_TAIL = True   # ResidualBlock (c = 192): 3x3 and 1x1 + skip in one launch (bit-identical; False: two launches)
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
@@ -464,11 +465,13 @@ _WS = {}
 
 
 def _workspace(nbytes, device):
-    """One growing scratch buffer per device for the split-K slabs of the gradient kernels."""
-    buf = _WS.get(device)
+    """One growing scratch buffer per (device, launch stream) for the split-K slabs of the gradient kernels: launches on
+    one stream are ordered, launches on different streams (the trainer's weight-gradient stream) must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty((max(int(nbytes), 1 << 20),), dtype=torch.uint8, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 

@@ -144,6 +144,29 @@ class TConv:
         x, y = ctx
         if self.act is not None and not act_folded:
             g = ops.act_backward(g, y, self.act)
+        side = ops.WGRAD_STREAM
+        if side is None:
+            self._param_grads(x, g)
+        else:
+            # d loss / d kernel and d loss / d bias depend on (x, g) only; the input gradient below depends on g only: the
+            # two run side by side (on the small maps of the deep layers neither fills the device alone).  The trainer
+            # joins the side stream before a bucket's gradients are used.
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                self._param_grads(x, g)
+            x.record_stream(side)              # the caching allocator must not hand these to main-stream work early
+            g.record_stream(side)
+        if not need_dx:
+            return None
+        if self.adj_epilogue == capi.EPI_MASK_RELU:
+            return self.adj_plan(g, res=x)
+        if self.adj_epilogue == capi.EPI_ADD:
+            return self.adj_plan(g, res=adj_res)
+        return self.adj_plan(g)
+
+    def _param_grads(self, x, g):
         if self.kind == "sigup":               # comes out [k, k, Cout, Cin]: transpose to the layer's [k, k, Cin, Cout]
             ops.conv_wgrad(self.kind, self.k, self.s, self.cin, self.cout, x, g, self._gT)
             ops.transpose_last2(self._gT.view(self.k * self.k, self.cout, self.cin), self.gW)
@@ -153,13 +176,6 @@ class TConv:
             ops.small_matmul(self.M, self.gW.view(self.k * self.k, self.cin * self.cout), self.g_rdft, transpose_a=True)
         if self.gb is not None:
             ops.bias_grad(g, self.gb)
-        if not need_dx:
-            return None
-        if self.adj_epilogue == capi.EPI_MASK_RELU:
-            return self.adj_plan(g, res=x)
-        if self.adj_epilogue == capi.EPI_ADD:
-            return self.adj_plan(g, res=adj_res)
-        return self.adj_plan(g)
 
     def convs(self):
         return [self]
@@ -392,6 +408,7 @@ class Trainer:
         self.device = model.device
         self.seed = seed
         self.use_graph = True
+        self.overlap_wgrad = True        # weight / bias gradients on a side stream, next to the input-gradient chain
         self.store = FlatStore(self.device)
         w = model.get_weights()
         tr = model._transforms()
@@ -558,7 +575,26 @@ class Trainer:
         f = m.downsample_factor
         if h % f or w % f:
             raise ValueError(f"training patches must be multiples of {f} (the reference trains on 256 x 256 crops)")
-        notify = on_bucket or (lambda name: None)
+        on_bucket = on_bucket or (lambda name: None)
+        side = None
+        if self.overlap_wgrad:
+            if getattr(self, "_wgrad_stream", None) is None:
+                self._wgrad_stream = torch.cuda.Stream(device=x.device)
+            side = self._wgrad_stream
+
+        def notify(name):
+            if side is not None:               # the bucket's weight gradients were written on the side stream
+                torch.cuda.current_stream().wait_stream(side)
+            on_bucket(name)
+
+        ops.WGRAD_STREAM = side
+        try:
+            return self._loss_and_grads(x, rd_lambda, noise_z, noise_y, notify)
+        finally:
+            ops.WGRAD_STREAM = None
+
+    def _loss_and_grads(self, x, rd_lambda, noise_z, noise_y, notify):
+        n, h, w, c = x.shape
         w_bpp = 1.0 / (n * h * w)                                      # bpp = mean_B(bits) / (H W)        (:302-307)
         scale = rd_lambda * 2.0 * 255.0 * 255.0 / (n * h * w * c)     # d(lambda mean (255 d)^2) / d x_hat  (:313-317,343)
         step = self.step_count

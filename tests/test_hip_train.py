@@ -193,6 +193,20 @@ def test_loss_and_gradients_match_autograd(synthesis, analysis, uq, dev):
     for k in rg:
         assert np.abs(rg[k]).max() > 0, f"{k}: reference gradient is identically zero (test would be vacuous)"
     assert worst[0] < 2e-5, worst          # measured: 3e-6
+    # the weight / bias gradients run on a side stream next to the input-gradient chain (Trainer.overlap_wgrad): the same
+    # kernels in another order of launches -- every gradient bit for bit, run after run
+    # (the deep-factorized prior's own gradients are float atomics: equal to ~1e-7 only, overlap or not)
+    assert tr.overlap_wgrad
+    for overlap in (False, True, True):
+        tr.overlap_wgrad = overlap
+        tr.store.grad.zero_()
+        tr.loss_and_grads(xd, lam, torch.from_numpy(nz).to(dev), torch.from_numpy(ny).to(dev))
+        again = tr.store.export(tr.store.grad)
+        for k in got:
+            if k.startswith("prior/"):
+                assert _rel(again[k], got[k]) < 1e-6, (k, overlap)
+            else:
+                assert np.array_equal(again[k], got[k]), (k, overlap)
 
 
 @pytest.mark.parametrize("which", ["mbt2018", "bls2017"])
