@@ -107,3 +107,60 @@ def test_image_to_bpp_psnr_at_full_width(name, hw, point, dev):
     assert abs(rep["d_psnr"]) <= 1e-3, rep
     assert zflips == 0, rep
     assert flips <= sym.size * 1e-4, rep             # a loose sanity bound; the tolerance above is the bar
+
+
+GDN_CONFIGS = [("bls2017", True, "analysis/layer_2", 0.8), ("mbt2018", False, "analysis/layer_3", 0.5)]
+
+
+@pytest.mark.parametrize("name,factorized,last,y_std", GDN_CONFIGS, ids=[c[0] for c in GDN_CONFIGS])
+def test_gdn_signal_conv_configs_image_to_bpp_psnr_at_full_width(name, factorized, last, y_std, dev):
+    """BASELINE.json configs[0] (factorized/configs/bls2017.py: 256 filters, 9x9 / 4 SignalConv2D, GDN) and configs[1]
+    (mshyper/configs/mbt2018.py: 192 / 320, 5x5 / 2 SignalConv2D, GDN / IGDN) at their real widths and their 256 x 256
+    size: image -> (bpp, PSNR) of the HIP path against the float64 oracle end to end from pixels, BASELINE tolerance
+    asserted unconditionally.  Random-init weights with the last analysis layer rescaled (and, with a hyperprior, the
+    predicted scales lifted) so that the codec works at a published rate instead of at sigma_min."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.factorized.models import Model as FModel
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = configs.CONFIGS[name](rd_lambda=0.02)
+    model = (FModel if factorized else Model)(device=dev, **cfg)
+    model._step = 10 ** 9
+    w = dict(model.get_weights())
+    rng = np.random.default_rng(3)
+    if not factorized:
+        b = w["hyper_synthesis/layer_2/bias"].copy()
+        c = b.shape[0] // 2
+        b[c:] = rng.uniform(1.6, 2.5, size=c)
+        w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
+        model.set_weights(w)
+    probe = data_lib.normalize_image(data_lib.synthetic_images(1, 256, 256, seed=99))
+    gain = np.float32(y_std / float(model.infer_latent_rvs(probe).uq[-1].loc.std()))
+    w[last + "/kernel"] = (w[last + "/kernel"] * gain).astype(np.float32)
+    if last + "/bias" in w:
+        w[last + "/bias"] = (w[last + "/bias"] * gain).astype(np.float32)
+    model.set_weights(w)
+    x = data_lib.normalize_image(data_lib.synthetic_images(1, 256, 256, seed=6))
+    lat = model.infer_latent_rvs(x)
+    r = model._rate_and_reconstruction(lat, want_symbols=True)
+    _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
+    m = metrics.scalars_float
+    ref_model = model_np.Model(cfg["transform_config"], rd_lambda=0.02, factorized=factorized)
+    ref = ref_model.end_to_end(w, x, be=train_ref)
+    if factorized:                       # no integer symbols on this path: y_hat = round(y - median) + median, compared as values
+        sym = r["y_hat"].cpu().numpy()
+        flips = int((np.abs(sym - ref["y_hat"]) > 0.25).sum())
+    else:
+        sym = r["symbols"].cpu().numpy()
+        flips = int((sym != ref["symbols_y"]).sum())
+    rep = dict(symbols=int(sym.size), symbol_flips=flips, bpp_hip=m["bpp"], bpp_f64=float(ref["bpp"]), d_bpp=m["bpp"] - float(ref["bpp"]),
+               psnr_hip=m["psnr"], psnr_f64=float(ref["psnr"]), d_psnr=m["psnr"] - float(ref["psnr"]))
+    REPORT[f"{name}/256x256"] = rep
+    print(json.dumps({name: rep}))
+    out = ROOT / "gpurun_out"
+    if out.is_dir():
+        (out / "e2e_parity.json").write_text(json.dumps(REPORT, indent=1))
+    assert 0.05 <= rep["bpp_f64"] <= 8.0, rep
+    assert abs(rep["d_bpp"]) <= 1e-4, rep            # BASELINE.json north_star tolerance
+    assert abs(rep["d_psnr"]) <= 1e-3, rep
+    assert flips <= sym.size * 1e-4, rep
