@@ -109,14 +109,15 @@ def test_image_to_bpp_psnr_at_full_width(name, hw, point, dev):
     assert flips <= sym.size * 1e-4, rep             # a loose sanity bound; the tolerance above is the bar
 
 
-GDN_CONFIGS = [("bls2017", True, "analysis/layer_2", 0.8), ("mbt2018", False, "analysis/layer_3", 0.5)]
+GDN_CONFIGS = [("bls2017", True, "analysis/layer_2", 0.8), ("mbt2018", False, "analysis/layer_3", 0.5),
+               ("two_layer_syn2", False, "analysis/layer_3", 0.4)]
 
 
 @pytest.mark.parametrize("name,factorized,last,y_std", GDN_CONFIGS, ids=[c[0] for c in GDN_CONFIGS])
 def test_gdn_signal_conv_configs_image_to_bpp_psnr_at_full_width(name, factorized, last, y_std, dev):
-    """BASELINE.json configs[0] (factorized/configs/bls2017.py: 256 filters, 9x9 / 4 SignalConv2D, GDN) and configs[1]
-    (mshyper/configs/mbt2018.py: 192 / 320, 5x5 / 2 SignalConv2D, GDN / IGDN) at their real widths and their 256 x 256
-    size: image -> (bpp, PSNR) of the HIP path against the float64 oracle end to end from pixels, BASELINE tolerance
+    """BASELINE.json configs[0] (factorized/configs/bls2017.py: 256 filters, 9x9 / 4 SignalConv2D, GDN), configs[1]
+    (mshyper/configs/mbt2018.py: 192 / 320, 5x5 / 2 SignalConv2D, GDN / IGDN) and the model of configs[4]
+    (mshyper/configs/two_layer_syn2.py: CNNAnalysis 256 -> 320 with leaky_relu, TwoLayerSynthesis) at their real widths, 256 x 256: image -> (bpp, PSNR) of the HIP path against the float64 oracle end to end from pixels, BASELINE tolerance
     asserted unconditionally.  Random-init weights with the last analysis layer rescaled (and, with a hyperprior, the
     predicted scales lifted) so that the codec works at a published rate instead of at sigma_min."""
     from shallow_ntc_amd.common import data_lib
