@@ -38,6 +38,8 @@ ap.add_argument("--eval-every", type=int, default=200)            # :27
 ap.add_argument("--rd-lambda", type=float, default=0.005)
 ap.add_argument("--hidden", type=int, default=24)                 # two_layer_syn2.py:9-12 (FLOP-matched hidden width)
 ap.add_argument("--workdir", default=None)
+ap.add_argument("--operating-point", action="store_true",
+                help="no checkpoint: rescale the initial weights so that the codec works near 1 bpp (tools/operating_point.py)")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 
@@ -53,6 +55,10 @@ else:
     cfg = configs.two_layer_syn2(rd_lambda=args.rd_lambda, hidden_channels=args.hidden)
     cfg.update(update)
     model = Model(device=dev, **cfg)
+    if args.operating_point:
+        sys.path.insert(0, str(ROOT / "tools"))
+        import operating_point
+        operating_point.apply(model)
 h, w = args.hw
 num_units = -(-args.images // args.batch)
 
