@@ -299,6 +299,15 @@ int sntc_sga_normal_fwd(const float* y_loc, const float* hyper, int n, int64_t h
 /* g_yloc = (g_ytilde + weight dbits_dv) sprime;  g_hyper = [g_ytilde (1 - sprime) - weight dbits_dv sprime | weight dbits_draw] */
 int sntc_sga_normal_bwd(const float* g_ytilde, const float* sprime, const float* dbits_dv, const float* dbits_draw,
                         float weight, int64_t npix, int c, float* g_yloc, float* g_hyper, void* stream);
+/* UQLatentRV.sample(training, method, offset, **kwargs) / .quantize(offset) (common/latent_rvs_lib.py:77-116) on [npix, c]
+ * values: u = loc - offset (offset NULL = none; else element (p, ch) is offset[p * offset_stride + ch], e.g. the mean half of
+ * the hyper-synthesis output with offset_stride = 2 c; offset_stride 0 broadcasts a per-channel [c] offset).  mode 0: round-half-even(u) + offset (training=False, :95-102; also
+ * tfc.round_st's forward value, :77-78); 1 'unoise': loc + U(-.5, .5) (:104-107); 2 'sga': sga_round(u, tau = param) + offset
+ * (:108-110, common/latent_rvs_utils.py:8-48); 3 'soft_round': tfc.soft_round(u, alpha = param) + offset (:111-114).
+ * noise: NULL -> counter-based generator keyed by (seed, step, element); else the uniform values [npix, c] in (-.5, .5) (mode 1)
+ * or the Gumbel pairs [npix, c, 2] (mode 2). */
+int sntc_uq_sample(const float* loc, const float* offset, int64_t npix, int c, int offset_stride, int mode, float param,
+                   const float* noise, uint64_t seed, uint64_t step, float* out, void* stream);
 /* out = (g + weight dbits) sprime */
 int sntc_sga_chain(const float* g, const float* dbits, const float* sprime, float weight, int64_t total, float* out,
                    void* stream);

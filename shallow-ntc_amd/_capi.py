@@ -89,6 +89,7 @@ SIGNATURES = {
     "sntc_sga_normal_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, _P, C.c_uint64, C.c_uint64, _P, _P, _P,
                                       _P, _P, _P]),
     "sntc_sga_normal_bwd": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, C.c_int, _P, _P, _P]),
+    "sntc_uq_sample": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "sntc_sga_chain": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, _P, _P]),
     "sntc_distortion_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
     "sntc_two_layer_tail_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),

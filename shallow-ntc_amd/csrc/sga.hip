@@ -191,6 +191,45 @@ __global__ void __launch_bounds__(256) sga_chain_kernel(const float* __restrict_
     out[i] = (g[i] + w * dbits[i]) * sprime[i];
 }
 
+// ---- UQLatentRV.sample / .quantize (reference common/latent_rvs_lib.py:77-116) as one element-wise kernel ----
+// u = loc - offset (offset: NULL = 0, or a tensor read with a pixel stride: the mean half of the hyper-synthesis output);
+// mode 0: round-half-even(u) (training=False, :95-102 / tfc.round_st forward); 1: loc + U(-.5, .5) ('unoise', :104-107: the
+// offset plays no role); 2: sga_round (common/latent_rvs_utils.py:8-48); 3: tfc.soft_round(u, alpha) (:111-114) [DEP]:
+// m = floor(u) + .5, out = m + tanh(alpha (u - m)) / (2 tanh(alpha / 2)), alpha bounded below by 1e-3 (identity under it).
+__global__ void __launch_bounds__(256) uq_sample_kernel(const float* __restrict__ loc, const float* __restrict__ offset,
+                                                        int64_t npix, int c, int ostride, int mode, float param,
+                                                        const float* __restrict__ noise, unsigned long long seed,
+                                                        unsigned long long step, float* __restrict__ out) {
+  const int64_t total = npix * c;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c;
+    const int ch = (int)(i - p * c);
+    const float off = offset ? offset[p * ostride + ch] : 0.0f;
+    const float x = loc[i];
+    const float u = x - off;
+    float v;
+    if (mode == 0) {
+      v = rintf(u) + off;
+    } else if (mode == 1) {
+      v = x + (noise ? noise[i] : uniform01(splitmix64(stream_key(seed, step) + (unsigned long long)i)) - 0.5f);
+    } else if (mode == 2) {
+      const float g0 = noise ? noise[2 * i] : gumbel_from(seed, step, (unsigned long long)i, 0);
+      const float g1 = noise ? noise[2 * i + 1] : gumbel_from(seed, step, (unsigned long long)i, 1);
+      float sp;
+      sga_sample(u, param, g0, g1, &v, &sp);
+      v += off;
+    } else {
+      if (param < 1e-3f) {
+        v = x;
+      } else {
+        const float m = floorf(u) + 0.5f;
+        v = m + tanhf(param * (u - m)) / (2.0f * tanhf(0.5f * param)) + off;
+      }
+    }
+    out[i] = v;
+  }
+}
+
 // ---- distortion: sse[n] of 255 (x - x_hat) and g_xhat = scale (x_hat - x) (zeros in the padded margin) ----
 __global__ void __launch_bounds__(256) distortion_grad_kernel(const float* __restrict__ x, const float* __restrict__ xh, int h, int w,
                                                               int c, int hs, int ws, float scale, float* __restrict__ g,
@@ -616,6 +655,19 @@ extern "C" int sntc_sga_factorized_fwd(const sntc_prior* prior, const float* z_l
   hipLaunchKernelGGL(sga_factorized_fwd_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, prior->rec,
                      prior->d, z_loc, hw, c, tau, noise, (unsigned long long)seed,
                      (unsigned long long)step, z_tilde, sprime, dbits_dz, bits);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_uq_sample(const float* loc, const float* offset, int64_t npix, int c, int offset_stride, int mode,
+                              float param, const float* noise, uint64_t seed, uint64_t step, float* out, void* stream) {
+  if (!loc || !out) return fail(SNTC_ERR_BAD_SHAPE, "sntc_uq_sample: null argument");
+  if (npix < 1 || c < 1 || (offset && offset_stride != 0 && offset_stride < c))      // stride 0: one offset per channel, broadcast over pixels
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_uq_sample: bad sizes");
+  if (mode < 0 || mode > 3) return fail(SNTC_ERR_UNSUPPORTED, "sntc_uq_sample: mode must be 0 round, 1 unoise, 2 sga, 3 soft_round");
+  if (mode == 2 && !(param > 0.0f)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_uq_sample: sga needs tau > 0");
+  hipLaunchKernelGGL(uq_sample_kernel, dim3(grid_for(npix * c)), dim3(256), 0, (hipStream_t)stream, loc, offset, npix, c,
+                     offset_stride, mode, param, noise, (unsigned long long)seed, (unsigned long long)step, out);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }

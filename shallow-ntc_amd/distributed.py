@@ -23,9 +23,12 @@ def env_world():
 
 
 def init(backend=None):
-    """Initialise torch.distributed if WORLD_SIZE > 1 (nccl == RCCL on ROCm; gloo for CPU tests)."""
+    """Initialise torch.distributed if WORLD_SIZE > 1 (nccl == RCCL on ROCm; gloo for CPU tests).  A backend named
+    explicitly -- the argument or SNTC_DIST_BACKEND -- also forms a ONE-rank group, so that the collectives of the path run
+    through RCCL on a single GPU (the only RCCL evidence obtainable on a one-GPU box; bench.py does this by default)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    explicit = backend or os.environ.get("SNTC_DIST_BACKEND")
+    if (world > 1 or explicit) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -155,13 +158,14 @@ class BucketReducer:
     def __init__(self, flat, slices):
         self.flat, self.slices = flat, dict(slices)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = dist.is_initialized()        # a one-rank group still runs its all-reduces through the backend
         self._handles = []
         self._launched = []
 
     def launch(self, name):
         lo, hi = self.slices[name]
         self._launched.append(name)
-        if self.world > 1 and hi > lo:
+        if self.active and hi > lo:
             self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

@@ -49,6 +49,24 @@ class Model(_ms.Model):
         return dict(z_hat=None, y_hat=y_hat, symbols=None, hyper=None, bits_z=torch.zeros_like(bits), bits_y=bits,
                     recon=recon)
 
+    def _training_samples(self, latent_rvs, noise, seed):                # reference :101-118, training=True
+        uq = self._latent_config["uq"].get("method", "unoise")
+        step = self.global_step
+        ny = None if noise is None else noise[-1]
+        (y_rv,) = latent_rvs.uq
+        prior = self._get_prior()
+        if uq in ("unoise", "mixedq"):
+            y_t = y_rv.sample(True, "unoise", noise=ny, seed=seed, step=2 * step + 1)
+            bits, _ = ops.noisy_factorized(prior, y_t)
+            return None, bits, (y_rv.quantize() if uq == "mixedq" else y_t)
+        cfg = dict(self.latent_config["uq"])
+        if uq == "sga":
+            y_t, _, _, bits = ops.sga_factorized_fwd(prior, y_rv.loc, cfg["tau"], ny, seed, step)
+            return None, bits, y_t
+        y_t = y_rv.sample(True, offset=None, noise=ny, seed=seed, step=2 * step + 1, **cfg)
+        bits, _ = ops.noisy_factorized(prior, y_t)
+        return None, bits, y_t
+
     def encode(self, x):
         lat = self.infer_latent_rvs(self._as_device_images(x))
         y_hat, bits = self._get_prior()(lat.uq[0].loc)

@@ -263,10 +263,60 @@ class Model:
         recon = self._timed("synthesis", self._synthesis, y_hat)                # :297
         return dict(z_hat=z_hat, y_hat=y_hat, symbols=sym, hyper=hyper, bits_z=bits_z, bits_y=bits_y, recon=recon)
 
-    def frame_loss_given_latent_rvs(self, image_batch, latent_rvs, training):
+    def frame_loss_given_latent_rvs(self, image_batch, latent_rvs, training, noise=None, seed=None):
+        """reference :234-359.  ``training=False``: hard rounding, uint8 distortion, MS-SSIM.  ``training=True``: the loss value
+        the reference's ``train_step`` / ``itinf_train_step`` differentiate -- the latents are perturbed as
+        ``latent_config['uq']['method']`` says ('unoise' / 'mixedq': additive uniform noise, :253-259,277-283; anything else,
+        e.g. 'sga' / 'soft_round': explicit ``UQLatentRV.sample``, :260-268,285-291), the rate is the noisy densities' at those
+        samples and the distortion is taken on unrounded 0-255 floats (data_lib.py:48-52).  Forward value only: the
+        gradients live in ``train_step`` (shallow_ntc_amd.train.Trainer) and ``itinf_train_step`` (sga.SGAEngine), which
+        draw the same numbers from the same (seed, step).  ``noise`` = (for z, for y) fixes the draw (tests)."""
         if training:
-            raise NotImplementedError("training=True runs through train_step (noise proxies) / itinf_train_step (SGA)")
+            return self._training_frame(image_batch, latent_rvs, noise, seed)
         return self._finish_frame(self._launch_frame(image_batch, latent_rvs))
+
+    def _training_samples(self, latent_rvs, noise, seed):
+        """-> (bits_z[n] or None, bits_y[n], the tensor the synthesis decodes): the training=True branch up to the synthesis."""
+        uq = self._latent_config["uq"].get("method", "unoise")
+        step = self.global_step
+        nz, ny = (None, None) if noise is None else noise
+        z_rv, y_rv = latent_rvs.uq
+        prior = self._get_prior()
+        if uq in ("unoise", "mixedq"):
+            z_t = z_rv.sample(True, "unoise", noise=nz, seed=seed, step=2 * step)                 # :253-259
+            bits_z, _ = ops.noisy_factorized(prior, z_t)
+            z_dec = z_rv.quantize() if uq == "mixedq" else z_t                                    # offset 0 (SURVEY App. A.5)
+            hyper = self._hyper_synthesis(z_dec)                                                  # :273
+            y_t = y_rv.sample(True, "unoise", noise=ny, seed=seed, step=2 * step + 1)             # :277-283
+            bits_y, _, _ = ops.noisy_normal(y_t, hyper)
+            y_dec = ops.entropy_scale_normal(y_rv.loc, hyper)[0] if uq == "mixedq" else y_t
+            return bits_z, bits_y, y_dec
+        cfg = dict(self.latent_config["uq"])                                                      # explicit sampling, :260-268
+        if uq == "sga":       # the fused kernels of itinf_train_step: same draw, same rate arithmetic
+            z_t, _, _, bits_z = ops.sga_factorized_fwd(prior, z_rv.loc, cfg["tau"], nz, seed, step)
+            hyper = self._hyper_synthesis(z_t)
+            y_t, _, _, _, bits_y = ops.sga_normal_fwd(y_rv.loc, hyper, cfg["tau"], ny, seed, step)
+            return bits_z, bits_y, y_t
+        z_t = z_rv.sample(True, offset=None, noise=nz, seed=seed, step=2 * step, **cfg)
+        bits_z, _ = ops.noisy_factorized(prior, z_t)
+        hyper = self._hyper_synthesis(z_t)
+        c = y_rv.loc.shape[-1]
+        y_t = y_rv.sample(True, offset=hyper[..., :c], noise=ny, seed=seed, step=2 * step + 1, **cfg)       # :285-291
+        bits_y, _, _ = ops.noisy_normal(y_t, hyper)
+        return bits_z, bits_y, y_t
+
+    def _training_frame(self, image_batch, latent_rvs, noise=None, seed=None):
+        x = self._as_device_images(image_batch)
+        seed = self._seed if seed is None else seed
+        with torch.cuda.device(self.device):
+            bits_z, bits_y, y_dec = self._training_samples(latent_rvs, noise, seed)
+            recon = self._synthesis(y_dec, training=True)                                         # :297
+            sse = ops.float_sse(x, recon)                                                         # unpad + 0-255 floats, unrounded
+            rows = [bits_y if bits_z is None else bits_z, bits_y, sse]
+            host = torch.stack(rows).cpu().numpy()
+        rd_loss, metrics = self._finish_metrics(x.shape, None if bits_z is None else host[0], host[1], host[2])
+        metrics.record_image("reconstruction", recon)
+        return rd_loss, metrics
 
     def _launch_frame(self, image_batch, latent_rvs=None):
         """Everything of end_to_end_frame_loss(training=False) that runs on the GPU, launched on the current stream with
@@ -511,8 +561,6 @@ class Model:
     def initialize_itinf(self, image_batch):
         """latent_rvs = trainable copy of the encoder's latents; fresh Adam state (:389-395)."""
         from ..sga import SGAEngine
-        if self.factorized:
-            raise NotImplementedError("SGA is implemented for the mean-scale hyperprior model")
         if self._optimizer_config.get("global_clipnorm") is not None:
             raise NotImplementedError("gradient clipping is not used by the reference's itinf config")
         self.latent_rvs = self.infer_latent_rvs(image_batch).get_trainable_copy()
@@ -534,19 +582,21 @@ class Model:
             raise NotImplementedError("itinf_train_step implements latent_config uq.method == 'sga'")
         tau = cfg["tau"]
         lr = self._scheduled_lr
-        z_loc, y_loc = self.latent_rvs.uq[0].loc, self.latent_rvs.uq[1].loc
+        locs = [rv.loc for rv in self.latent_rvs.uq]                     # (z_loc, y_loc); the factorized model: (y_loc,)
         with torch.cuda.device(self.device):
-            r = self._sga.loss_and_grads(x, z_loc, y_loc, tau, self._scheduled_rd_lambda, step=self._itinf_step, seed=seed,
+            r = self._sga.loss_and_grads(x, locs[0] if len(locs) == 2 else None, locs[-1], tau, self._scheduled_rd_lambda,
+                                         step=self._itinf_step, seed=seed,
                                          noise_z=None if noise is None else noise[0],
-                                         noise_y=None if noise is None else noise[1])
+                                         noise_y=None if noise is None else noise[-1])
             t = self._itinf_step + 1
-            for p, g, st in ((z_loc, r["g_z"], self._adam[0]), (y_loc, r["g_y"], self._adam[1])):
+            grads = [r["g_z"], r["g_y"]] if len(locs) == 2 else [r["g_y"]]
+            for p, g, st in zip(locs, grads, self._adam):
                 ops.adam_step(p, g, st["m"], st["v"], lr, t, self._optimizer_config.get("beta_1", 0.9),
                               self._optimizer_config.get("beta_2", 0.999), self._optimizer_config.get("epsilon", 1e-7))
             host = torch.stack([r["bits_z"], r["bits_y"], r["sse"]]).cpu().numpy()
-        _, metrics = self._finish_metrics(x.shape, host[0], host[1], host[2])
+        _, metrics = self._finish_metrics(x.shape, host[0] if len(locs) == 2 else None, host[1], host[2])
         self._itinf_step += 1
-        self.last_grads = (r["g_z"], r["g_y"])
+        self.last_grads = tuple(grads)
         return metrics
 
     def itinf_validation_step(self, image_batch, training=False) -> Metrics:

@@ -417,6 +417,36 @@ def sga_chain(g, dbits, sprime, weight):
     return out
 
 
+UQ_MODES = {"round": 0, "unoise": 1, "sga": 2, "soft_round": 3}
+
+
+def uq_sample(loc, offset=None, mode="round", param=0.0, noise=None, seed=0, step=0):
+    """UQLatentRV.sample / .quantize (reference common/latent_rvs_lib.py:77-116) on an NHWC tensor.  ``offset``: None, a
+    tensor shaped like ``loc``, the mean half ``hyper[..., :c]`` of a hyper-synthesis output (a strided view is read in
+    place), or a per-channel [c] tensor."""
+    _check_nhwc(loc)
+    c = loc.shape[-1]
+    npix = loc.numel() // c
+    ostride = 0
+    if offset is not None:
+        if offset.dim() == 1:
+            if offset.shape[0] != c or not offset.is_contiguous():
+                raise ValueError(f"per-channel offset must be a contiguous [{c}] tensor")
+        else:
+            if tuple(offset.shape) != tuple(loc.shape) or offset.stride(-1) != 1:
+                raise ValueError(f"offset shape {tuple(offset.shape)} does not match the latent {tuple(loc.shape)}")
+            ostride = int(offset.stride(-2))
+            n, h, w, _ = loc.shape
+            if tuple(offset.stride()) != (h * w * ostride, w * ostride, ostride, 1):
+                raise ValueError("offset must be dense over pixels (a contiguous tensor or a last-axis slice of one)")
+        if offset.dtype != torch.float32 or not offset.is_cuda:
+            raise ValueError("offset must be a float32 CUDA tensor")
+    out = torch.empty_like(loc)
+    capi.call("sntc_uq_sample", _ptr(loc), _ptr(offset), npix, c, ostride, UQ_MODES[mode], float(param), _ptr(noise),
+              int(seed), int(step), _ptr(out), _stream())
+    return out
+
+
 def distortion_grad(x, x_hat, scale):
     """-> (g_xhat with x_hat's (padded) shape, sse[n] float64 of 255 (x - x_hat) over the un-padded region)."""
     _check_nhwc(x)
@@ -580,6 +610,17 @@ def noisy_normal(y_tilde, hyper):
     bits = torch.empty((n,), dtype=torch.float64, device=y_tilde.device)
     capi.call("sntc_noisy_normal", _ptr(y_tilde), _ptr(hyper), n, h * w, c, _ptr(dv), _ptr(dr), _ptr(bits), _stream())
     return bits, dv, dr
+
+
+def noisy_factorized(prior, z_tilde):
+    """bits[n] (float64) of explicit samples under the noisy deep-factorized density (the training=True value of
+    ContinuousBatchedEntropyModel / ``prior.log_prob``, reference mshyper/models.py:253-268), and d bits / d z~."""
+    _check_nhwc(z_tilde, prior.channels)
+    n, hw = z_tilde.shape[0], z_tilde.shape[1] * z_tilde.shape[2]
+    dbits = torch.empty_like(z_tilde)
+    bits = torch.empty((n,), dtype=torch.float64, device=z_tilde.device)
+    capi.call("sntc_noisy_factorized", prior._h, _ptr(z_tilde), n, hw, _ptr(dbits), _ptr(None), _ptr(bits), _stream())
+    return bits, dbits
 
 
 # ------------------------------------------------------------------------------------------

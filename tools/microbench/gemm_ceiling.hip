@@ -1,0 +1,205 @@
+// What an LDS-fed fp32-MFMA K loop of the gather-GEMM's shape can reach on THIS device with RANDOM operands -- the known-good
+// reference the kernel's roofline fraction is read against (cdna_hip_programming.md 5.4 rule 10: no ceiling claims from one's
+// own failed attempts; rule 25: zero / constant operands read high because the chip holds a higher clock on them).
+//
+// One workgroup = 4 waves as 2 x 2, wave tile 64 x 64 (the 128 x 128 instance of csrc/gather_gemm.hip), a ring of three
+// 16-deep stages of (128 + 128) rows x 64 B in LDS, fragments by ds_read_b128, 32 v_mfma_f32_32x32x2_f32 per wave and stage.
+// Modes (bit mask):
+//   1  barrier per stage (the ring hand-off)
+//   2  stage traffic: 4 buffer_load_dwordx4 per thread and stage from an L2-resident array + 4 ds_write_b128 into the ring
+//   4  constant operands instead of random ones (what tools/microbench/mfma_peak.hip measures)
+//   8  no LDS fragment reads (operands stay in registers)
+// The loop does exactly the kernel's per-stage instruction mix and nothing else (no tile bookkeeping, no epilogue), so its rate
+// is an upper bound for any schedule of that mix; the difference between modes prices barriers, fragment reads and staging.
+// Build: hipcc --offload-arch=gfx950 -O3 -o gemm_ceiling gemm_ceiling.hip ; run: ./gemm_ceiling
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kRows = 256;          // A rows + B rows of a stage
+constexpr int kSlot = kRows * 16;   // floats per ring slot
+
+// PAT 0: every wave instruction loads 1 KB contiguous.  PAT 1: the kernel's gather shape -- 4 lanes per row fetch one 64-B
+// K slab of a row, 64 rows per instruction, rows `row_stride` bytes apart (an NHWC pixel of Cin channels); the slab advances
+// by 64 B per stage and wraps inside the row, so every 128-B line is touched by two different stages.
+template <int MODE, int PAT = 0>
+__global__ void __launch_bounds__(256, 2) loop_f32(const float* __restrict__ src, float* out, int stages, unsigned src_bytes, unsigned row_stride) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  for (int i = tid; i < 3 * kSlot; i += 256) ring[i] = (MODE & 4) ? 0.5f : src[(blockIdx.x * 977 + i) & ((src_bytes >> 2) - 1)];
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, 0x00020000);
+  const int swz = (l31 >> 2) & 3;
+  const int fa = (wm * 64 + l31) * 16, fb = (128 + wn * 64 + l31) * 16;
+  const int o0 = ((0 + h) ^ swz) << 2, o1 = ((2 + h) ^ swz) << 2;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x4 A0[2], B0[2], A1[2], B1[2];
+  auto rd = [&](f32x4* A, f32x4* B, int slot, int off) {
+    const float* base = ring + slot * kSlot;
+    for (int i = 0; i < 2; ++i) A[i] = *reinterpret_cast<const f32x4*>(base + fa + i * 512 + off);
+    for (int j = 0; j < 2; ++j) B[j] = *reinterpret_cast<const f32x4*>(base + fb + j * 512 + off);
+  };
+  auto mm = [&](const f32x4* A, const f32x4* B) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e], B[j][e], acc[i][j], 0, 0, 0);
+  };
+  rd(A0, B0, 0, o0);
+  rd(A1, B1, 0, o1);
+  f32x4 R[4];
+  const int r0 = tid >> 2, c = tid & 3, wsw = (c ^ ((r0 >> 2) & 3)) << 2;
+  unsigned goff = ((unsigned)blockIdx.x * 65536u + (unsigned)tid * 16u) & (src_bytes - 1);
+  unsigned rowoff[4];
+  unsigned slab = 0;
+  for (int i = 0; i < 4; ++i) rowoff[i] = (unsigned)(((unsigned long long)(blockIdx.x * 256 + r0 + 64 * i) * row_stride) & (src_bytes - 1)) + c * 16u;
+  auto gaddr = [&](int i) { return PAT == 0 ? ((goff + i * 4096u) & (src_bytes - 1)) : ((rowoff[i] + slab) & (src_bytes - 1)); };
+  if (MODE & 2)
+    for (int i = 0; i < 4; ++i) R[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gaddr(i), 0, 0));
+  int s0 = 0, s1 = 1, s2 = 2;
+  for (int st = 0; st < stages; ++st) {
+    if (MODE & 2) {
+      float* dst = ring + s2 * kSlot;
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst + (r0 + 64 * i) * 16 + wsw) = R[i];
+      goff = (goff + 16384u) & (src_bytes - 1);
+      slab += 64u;
+      if (slab >= row_stride) slab = 0;
+      for (int i = 0; i < 4; ++i) R[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gaddr(i), 0, 0));
+    }
+    if (!(MODE & 8)) rd(A1, B1, s0, o1);
+    mm(A0, B0);
+    if (!(MODE & 8)) rd(A0, B0, s1, o0);
+    mm(A1, B1);
+    if (MODE & 2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 13, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE & 1) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    const int t = s0; s0 = s1; s1 = s2; s2 = t;
+  }
+  float s = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  if (s == 12345.678f) out[0] = s;
+}
+
+// The bf16 x 3 counterpart: the same 64 x 64 wave tile, operands as three bf16 planes (32 B per row, plane and stage), six
+// v_mfma_f32_32x32x16_bf16 per 32 x 32 tile and 16-deep stage.  MODE 1: barrier per stage; 8: no fragment reads.
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) loop_bf3(const float* __restrict__ src, float* out, int stages, unsigned src_bytes, unsigned row_stride) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];      // 3 slots x 256 rows x 96 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  constexpr int kSlot3 = kRows * 24;
+  for (int i = tid; i < 3 * kSlot3; i += 256) {
+    const float v = src[(blockIdx.x * 977 + i) & ((src_bytes >> 2) - 1)];
+    __bf16 two[2] = {(__bf16)v, (__bf16)(v * 0.37f)};
+    ring[i] = __builtin_bit_cast(float, two);
+  }
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8 A[3][2], B[3][2];
+  const int hoff = (h ^ ((l31 >> 3) & 1)) << 4;
+  auto rd = [&](int slot) {
+    const char* base = reinterpret_cast<const char*>(ring + slot * kSlot3);
+    for (int p = 0; p < 3; ++p) {
+      for (int i = 0; i < 2; ++i) A[p][i] = *reinterpret_cast<const bf16x8*>(base + p * 128 * 32 + (wm * 64 + i * 32 + l31) * 32 + hoff);
+      for (int j = 0; j < 2; ++j) B[p][j] = *reinterpret_cast<const bf16x8*>(base + 3 * 128 * 32 + p * 128 * 32 + (wn * 64 + j * 32 + l31) * 32 + hoff);
+    }
+  };
+  rd(0);
+  int s0 = 0;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  for (int st = 0; st < stages; ++st) {
+    if (!(MODE & 8)) rd(s0);
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[t]][i], B[PB[t]][j], acc[i][j], 0, 0, 0);
+    if (MODE & 1) __syncthreads();
+    s0 = s0 == 2 ? 0 : s0 + 1;
+  }
+  float s = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <class K>
+static void run(const char* label, K kern, size_t lds, const float* src, float* out, unsigned src_bytes, double flop_per_stage_block, unsigned row_stride = 1920) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int blocks = 512, stages = 20000;
+  float best = 1e30f, sum = 0;
+  for (int rep = 0; rep < 6; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, src, out, rep == 0 ? 2000 : stages, src_bytes, row_stride);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep) { best = ms < best ? ms : best; sum += ms; }
+  }
+  const double tf = flop_per_stage_block * blocks * stages / (sum / 5) / 1e9;
+  printf("%-58s mean %.2f ms  %.1f TFLOP/s(-equivalent)  = %.3f of 157.3   (best %.1f)\n", label, sum / 5, tf, tf / 157.3,
+         flop_per_stage_block * blocks * stages / best / 1e9);
+}
+
+int main() {
+  const unsigned src_bytes = 16u << 20;      // L2 / Infinity-Cache resident
+  const unsigned big_bytes = 1u << 30;       // streams from HBM
+  std::vector<float> h(src_bytes / 4);
+  srand(1);
+  for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+  float *src, *out;
+  hipMalloc(&src, big_bytes);
+  hipMalloc(&out, 4);
+  for (unsigned o = 0; o < big_bytes / src_bytes; ++o) hipMemcpy(reinterpret_cast<char*>(src) + (size_t)o * src_bytes, h.data(), src_bytes, hipMemcpyHostToDevice);
+  const double f = 2.0 * 128 * 128 * 16;
+  const size_t lds = 3 * kSlot * 4, lds3 = 3 * kRows * 96;
+  run("fp32 constant operands, registers only (mode 12)", loop_f32<12>, lds, src, out, src_bytes, f);
+  run("fp32 random operands, registers only (mode 8)", loop_f32<8>, lds, src, out, src_bytes, f);
+  run("fp32 random, LDS fragment reads (mode 0)", loop_f32<0>, lds, src, out, src_bytes, f);
+  run("fp32 random, fragment reads + barrier per stage (mode 1)", loop_f32<1>, lds, src, out, src_bytes, f);
+  run("fp32 random, reads + barrier + stage loads / writes (mode 3)", loop_f32<3>, lds, src, out, src_bytes, f);
+  run("  the same, 1 GiB source (HBM)", loop_f32<3>, lds, src, out, big_bytes, f);
+  run("  the same, gathered 64-B row slabs, 16 MiB, stride 1920", (loop_f32<3, 1>), lds, src, out, src_bytes, f, 1920);
+  run("  the same, gathered 64-B row slabs, 1 GiB, stride 1920", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 1920);
+  run("  the same, gathered 64-B row slabs, 1 GiB, stride 768", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 768);
+  run("  the same, gathered 64-B row slabs, 1 GiB, stride 384", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 384);
+  run("bf16x3 random, registers only (mode 8)", loop_bf3<8>, lds3, src, out, src_bytes, f);
+  run("bf16x3 random, LDS fragment reads (mode 0)", loop_bf3<0>, lds3, src, out, src_bytes, f);
+  run("bf16x3 random, fragment reads + barrier per stage (mode 1)", loop_bf3<1>, lds3, src, out, src_bytes, f);
+  return 0;
+}
