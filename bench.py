@@ -49,6 +49,30 @@ def synthetic_batch(n, h, w, seed, device):
     return (img / 255.0 - 0.5).contiguous()
 
 
+def host_cpu():
+    """(model string, physical core count) of the host from /proc/cpuinfo (printed next to the CPU baseline)."""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or os.cpu_count())
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -96,7 +120,7 @@ def launch_ranks(n, argv):
     return rc if rc >= 0 else 1
 
 
-def launch_check(args):
+def launch_check(args, json_fd=1):
     """--launch-check: rendezvous, barrier, one all-gather, one max-reduce -- the collectives of the timed path
     without any kernel (works on a CPU-only host with gloo).  Prints a line that is visibly NOT a measurement."""
     from shallow_ntc_amd import distributed as D
@@ -111,8 +135,8 @@ def launch_check(args):
     D.barrier()
     if rank == 0:
         assert t == world - 1 and table[:, 0].tolist() == list(range(world))
-        print(json.dumps(dict(metric="launch-check (no kernels, not a measurement)", value=None, n_gpus=world,
-                              dry_run=True, rccl=info)), flush=True)
+        os.write(json_fd, (json.dumps(dict(metric="launch-check (no kernels, not a measurement)", value=None, n_gpus=world,
+                                           dry_run=True, rccl=info)) + "\n").encode())
     D.shutdown()
 
 
@@ -129,7 +153,7 @@ def main():
     ap.add_argument("--decode-only", action="store_true",
                     help="only launch decode kernels (the command profiles/ is recorded with): skips the "
                          "encode+decode loop, the (bpp, PSNR) evaluation and the CPU baseline")
-    ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline after one warm-up (SURVEY.md 8d: >= 5)")
     ap.add_argument("--streams", type=int, default=0,
                     help="decode the batches of the set on this many HIP streams at once (0 = one per batch shape): the tail of "
                          "one batch's kernels is filled by the other's blocks; 1 = serial on the current stream")
@@ -146,12 +170,19 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # not under torchrun: be the launcher (no GPU call before this)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE JSON line and nothing else: libraries write banners to the C-level stdout (RCCL prints its version
+    # block there, flushed at exit, i.e. AFTER the line), so file descriptor 1 is pointed at stderr for the life of the process
+    # and the line goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     global np, torch
     import numpy as np
     import torch
     graft.load_package()
     if args.launch_check:
-        return launch_check(args)
+        return launch_check(args, json_fd)
     from shallow_ntc_amd import distributed as D
     from shallow_ntc_amd import ops
     if args.no_fuse:
@@ -159,14 +190,27 @@ def main():
     from shallow_ntc_amd.mshyper import configs
     from shallow_ntc_amd.mshyper.models import Model
 
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
+    rccl_note = None
+    if int(os.environ.get("WORLD_SIZE", 1)) == 1 and not os.environ.get("SNTC_DIST_BACKEND"):
+        # N = 1: still form a ONE-rank RCCL group, so that the barrier / max-reduce / all-gather of the timed path run through
+        # RCCL on the GPU (the only RCCL evidence a one-GPU box can give).  If RCCL cannot initialise here the bench carries
+        # on without a group and says so in `rccl`.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        try:
+            D.init(backend="nccl")
+        except Exception as e:                     # noqa: BLE001 -- any backend failure degrades to "no group", never fails the bench
+            rccl_note = f"one-rank nccl group not formed: {type(e).__name__}: {e}"
     rank, local_rank, world = D.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
     if os.environ.get("SNTC_SHARE_GPU"):          # 2-rank dry run of the distributed flow on a 1-GPU box (gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     world_info = D.describe_world(dev)                # one all_gather_object: backend, world, every rank's device
+    if rccl_note:
+        world_info["note"] = rccl_note
 
     cfg = configs.two_layer_syn(rd_lambda=0.005)
     model = Model(device=dev, **cfg)
@@ -254,6 +298,21 @@ def main():
             cur.wait_stream(st)
         return outs
 
+    def on_codes(fn_per_code):
+        """fn(code) for every (z_hat, symbols, hw, x) of the set, independent batches on independent streams."""
+        if not side or len(codes) < 2:
+            return [fn_per_code(c) for c in codes]
+        cur = torch.cuda.current_stream()
+        outs = []
+        for i, c in enumerate(codes):
+            st = side[i % nstreams]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(fn_per_code(c))
+        for st in side:
+            cur.wait_stream(st)
+        return outs
+
     def e2e_one(batch):
         ids, x, hw = batch
         z_hat, sym, _, _ = model.encode(x)
@@ -262,17 +321,34 @@ def main():
     def e2e_step():
         return on_streams(e2e_one)
 
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, stats=None):
+        """The contract's timing: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
+        torch.cuda.synchronize() on both sides, MAX over ranks of the wall time.  ``stats`` (a dict) additionally receives
+        the per-step durations from HIP events recorded on the launch stream after every step (hipEvents,
+        median + min) -- every step joins its side streams back into the current stream before it returns."""
         for _ in range(warmup):
             fn()
         D.barrier()
         torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if stats is not None else None
         t0 = time.perf_counter()
-        for _ in range(steps):
+        if evs:
+            evs[0].record()
+        for i in range(steps):
             fn()
+            if evs:
+                evs[i + 1].record()
         torch.cuda.synchronize()
         D.barrier()
-        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        wall = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        if evs:
+            per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+            stats.update(steps=steps, warmup=warmup, mean_ms=round(1e3 * wall / steps, 4), median_ms=round(float(np.median(per)), 4),
+                         min_ms=round(float(per.min()), 4), timer="HIP events on the launch stream per step; mean = wall clock / steps")
+        return wall
+
+    # SURVEY.md 8d: >= 10 warm-up and >= 50 timed iterations per region (the 40 - 55 ms encode-side regions: >= 20)
+    R_WARM, R_STEPS, R_STEPS_ENC = 10, max(50, args.steps), max(20, min(args.steps, 50))
 
     def region_frac(fn, seconds_per_step):
         """Algorithmic conv FLOPs of one pass of ``fn`` (sntc_conv_flops of every launch, recorded by ops.PROFILE in an
@@ -285,27 +361,35 @@ def main():
         tf = flops / seconds_per_step / 1e12
         return dict(gflop_per_step=round(flops / 1e9, 2), tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4))
 
-    t_dec = timed(decode_step, args.steps, args.warmup)
+    t_dec = timed(decode_step, args.steps, args.warmup)                 # the headline: exactly --steps steps after --warmup
     ms_per_step = 1e3 * t_dec / args.steps
     value = world * pixels_per_step * args.steps / t_dec / 1e6
     e2e_value, table = None, None
-    regions = dict(decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2),
-                               roofline=region_frac(decode_eager, t_dec / args.steps)))
+
+    def region(fn, steps, px, frac_fn=None, **extra):
+        """One measured region: R_WARM warm-up steps, ``steps`` timed ones; rate from the median step (HIP events)."""
+        st = {}
+        t = timed(fn, steps, R_WARM, st)
+        med = st["median_ms"] * 1e-3
+        out = dict(extra, ms_per_step=st["median_ms"], mpixels_per_s=round(world * px / med / 1e6, 2), timing=st,
+                   roofline=region_frac(frac_fn or fn, med))
+        return out, t / steps
+
+    regions = {}
+    regions["decode"], _ = region(decode_step, R_STEPS, pixels_per_step, decode_eager)
     if not args.decode_only:
-        e2e_steps = max(2, args.steps // 4)
-        t_e2e = timed(e2e_step, e2e_steps, 1)
-        e2e_value = world * pixels_per_step * e2e_steps / t_e2e / 1e6
-        # the other regions of SURVEY.md 8d, whole job like `value`: encode alone on the metric's set, and
+        enc_fn = lambda: on_streams(lambda b: model.encode(b[1]))
+        regions["encode"], _ = region(enc_fn, R_STEPS_ENC, pixels_per_step)
+        regions["encode_decode_score"], t_e2e_step = region(e2e_step, R_STEPS_ENC, pixels_per_step)
+        e2e_value = regions["encode_decode_score"]["mpixels_per_s"]
         # encode+decode on the synthetic 256x256 batches the north star asks for at every GPU count
-        t_enc = timed(lambda: on_streams(lambda b: model.encode(b[1])), e2e_steps, 1)
         w1_x = synthetic_batch(64, 256, 256, 4321 + rank, dev)
 
         def w1_step():
             z_hat, sym, _, _ = model.encode(w1_x)
             model.decode(z_hat, sym, (256, 256), reference=w1_x)
 
-        t_w1 = timed(w1_step, e2e_steps, 1)
-        mpx = lambda px, t: round(world * px * e2e_steps / t / 1e6, 2)
+        regions["w1_encode_decode_score"], _ = region(w1_step, R_STEPS_ENC, 64 * 256 * 256, workload="64 x 256x256 per GPU")
         # training step (SURVEY.md 8 f4) at the reference's training shape (two_layer_syn.py:13-15: batch 8 x 256 x 256 per
         # replica); data-parallel: with N > 1 the bucketed gradient all-reduce over RCCL is inside the timed region
         from shallow_ntc_amd.train import Trainer
@@ -314,22 +398,12 @@ def main():
         train_model = Model(device=dev, **train_cfg)
         trainer = Trainer(train_model, seed=rank)
         train_x = synthetic_batch(8, 256, 256, 777 + rank, dev)
-        t_train = timed(lambda: trainer.train_step(train_x), e2e_steps, 2)
+        st = {}
+        timed(lambda: trainer.train_step(train_x), R_STEPS_ENC, R_WARM, st)
         del trainer, train_model
-        enc_fn = lambda: on_streams(lambda b: model.encode(b[1]))
-        regions = dict(
-            decode=dict(ms_per_step=round(ms_per_step, 4), mpixels_per_s=round(value, 2),
-                        roofline=region_frac(decode_eager, t_dec / args.steps)),
-            encode=dict(ms_per_step=round(1e3 * t_enc / e2e_steps, 3), mpixels_per_s=mpx(pixels_per_step, t_enc),
-                        roofline=region_frac(enc_fn, t_enc / e2e_steps)),
-            encode_decode_score=dict(ms_per_step=round(1e3 * t_e2e / e2e_steps, 3), mpixels_per_s=round(e2e_value, 2),
-                                     roofline=region_frac(e2e_step, t_e2e / e2e_steps)),
-            w1_encode_decode_score=dict(workload="64 x 256x256 per GPU", ms_per_step=round(1e3 * t_w1 / e2e_steps, 3),
-                                        mpixels_per_s=mpx(64 * 256 * 256, t_w1),
-                                        roofline=region_frac(w1_step, t_w1 / e2e_steps)),
-            train_step=dict(workload="8 x 256x256 per GPU, unoise, Adam + global_clipnorm, gradient all-reduce when N > 1",
-                            ms_per_step=round(1e3 * t_train / e2e_steps, 3),
-                            images_per_s=round(world * 8 * e2e_steps / t_train, 1), mpixels_per_s=mpx(8 * 256 * 256, t_train)))
+        regions["train_step"] = dict(workload="8 x 256x256 per GPU, unoise, Adam + global_clipnorm, gradient all-reduce when N > 1",
+                                     ms_per_step=st["median_ms"], images_per_s=round(world * 8 / (st["median_ms"] * 1e-3), 1),
+                                     mpixels_per_s=round(world * 8 * 256 * 256 / (st["median_ms"] * 1e-3) / 1e6, 2), timing=st)
         # the reference's own call pattern (mshyper/models.py:425-433, eval.py): evaluate() one image at a time -- encode,
         # rate, decode, PSNR (and MS-SSIM) per image.  "serial" synchronises after every image like the reference's eager
         # loop; the default launches same-shaped images among the next 16 four at a time and keeps 4 launches in flight on
@@ -343,17 +417,17 @@ def main():
         for label, quality, look in (("psnr_only_serial", False, 1), ("psnr_only", False, 4), ("with_msssim_serial", True, 1),
                                      ("with_msssim", True, 4)):
             model._quality_metrics = quality
-            t = timed(lambda: list(model.evaluate(singles, lookahead=look)), 2, 1)
-            b1[label] = dict(ms_per_image=round(1e3 * t / 2 / len(singles), 3), mpixels_per_s=round(world * pixels_per_step * 2 / t / 1e6, 2))
+            t = timed(lambda: list(model.evaluate(singles, lookahead=look)), 1, 1)
+            b1[label] = dict(ms_per_image=round(1e3 * t / len(singles), 3), mpixels_per_s=round(world * pixels_per_step / t / 1e6, 2))
         model._quality_metrics = keep_q
         regions["evaluate_b1"] = dict(workload=f"{len(singles)} images per GPU, one at a time through Model.evaluate()", **b1)
-        # EXPERIMENT, fenced: the same decode with the bf16 x 3 split-precision contraction in the hyper-synthesis
-        # and synthesis convolutions.  Reported next to -- never instead of -- the fp32 numbers, with its own parity figures.
-        ops.BF16X3_EXPERIMENT = True
-        model3 = Model(device=dev, **cfg)
+        # Split precision, opt-in (Model(precision="bf16x3")): the same decode / encode with the convolutions that
+        # qualify on the pre-split bf16 x 3 kernel.  Reported next to -- never instead of -- the fp32 numbers (`value` and `dtype`
+        # stay exact fp32), with its own parity figures against the fp32 model on the same codes.
+        model3 = Model(device=dev, precision="bf16x3", **cfg)
         model3.set_weights(model.get_weights())
-        ops.BF16X3_EXPERIMENT = False
-        t_dec3 = timed(lambda: [model3.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes], args.steps, args.warmup)
+        dec3 = lambda: on_codes(lambda c: model3.decode(c[0], c[1], c[2]))
+        r3, _ = region(dec3, R_STEPS, pixels_per_step, lambda: [model3.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes])
         diff = tot = 0
         sse32 = sse3 = 0
         for z_hat, sym, hw, x in codes:
@@ -365,10 +439,20 @@ def main():
             sse32 += int(s32.sum()); sse3 += int(s3.sum())
         psnr = lambda sse: 10.0 * np.log10(255.0 ** 2 / (sse / tot))
         regions["decode_bf16x3"] = dict(
-            experiment="split precision: 3 bf16 terms per fp32 operand, 6 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate",
-            ms_per_step=round(1e3 * t_dec3 / args.steps, 4), mpixels_per_s=round(world * pixels_per_step * args.steps / t_dec3 / 1e6, 2),
-            speedup_over_fp32=round(t_dec / t_dec3, 3), pixel_values=tot, pixels_differing_from_fp32=diff,
-            max_code_difference=1 if diff else 0, d_psnr_vs_fp32_db=round(float(psnr(sse3) - psnr(sse32)), 7))
+            r3, mode="opt-in split precision: 3 bf16 terms per fp32 operand (activations and weights pre-split), 6 cross products on "
+                     "v_mfma_f32_32x32x16_bf16, fp32 accumulate; csrc/bf3_gemm.hip",
+            speedup_over_fp32=round(regions["decode"]["ms_per_step"] / r3["ms_per_step"], 3), pixel_values=tot,
+            pixels_differing_from_fp32=diff, max_code_difference=1 if diff else 0,
+            d_psnr_vs_fp32_db=round(float(psnr(sse3) - psnr(sse32)), 7))
+        enc3 = lambda: on_streams(lambda b: model3.encode(b[1]))
+        r3e, _ = region(enc3, R_STEPS_ENC, pixels_per_step)
+        sym_diff = sym_tot = 0
+        for ids, xb, hw in batches:
+            _, s_a, _, _ = model.encode(xb)
+            _, s_b, _, _ = model3.encode(xb)
+            sym_diff += int((s_a != s_b).sum()); sym_tot += s_a.numel()
+        regions["encode_bf16x3"] = dict(r3e, speedup_over_fp32=round(regions["encode"]["ms_per_step"] / r3e["ms_per_step"], 3),
+                                        symbols=sym_tot, symbols_differing_from_fp32=sym_diff)
         del model3
         rows = []                          # per-image (bpp, psnr, mse) of the rank's set, then ONE all-gather
         for ids, x, hw in batches:
@@ -453,7 +537,7 @@ def main():
         from oracle import transforms_np as T
         enc_x = batches[0][1][:2].cpu().numpy()
         enc_times = []
-        for p in range(3):
+        for p in range(args.cpu_passes + 1):
             t0 = time.perf_counter()
             yc = torch_ref.analysis_only(ref_model, weights, enc_x)
             with torch.no_grad():
@@ -461,13 +545,17 @@ def main():
             if p > 0:
                 enc_times.append(time.perf_counter() - t0)
         enc_px = enc_x.shape[0] * enc_x.shape[1] * enc_x.shape[2]
+        cpu_model, phys = host_cpu()
         cpu_baseline = dict(value=round(pixels_per_step / t_cpu / 1e6, 3), unit="Mpixel/s", cores=torch.get_num_threads(),
+                            cpu_model=cpu_model, physical_cores=phys, min_value=round(pixels_per_step / float(np.max(times)) / 1e6, 3),
+                            max_value=round(pixels_per_step / float(np.min(times)) / 1e6, 3),
                             encode_transforms_value=round(enc_px / float(np.median(enc_times)) / 1e6, 3),
-                            encode_sample=f"analysis + hyper-analysis of {enc_x.shape[0]} images of the set, median of 2 passes after 1 warm-up",
+                            encode_sample=f"analysis + hyper-analysis of {enc_x.shape[0]} images of the set, median of "
+                                          f"{args.cpu_passes} passes after 1 warm-up",
                             kind="port",
-                            sample=f"{n_img} Kodak-shaped images decoded by oracle/torch_ref.py (float32, oneDNN), "
-                                   f"median of {args.cpu_passes} passes after 1 warm-up; the reference's TF-CPU path "
-                                   f"cannot be installed here")
+                            sample=f"{n_img} Kodak-shaped images decoded by oracle/torch_ref.py (float32, oneDNN, "
+                                   f"{torch.get_num_threads()} threads), median of {args.cpu_passes} passes after 1 warm-up; "
+                                   f"the reference's TF-CPU path cannot be installed here")
 
     if rank == 0:
         rd = None
@@ -492,7 +580,7 @@ def main():
             encode_decode_mpixels_per_s=None if e2e_value is None else round(e2e_value, 2),
             regions=regions, rd=rd, roofline=roofline, cpu_baseline=cpu_baseline, rccl=world_info,
         )
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     D.shutdown()
 
 

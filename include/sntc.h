@@ -87,9 +87,13 @@ typedef struct sntc_conv_desc {
                         * native layout (so that the input-gradient plan of a layer -- the adjoint kind -- packs straight
                         * from the layer's own kernel array; Keras Conv2D <-> Conv2DTranspose are each other's swap already,
                         * tfc.SignalConv2D down <-> up need the flag);
-                        * reserved[1] != 0: EXPERIMENT -- bf16 x 3 split-precision contraction (hi + mid + lo bfloat16 terms, six
-                        * cross products on the bf16 matrix cores, fp32 accumulation): ~1e-7 relative like fp32 but NOT
-                        * bit-identical to it; Cin % 16 == 0, no prologue; never used by the default paths;
+                        * reserved[1] != 0: bf16 x 3 split-precision contraction (hi + mid + lo bfloat16 terms, six cross
+                        * products on the bf16 matrix cores, fp32 accumulation): ~1e-7 relative like fp32 but NOT
+                        * bit-identical to it; Cin % 16 == 0, no prologue; opt-in (Model(precision="bf16x3")), never a default.
+                        *   1: fp32 NHWC input, split while it is staged (the round-2 experiment);
+                        *   2: the INPUT is pre-split too -- format S3, see sntc_split3 -- and the launch runs the 256-wide
+                        *      direct-to-LDS kernel of csrc/bf3_gemm.hip; output fp32 NHWC; Cout % 4 == 0, epilogues
+                        *      STORE / ADD / GATE / MASK_*; no split-K;
                         * the rest must be 0 */
 } sntc_conv_desc;
 
@@ -148,6 +152,27 @@ int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
  * produces bit-identical outputs (each element is the same k-ordered fma chain); the switches exist so that a test can
  * assert exactly that. */
 int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int flags);
+/* ------------------------------------------------------------------------------------------
+ * Split-precision operands (bf16 x 3).  Format S3 of an NHWC tensor with C % 16 == 0: per pixel and 16-channel slab
+ * 96 bytes [hi x 16 | mid x 16 | lo x 16] bfloat16 with x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi),
+ * lo = bf16(x - hi - mid)): 6 bytes per element, what a conv plan with reserved[1] == 2 reads.  The reference has no
+ * counterpart (fp32 tf.nn.conv2d, common/transforms.py:81-90); these feed the same contractions.
+ * ------------------------------------------------------------------------------------------ */
+/* out (S3, npix * c * 6 bytes) = split(x [npix, c] fp32) */
+int sntc_split3(const float* x, int64_t npix, int c, void* out, void* stream);
+/* decoder side of sntc_entropy_scale_normal fused with the split: y_hat = symbols + mu (mu = first half of hyper
+ * [npix, 2c], mshyper/models.py:278-279) -> out (S3); y_hat (fp32 [npix, c]) is also written when not NULL */
+int sntc_dequant_split3(const int32_t* symbols, const float* hyper, int64_t npix, int c, void* out, float* y_hat,
+                        void* stream);
+/* Stream-K health.  The persistent stream-K schedule needs every worker of a launch resident at once, which HIP does not
+ * promise on a device that other streams or processes share.  A worker that waits in vain (bounded spin) for its neighbour's
+ * hand-off no longer traps: it sets bit 0 of a sticky per-device status word and the launch completes with INVALID results.
+ * sntc_conv_status copies that word to *flags (synchronising `stream`) and clears it -- call it where the host synchronises
+ * anyway (the Python driver does, at every device -> host copy of metrics); non-zero means: discard the results since the last
+ * check, and re-run after sntc_conv_set_stream_k(0), which makes every later call use the static one-workgroup-per-tile /
+ * split-K schedules (bit-identical results).  The reference has no counterpart (single stream, cuDNN). */
+int sntc_conv_status(int* flags, void* stream);
+int sntc_conv_set_stream_k(int enabled);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);

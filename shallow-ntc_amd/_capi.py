@@ -58,6 +58,10 @@ SIGNATURES = {
     "sntc_conv_forward_fused": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "sntc_conv_plan_set_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "sntc_conv_plan_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "sntc_split3": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
+    "sntc_dequant_split3": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P]),
+    "sntc_conv_status": (C.c_int, [C.POINTER(C.c_int), _P]),
+    "sntc_conv_set_stream_k": (C.c_int, [C.c_int]),
     "sntc_conv_launch_info": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sntc_gdn_small": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_two_layer_tail": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,

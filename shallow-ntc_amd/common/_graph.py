@@ -12,12 +12,59 @@ from __future__ import annotations
 
 from collections import OrderedDict
 
+import torch
+
 from .. import _capi as capi
 from .. import ops
 
 
+S3_MIN_ROWS = 256      # a layer runs on the pre-split bf16 x 3 kernel when one IMAGE offers at least one 256-row strip of its GEMM
+
+
+def s3_eligible(kind, cin, cout, epilogue):
+    """Static part of the rule: what csrc/bf3_gemm.hip can run (include/sntc.h, sntc_conv_desc.reserved[1] == 2)."""
+    return cin % 16 == 0 and cout % 4 == 0 and epilogue in (capi.EPI_STORE, capi.EPI_ADD, capi.EPI_GATE, capi.EPI_MASK_RELU,
+                                                              capi.EPI_MASK_LEAKY)
+
+
+def s3_rows(kind, stride, h, w):
+    """Rows of the layer's GEMM per image (the macro-pixel grid): input pixels of a transposed layer, output pixels of a conv."""
+    if kind in ("convT", "sigup"):
+        return h * w
+    return (-(-h // stride)) * (-(-w // stride))
+
+
+class DualPlan:
+    """A convolution's fp32 plan and, under ``precision="bf16x3"``, its pre-split split-precision plan.  Which of the two
+    runs is a function of the LAYER and of the per-image geometry only -- never of the batch size -- so an encoder and a
+    decoder that see the same image size take the same arithmetic whatever their batching (the decoder must reproduce the
+    encoder's mu / sigma bit for bit)."""
+
+    def __init__(self, kind, weight, bias, stride, act=None, prologue=capi.PRO_NONE, epilogue=capi.EPI_STORE, precision="fp32"):
+        self.kind, self.stride = kind, int(stride)
+        self.fp32 = ops.ConvPlan(kind, weight, bias, stride, act, prologue, epilogue)
+        self.s3 = None
+        if precision == "bf16x3" and prologue == capi.PRO_NONE and s3_eligible(kind, self.fp32.cin, self.fp32.cout, epilogue):
+            self.s3 = ops.ConvPlan(kind, weight, bias, stride, act, prologue, epilogue, bf16x3="presplit")
+        self.cin, self.cout = self.fp32.cin, self.fp32.cout
+
+    def takes_s3(self, h, w):
+        return self.s3 is not None and s3_rows(self.kind, self.stride, h, w) >= S3_MIN_ROWS
+
+    def __call__(self, x, res=None, aux=None):
+        if self.takes_s3(x.shape[1], x.shape[2]):
+            return self.s3(x if x.dtype == torch.bfloat16 else ops.split3(x), res, aux)
+        return self.fp32(x, res, aux)
+
+    # the fp32 plan's interface, for the callers that fuse / profile / shape-infer
+    def __getattr__(self, name):
+        return getattr(self.fp32, name)
+
+
 class Conv:
     """kind: conv (Keras Conv2D SAME) | convT (Keras Conv2DTranspose SAME) | sigdown / sigup (tfc.SignalConv2D)."""
+
+    precision = "fp32"
 
     def __init__(self, name, kind, cout, k, s, act=None, bias=True, epilogue=capi.EPI_STORE):
         self.name, self.kind, self.cout, self.k, self.s, self.act, self.bias = name, kind, cout, k, s, act, bias
@@ -32,8 +79,9 @@ class Conv:
         return d, self.cout
 
     def build(self, w, cin):
-        self.plan = ops.ConvPlan(self.kind, w[f"{self.name}/kernel"], w.get(f"{self.name}/bias") if self.bias else None,
-                                 self.s, self.act, capi.PRO_NONE, self.epilogue)
+        args = (self.kind, w[f"{self.name}/kernel"], w.get(f"{self.name}/bias") if self.bias else None, self.s, self.act,
+                capi.PRO_NONE, self.epilogue)
+        self.plan = DualPlan(*args, precision=self.precision) if self.precision != "fp32" else ops.ConvPlan(*args)
         return self.cout
 
     def __call__(self, x, res=None, aux=None):
@@ -46,6 +94,14 @@ class Conv:
 
     def flops(self, n, h, w):
         return self.plan.flops(n, h, w), self.plan.out_hw(h, w)
+
+
+def set_precision(node, precision):
+    """Mark every convolution under ``node`` (before it is built) with the arithmetic it should prefer."""
+    if isinstance(node, Conv):
+        node.precision = precision
+    for child in getattr(node, "layers", ()) or ():
+        set_precision(child, precision)
 
 
 class GDN:

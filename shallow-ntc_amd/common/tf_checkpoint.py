@@ -22,6 +22,9 @@ import struct
 from collections import OrderedDict
 from pathlib import Path
 
+import os
+import warnings
+
 import numpy as np
 
 TABLE_MAGIC = 0xDB4775248B80FB57
@@ -416,16 +419,42 @@ def gdn_parameter_variable(value):
     return np.sqrt(np.maximum(np.asarray(value, np.float64) + GDN_PEDESTAL, GDN_PEDESTAL)).astype(np.float32)
 
 
-def irdft_matrix(shape):
+RDFT_LAYOUTS = ("real_then_imag", "interleaved")
+RDFT_LAYOUT = os.environ.get("SNTC_RDFT_LAYOUT", "real_then_imag")
+_rdft_warned = set()
+
+
+def _warn_rdft(direction):
+    """Import / export of tfc.RDFTParameter variables is UNVERIFIED against a TensorFlow-written checkpoint: say so, loudly,
+    once per direction and process.  Both column orders of the basis are orthonormal frames of the same shape, so no shape or
+    round-trip check can tell them apart -- only a real SignalConv2D checkpoint can."""
+    if direction not in _rdft_warned:
+        _rdft_warned.add(direction)
+        warnings.warn(f"tf_checkpoint: {direction} of tfc.SignalConv2D kernels stored as real-DFT coefficients (bls2017 / mbt2018 "
+                      f"models) assumes the '{RDFT_LAYOUT}' column order of tfc's irdft_matrix; this restatement has NOT been "
+                      "verified against a TensorFlow-written bundle -- a wrong order imports wrong kernels silently.  Check one "
+                      "layer against the reference (or set SNTC_RDFT_LAYOUT to the other order, 'interleaved' / 'real_then_imag') "
+                      "before trusting the result.", RuntimeWarning, stacklevel=3)
+
+
+def irdft_matrix(shape, layout=None):
     """tfc's real-DFT kernel basis (tensorflow_compression spectral_ops.irdft_matrix, the matrix behind
     ``tfc.layers.RDFTParameter``, the default ``kernel_parameter="rdft"`` of tfc.SignalConv2D; reference call sites
     common/transforms.py:101-112,123-134,152-155,172-175) [DEP: restated from the published definition, NOT verified
     against a TF-written checkpoint]: the rows of the identity over the kernel's spatial ``shape`` are taken through
     ``rfftn``; the bins of the last axis that have a distinct conjugate partner are scaled by sqrt(2), everything by
-    1 / sqrt(size); real and imaginary parts are concatenated along the last axis and flattened.  The result M is
-    [size, 2 * prod(shape[:-1]) * (shape[-1] // 2 + 1)] with M @ M.T = I, so that
+    1 / sqrt(size).  Column order (``layout``, default the module's RDFT_LAYOUT / SNTC_RDFT_LAYOUT):
+    'real_then_imag' -- the half spectrum is flattened to [size, -1] first and then [real | imag] are concatenated (all real
+    columns, then all imaginary ones; the default: tfc reshapes before it concatenates); 'interleaved' -- real and imaginary
+    parts are concatenated along the last frequency axis before flattening (per frequency row [re.. | im..]; the order this
+    repository used through round 2).  Either way M is [size, 2 * prod(shape[:-1]) * (shape[-1] // 2 + 1)] with
+    M @ M.T = I, so that
         rdft   = M.T @ kernel.reshape(size, cin * cout)         (what the checkpoint stores)
-        kernel = (M @ rdft).reshape(*shape, cin, cout)          (what the layer convolves with)."""
+        kernel = (M @ rdft).reshape(*shape, cin, cout)          (what the layer convolves with);
+    the two orders differ by a permutation of the rdft rows only (training is unaffected: Adam is element-wise)."""
+    layout = layout or RDFT_LAYOUT
+    if layout not in RDFT_LAYOUTS:
+        raise ValueError(f"rdft layout must be one of {RDFT_LAYOUTS}, not {layout!r}")
     shape = tuple(int(v) for v in shape)
     size = int(np.prod(shape))
     rank = len(shape)
@@ -434,7 +463,10 @@ def irdft_matrix(shape):
     n = shape[-1]
     f[..., 1:(n + 1) // 2] *= np.sqrt(2.0)
     f /= np.sqrt(size)
-    return np.concatenate([f.real, f.imag], axis=-1).reshape(size, -1)
+    if layout == "interleaved":
+        return np.concatenate([f.real, f.imag], axis=-1).reshape(size, -1)
+    f = f.reshape(size, -1)
+    return np.concatenate([f.real, f.imag], axis=-1)
 
 
 def rdft_to_kernel(rdft, spatial, cin, cout):
@@ -474,6 +506,7 @@ class CheckpointMapper:
 
     def signal_conv(self, node, name, spatial, cin, cout, bias=True):     # tfc.SignalConv2D, kernel_parameter="rdft"
         kp = self.g.path(node, ("_kernel_parameter", "kernel_parameter", "kernel"), "rdft")
+        _warn_rdft("import")
         self.out[f"{name}/kernel"] = rdft_to_kernel(self.var(kp), spatial, cin, cout)
         if bias:
             self.out[f"{name}/bias"] = self.var(self.g.child(node, "_bias_parameter", "bias_parameter", "bias"))
@@ -682,6 +715,7 @@ class _GraphWriter:
             n = self.add(parent, f"layer_with_weights-{i}")
             lp = f"{path}/layer_with_weights-{i}"
             kp = self.add(n, "_kernel_parameter")
+            _warn_rdft("export")
             self.var(kp, "rdft", f"{lp}/_kernel_parameter", kernel_to_rdft(self.w[f"{ours_prefix}layer_{i}/kernel"]))
             if f"{ours_prefix}layer_{i}/bias" in self.w:
                 self.var(n, "_bias_parameter", lp, self.w[f"{ours_prefix}layer_{i}/bias"])

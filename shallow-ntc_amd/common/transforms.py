@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ._graph import GDN, Conv, ResidualBlock, Seq, SimpleAttention
+from ._graph import GDN, Conv, DualPlan, ResidualBlock, Seq, SimpleAttention, set_precision
 from .utils import ClassBuilder
 
 
@@ -70,6 +70,7 @@ class Transform:
         self._graph = graph
         self._cin = input_channels
         self._seed = seed
+        self._precision = "fp32"      # "bf16x3": the convolutions that qualify run split precision (Model(precision=...))
         self._weights = None          # host, OrderedDict name -> float32 ndarray
         self._built_on = None
         self.output_channels = None
@@ -115,6 +116,7 @@ class Transform:
             return self
         host = self._prepare_weights(self.get_weights())
         dev = {k: ops.to_device(v, device) for k, v in host.items()}
+        set_precision(self._graph, self._precision)
         with torch.cuda.device(device):
             self.output_channels = self._graph.build(dev, self._graph_cin())
         self._dev = dev
@@ -130,7 +132,7 @@ class Transform:
     # -- call -----------------------------------------------------------------------------------
     def __call__(self, x, training=False):
         if self._built_on != x.device:
-            self.build(x.shape[-1], x.device)
+            self.build(x.shape[-1] if x.dim() == 4 else x.shape[3] * 16, x.device)
         return self._forward(x)
 
     def _forward(self, x):
@@ -142,6 +144,13 @@ class Transform:
     def out_hw(self, h, w):
         """Output spatial size for an h x w input (shape inference only, nothing is launched)."""
         return self._graph.out_hw(h, w)
+
+    def takes_s3(self, h, w):
+        """True if the transform's FIRST convolution reads pre-split (format S3) input for h x w images: its producer can then
+        emit S3 directly (the decoder's dequantisation does, ops.dequant_split3)."""
+        first = self._graph.layers[0] if isinstance(self._graph, Seq) and self._graph.layers else None
+        plan = getattr(first, "plan", None)
+        return isinstance(plan, DualPlan) and plan.takes_s3(h, w)
 
 
 class BLS2017Analysis(Transform):
@@ -332,7 +341,7 @@ class _TwoLayerBase(Transform):
             k1 = np.concatenate([k1, w[f"{nr}/kernel"]], axis=2)
             b1 = np.concatenate([b1, w[f"{nr}/bias"]])
         with torch.cuda.device(device):
-            self._up = ops.ConvPlan("convT", ops.to_device(k1, device), ops.to_device(b1, device), self._s[0])
+            self._up = DualPlan("convT", ops.to_device(k1, device), ops.to_device(b1, device), self._s[0], precision=self._precision)
         self._beta = ops.to_device(w["act/beta"], device) if "act/beta" in w else None
         self._gamma = ops.to_device(w["act/gamma"], device) if "act/gamma" in w else None
         self._w2 = ops.to_device(w[f"{n2}/kernel"], device)
@@ -340,6 +349,9 @@ class _TwoLayerBase(Transform):
         self.output_channels = self._out_ch
         self._built_on = device
         return self
+
+    def takes_s3(self, h, w):
+        return self._built_on is not None and self._up.takes_s3(h, w)
 
     def _forward(self, x):
         t = self._up(x)
@@ -350,7 +362,7 @@ class _TwoLayerBase(Transform):
         """Decoder form: the synthesis ends in uint8 pixels cropped to h x w (and the integer SSE against ``reference``)
         in the same launch as the activation and the output layer -- no float image round trip."""
         if self._built_on != x.device:
-            self.build(x.shape[-1], x.device)
+            self.build(x.shape[-1] if x.dim() == 4 else x.shape[3] * 16, x.device)
         t = self._up(x)
         return ops.two_layer_tail_pixels(t, self._ch, self._has_res, self._act_kind, self._beta, self._gamma, self._w2, self._b2,
                                          h, w, reference, self._k[1], self._s[1])

@@ -7,6 +7,7 @@
 // <= 4 groups that share a tap pattern; each group is one GEMM whose columns are
 // (phase, channel) pairs: N = phases*Cout, K = taps*Cin -- no zero stuffing, no col2im.
 #include <algorithm>
+#include <atomic>
 #include <vector>
 #include "sntc_internal.h"
 
@@ -132,7 +133,8 @@ struct sntc_conv_plan {
   } g[kMaxGroups];
   float* bias = nullptr;
   int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
-  bool bf3 = false;         // desc.reserved[1]: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
+  bool bf3 = false;         // desc.reserved[1]: bf16 x 3 split precision (weights packed as three bf16 planes)
+  bool s3 = false;          // desc.reserved[1] == 2: the INPUT arrives pre-split too (format S3, 6 B per element): csrc/bf3_gemm.hip
   bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
   int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
@@ -141,7 +143,8 @@ struct sntc_conv_plan {
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_tile: null plan");
-  if (variant < 0 || variant > kNumVariants) return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_tile: unknown tile variant");
+  if (variant < 0 || variant > (p->s3 ? 14 : kNumVariants) || (p->s3 && variant != 0 && variant < 11))
+    return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_tile: unknown tile variant");
   p->tile = variant;
   return SNTC_OK;
 }
@@ -311,9 +314,15 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
   // array is the channel-transposed one (the adjoint of a SignalConv2D layer runs on the layer's own kernel array)
   p->out_major = (d.kind == SNTC_CONV2D_TRANSPOSE) != (d.reserved[0] != 0);
   p->bf3 = d.reserved[1] != 0;
+  p->s3 = d.reserved[1] == 2;
   if (p->bf3 && (!p->vec || d.prologue != SNTC_PRO_NONE)) {
     delete p;
     return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 plans need Cin % 16 == 0 and no prologue");
+  }
+  if (p->s3 && ((d.cout & 3) || (d.epilogue != SNTC_EPI_STORE && d.epilogue != SNTC_EPI_ADD && d.epilogue != SNTC_EPI_GATE &&
+                                d.epilogue != SNTC_EPI_MASK_RELU && d.epilogue != SNTC_EPI_MASK_LEAKY))) {
+    delete p;
+    return fail(SNTC_ERR_UNSUPPORTED, "pre-split bf16 x 3 plans need Cout % 4 == 0 and a store / add / gate / mask epilogue");
   }
   rc = build_plan(p, weight, bias, (hipStream_t)stream);
   if (rc) {
@@ -517,8 +526,11 @@ static int pick_ksplit(const sntc_conv_plan* p, const Geo& g) {
   return std::max(1, std::min({8, want, std::max(1, steps_min / 8)}));
 }
 
+static int variant_bm(int v) { return v > kNumVariants ? bf3p_variant_bm(v) : gg_variant_bm(v); }
+static int variant_bn(int v) { return v > kNumVariants ? bf3p_variant_bn(v) : gg_variant_bn(v); }
+
 static void count_work(const sntc_conv_plan* p, int v, int64_t M, int64_t* tiles, int64_t* units, double* padded_macs) {
-  const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
+  const int bm = variant_bm(v), bn = variant_bn(v);
   const int64_t ntm = (M + bm - 1) / bm;
   *tiles = 0; *units = 0; *padded_macs = 0;
   for (int gi = 0; gi < p->ngroups; ++gi) {
@@ -535,7 +547,47 @@ static void count_work(const sntc_conv_plan* p, int v, int64_t M, int64_t* tiles
 constexpr int kDeepBlocksPerCU = 2;
 constexpr double kDeepCost = 0.6;      // relative cost of a deep-ring launch against the rounds model below (measured, tools/b1_layers.py)
 
+// Process-wide default of the stream-K schedule (sntc_conv_set_stream_k): on unless a caller has turned it off, e.g. after
+// sntc_conv_status reported a timed-out hand-off on an oversubscribed device.  Results are bit-identical either way.
+static std::atomic<int> g_stream_k_enabled{1};
+
+// Pre-split bf16 x 3 plans: 256 x 256 or 256 x 128 tiles on one 512-thread workgroup per CU; stream-K whenever every CU gets
+// at least a longest tile's worth of stages, else one workgroup per tile.  No split-K (layers that small stay on the fp32 path).
+static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
+  Sched best;
+  const int64_t M = n * g.Qh * g.Qw;
+  const int msteps = max_steps(p);
+  const int cus = std::max(8, gg_num_cus());
+  double best_cost = 1e300;
+  for (int v : {11, 12, 13, 14}) {
+    if (p->tile >= 11 ? v != p->tile : v > 12) continue;
+    int64_t tiles, units;
+    double macs;
+    count_work(p, v, M, &tiles, &units, &macs);
+    Sched s;
+    s.variant = v;
+    s.ksplit = 1;
+    s.units = units;
+    const int64_t fit = msteps > 0 ? units / msteps : 0;
+    const int workers = (int)(std::min<int64_t>(cus, fit) & ~7LL);
+    s.sk = !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 && 2 * workers >= cus;
+    s.workers = s.sk ? workers : 0;
+    s.blocks = s.sk ? workers : tiles;
+    double cost = macs;
+    if (s.sk) {
+      cost *= (double)cus / workers;
+    } else {
+      const double rounds = (double)tiles / cus;
+      cost *= rounds < 1.0 ? 1.0 / rounds : std::ceil(rounds) / rounds;
+    }
+    cost /= ((v == 11 || v == 13) ? 1.0 : 0.84);          // measured loop rates, tools/microbench/gemm_ceiling.hip: 276 vs 232 TFLOP/s-equivalent
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
 static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fused = false) {
+  if (p->s3) return schedule_s3(p, g, n);
   Sched best;
   const int64_t M = n * g.Qh * g.Qw;
   const int ksplit = fused ? 1 : pick_ksplit(p, g);
@@ -564,7 +616,8 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // of stages (an idle slot costs less than a second, half-empty round of whole tiles); a multiple of 8 (XCD dealing)
     const int64_t fit = msteps > 0 ? units / msteps : 0;
     const int workers = (int)(std::min<int64_t>(resident, fit) & ~7LL);
-    s.sk = ksplit == 1 && !p->no_stream_k && units < (1LL << 31) && workers >= 8 && 2 * workers >= resident;
+    s.sk = ksplit == 1 && !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) &&
+           workers >= 8 && 2 * workers >= resident;
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles * ksplit;
     double cost = macs;
@@ -593,7 +646,8 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
 }
 
 static int64_t workspace_floats(const sntc_conv_plan* p, int64_t M, const Sched& s) {
-  if (s.sk) return (int64_t)s.workers * (int64_t)gg_sk_slab_floats(s.variant) + s.workers;   // slabs + one flag per worker
+  if (s.sk)      // slabs + one flag per worker
+    return (int64_t)s.workers * (int64_t)(s.variant > kNumVariants ? bf3p_sk_slab_floats(s.variant) : gg_sk_slab_floats(s.variant)) + s.workers;
   if (s.ksplit <= 1) return 0;
   int64_t cols = 0;
   for (int gi = 0; gi < p->ngroups; ++gi) cols += p->g[gi].Ncol;
@@ -631,7 +685,7 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   int rc = geometry(p, h, w, &g);
   if (rc) return rc;
   const int64_t M = (int64_t)n * g.Qh * g.Qw;
-  const int64_t x_bytes = (int64_t)n * h * w * d.cin * 4;
+  const int64_t x_bytes = (int64_t)n * h * w * d.cin * (p->s3 ? 6 : 4);
   if (M > 0x7fffffffLL || x_bytes >= (1LL << 31))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: input tensor must be < 2 GiB (32-bit buffer offsets); split the batch");
   if (p2 && M * p2->d.cout >= (1LL << 32)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward_fused: output too large; split the batch");
@@ -641,7 +695,7 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: this call needs sntc_conv_workspace_bytes() of workspace "
                                     "(split-K slabs / stream-K hand-off)");
   const int v = sc.variant;
-  const int bm = gg_variant_bm(v), bn = gg_variant_bn(v);
+  const int bm = variant_bm(v), bn = variant_bn(v);
   GGArgs a{};
   a.ksplit = sc.ksplit;
   a.slab = static_cast<float*>(workspace);
@@ -657,12 +711,14 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   a.bf3 = p->bf3 ? 1 : 0;
   a.dma = p2 ? 0 : sc.deep ? 2 : plan_dma(p) ? 1 : 0;
   if (p2) { a.w2f = p2->w2f; a.bias2 = p2->bias; a.Cout2 = p2->d.cout; }
+  a.status = gg_status_word();
+  if (!a.status) return fail(SNTC_ERR_HIP, "sntc_conv_forward: the device tables of the current device are not initialised");
   a.sk = sc.sk ? 1 : 0;
   a.nworkers = sc.workers;
   a.units = sc.units;
   if (sc.sk) {
     a.sk_slab = static_cast<float*>(workspace);
-    a.sk_flags = reinterpret_cast<int*>(a.sk_slab + (size_t)sc.workers * gg_sk_slab_floats(v));
+    a.sk_flags = reinterpret_cast<int*>(a.sk_slab + (size_t)sc.workers * (v > kNumVariants ? bf3p_sk_slab_floats(v) : gg_sk_slab_floats(v)));
     a.slab = nullptr;
     SNTC_HIP(hipMemsetAsync(a.sk_flags, 0, sizeof(int) * sc.workers, (hipStream_t)stream));
   }
@@ -687,6 +743,10 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   }
   a.tps = tile0;
   a.ups = (int)unit0;
+  if (p->s3) {
+    a.order = p->dma == 0 ? 1 : 0;        // sntc_conv_plan_set_schedule's stage-path bit doubles as the unit-order A/B switch here
+    return bf3p_launch(v, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
+  }
   rc = gg_launch(v, p->vec, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
   if (rc || sc.sk || sc.ksplit <= 1) return rc;
   return gg_reduce_launch(a, (hipStream_t)stream);
@@ -724,4 +784,23 @@ extern "C" int sntc_conv_forward_fused(const sntc_conv_plan* p, const sntc_conv_
                                        void* stream) {
   if (const char* why = fused_pair_error(p, p2)) return fail(SNTC_ERR_UNSUPPORTED, why);
   return conv_forward_impl(p, p2, x, n, h, w, y, res, aux, workspace, workspace_bytes, stream);
+}
+
+// ---- stream-K health: a worker that waits in vain for its neighbour's hand-off flags the launch instead of
+// trapping; the host asks at a point where it synchronises anyway.
+extern "C" int sntc_conv_set_stream_k(int enabled) {
+  g_stream_k_enabled.store(enabled ? 1 : 0, std::memory_order_relaxed);
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_status(int* flags, void* stream) {
+  if (!flags) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_status: null argument");
+  int rc = gg_init();
+  if (rc) return rc;
+  int* word = gg_status_word();
+  hipStream_t s = (hipStream_t)stream;
+  SNTC_HIP(hipMemcpyAsync(flags, word, sizeof(int), hipMemcpyDeviceToHost, s));
+  SNTC_HIP(hipStreamSynchronize(s));
+  if (*flags) SNTC_HIP(hipMemsetAsync(word, 0, sizeof(int), s));
+  return SNTC_OK;
 }

@@ -31,6 +31,7 @@
 // Between tiles the next tile's first two stages are in flight while the current tile's epilogue runs.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "sntc_internal.h"
 
@@ -41,7 +42,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kOutOfRange = 0x80000000u;   // > any in-range offset: buffers are < 2 GiB (host check)
-constexpr int kSpinLimit = 1 << 22;             // bounded wait on a neighbour's hand-off (~seconds), then trap
+constexpr int kSpinLimit = 1 << 22;             // bounded wait on a neighbour's hand-off (~seconds), then the launch is flagged invalid
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -661,7 +662,14 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
         int spins = 0;
         while (__hip_atomic_load(a.sk_flags + P.consume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           __builtin_amdgcn_s_sleep(8);
-          if (++spins > kSpinLimit) __builtin_trap();      // a neighbour that never published: fail loudly, never hang
+          if (++spins > kSpinLimit) {
+            // a neighbour that never published (it cannot be co-resident: HIP promises neither residency nor dispatch
+            // order): never hang and never take the context down -- flag the launch as invalid and carry on with whatever
+            // the slab holds; the host reads the sticky word at its next synchronisation point (sntc_conv_status), raises,
+            // and can re-run on the static schedule (sntc_conv_set_stream_k(0))
+            __hip_atomic_fetch_or(fresh_args().status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1156,21 +1164,26 @@ static const void* variant_kernel(int v, bool vec, bool pro) {
   }
 }
 
-static thread_local int g_init_device = -1;
-static thread_local int g_resident[kNumVariants + 1][3];      // per (variant, {vec, vec+pro, gather}) workgroups per device
-static thread_local int g_num_cus = 0;
-static thread_local int g_resident_bf3[kNumVariants + 1];
-static thread_local int g_resident_dma[kNumVariants + 1];
-static thread_local int g_resident_deep[kNumVariants + 1];
-static thread_local int g_resident_fused = 0;
+// Residency tables, one per device, filled once per process (std::call_once): every thread and every plan sees the same
+// schedule whatever thread created the plan, and switching devices costs a table lookup.
+constexpr int kMaxDevices = 16;
+struct DeviceTables {
+  std::once_flag once;
+  int rc = SNTC_OK;
+  int num_cus = 0;
+  int resident[kNumVariants + 1][3] = {};      // per (variant, {vec, vec+pro, gather}) workgroups per device
+  int resident_bf3[kNumVariants + 1] = {};
+  int resident_dma[kNumVariants + 1] = {};
+  int resident_deep[kNumVariants + 1] = {};
+  int resident_fused = 0;
+  int* status = nullptr;                       // sticky status word (device memory)
+};
+static DeviceTables g_dev[kMaxDevices];
 
-int gg_init() {
-  int dev = 0;
-  SNTC_HIP(hipGetDevice(&dev));
-  if (g_init_device == dev) return SNTC_OK;
+static int fill_tables(DeviceTables& T, int dev) {
   hipDeviceProp_t prop;
   SNTC_HIP(hipGetDeviceProperties(&prop, dev));
-  g_num_cus = prop.multiProcessorCount;
+  T.num_cus = prop.multiProcessorCount;
   for (int v = 1; v <= kNumVariants; ++v) {
     for (int k = 0; k < 3; ++k) {
       const void* fn = variant_kernel(v, k < 2, k >= 1);
@@ -1180,7 +1193,7 @@ int gg_init() {
       // the API can answer one workgroup per CU high near an SGPR allocation edge (MI355X_MICROARCH.md, Residency):
       // stream-K needs every worker resident, so stay at or below 8 and keep the LDS bound exact
       per_cu = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(v))}));
-      g_resident[v][k] = per_cu * g_num_cus;
+      T.resident[v][k] = per_cu * T.num_cus;
     }
   }
   for (int v : {1, 2, 3, 4, 5, 8, 9}) {
@@ -1188,52 +1201,85 @@ int gg_init() {
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_dma(v)));
     int per_cu = 0;
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_dma(v)));
-    g_resident_dma[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_dma(v))})) * g_num_cus;
+    T.resident_dma[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_dma(v))})) * T.num_cus;
   }
   for (int v : {8}) {
     const void* fn = variant_kernel_deep(v);
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_deep(v)));
     int per_cu = 0;
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_deep(v)));
-    g_resident_deep[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_deep(v))})) * g_num_cus;
+    T.resident_deep[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_deep(v))})) * T.num_cus;
   }
   {
     const void* fn = kernel_fused();
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(3)));
     int per_cu = 0;
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes(3)));
-    g_resident_fused = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(3))})) * g_num_cus;
+    T.resident_fused = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(3))})) * T.num_cus;
   }
   for (int v : {2, 4}) {
     const void* fn = variant_kernel_bf3(v);
     SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_bf3(v)));
     int per_cu = 0;
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_bf3(v)));
-    g_resident_bf3[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_bf3(v))})) * g_num_cus;
+    T.resident_bf3[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_bf3(v))})) * T.num_cus;
   }
-  g_init_device = dev;
+  SNTC_HIP(hipMalloc(&T.status, sizeof(int)));
+  SNTC_HIP(hipMemset(T.status, 0, sizeof(int)));
   return SNTC_OK;
 }
 
+static DeviceTables* current_tables() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  DeviceTables& T = g_dev[dev];
+  std::call_once(T.once, [&] { T.rc = fill_tables(T, dev); });
+  return T.rc == SNTC_OK ? &T : nullptr;
+}
+
+int gg_init() {
+  int dev = 0;
+  SNTC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(SNTC_ERR_UNSUPPORTED, "device index beyond the residency tables");
+  DeviceTables& T = g_dev[dev];
+  std::call_once(T.once, [&] { T.rc = fill_tables(T, dev); });
+  return T.rc;
+}
+
 int gg_resident_blocks(int variant, bool vec, bool pro) {
-  if (variant < 1 || variant > kNumVariants || g_init_device < 0) return 0;
-  return g_resident[variant][!vec ? 2 : (pro ? 1 : 0)];
+  const DeviceTables* T = current_tables();
+  if (variant < 1 || variant > kNumVariants || !T) return 0;
+  return T->resident[variant][!vec ? 2 : (pro ? 1 : 0)];
 }
 
 int gg_resident_blocks_dma(int variant) {
-  return variant >= 1 && variant <= kNumVariants && variant_kernel_dma(variant) && g_init_device >= 0 ? g_resident_dma[variant] : 0;
+  const DeviceTables* T = current_tables();
+  return variant >= 1 && variant <= kNumVariants && variant_kernel_dma(variant) && T ? T->resident_dma[variant] : 0;
 }
 
 int gg_resident_blocks_deep(int variant) {
-  return variant >= 1 && variant <= kNumVariants && variant_kernel_deep(variant) && g_init_device >= 0 ? g_resident_deep[variant] : 0;
+  const DeviceTables* T = current_tables();
+  return variant >= 1 && variant <= kNumVariants && variant_kernel_deep(variant) && T ? T->resident_deep[variant] : 0;
 }
 
-int gg_num_cus() { return g_init_device >= 0 ? g_num_cus : 0; }
+int gg_num_cus() {
+  const DeviceTables* T = current_tables();
+  return T ? T->num_cus : 0;
+}
 
-int gg_resident_blocks_fused() { return g_init_device >= 0 ? g_resident_fused : 0; }
+int* gg_status_word() {
+  const DeviceTables* T = current_tables();
+  return T ? T->status : nullptr;
+}
+
+int gg_resident_blocks_fused() {
+  const DeviceTables* T = current_tables();
+  return T ? T->resident_fused : 0;
+}
 
 int gg_resident_blocks_bf3(int variant) {
-  return (variant == 2 || variant == 4) && g_init_device >= 0 ? g_resident_bf3[variant] : 0;
+  const DeviceTables* T = current_tables();
+  return (variant == 2 || variant == 4) && T ? T->resident_bf3[variant] : 0;
 }
 
 int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_t stream) {

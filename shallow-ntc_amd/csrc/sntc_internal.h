@@ -77,6 +77,8 @@ struct GGArgs {
   int tps, ups;        // tiles / units per row strip (all groups): tile order is strip-major, then group, then column tile
   float* sk_slab;      // [nworkers][256 threads * 16 TN floats], raw accumulators in register layout
   int* sk_flags;       // [nworkers], zeroed on the stream before the launch
+  int* status;         // sticky per-device status word (never NULL): bit 0 = a stream-K worker gave up waiting for its neighbour's
+                       // hand-off (the launch's results are invalid; sntc_conv_status reports and clears it)
   // Fused ResidualBlock tail (FUSE2 instance): after the 3x3 (this launch's groups, Cout = 96, bias / act above) the 1x1
   // 96 -> Cout2 = 192 with bias2, then `epi` with res / aux, into y [M][Cout2]
   const float* w2f;    // W2 in fragment order [2 halves][3 column tiles][12 k-quads pairs][64 lanes][4], or nullptr
@@ -84,6 +86,7 @@ struct GGArgs {
   int Cout2;
   int dma;             // 1: direct-to-LDS staging (buffer_load ... lds, four ring slots) where the instantiation exists
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
+  int order;           // bf3_gemm.hip stream-K unit order: 0 column tile outermost (default), 1 strip-major (as gather_gemm.hip)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
                        // 8 skip fragment reads, 16 skip the epilogue's stores, 32 its residual loads, 64 the MFMAs, 128 the fused
                        // ResidualBlock tail's second contraction -- to see what a launch waits on; results are meaningless with any bit set
@@ -102,10 +105,18 @@ int gg_init();   // sets the dynamic-LDS attribute on every instantiation (idemp
 int gg_resident_blocks(int variant, bool vec, bool pro);   // workgroups of this instantiation the device keeps resident
 int gg_resident_blocks_deep(int variant);                   // same for the deep-ring (8-slot) direct-to-LDS instances; 0 if none
 int gg_num_cus();
+int* gg_status_word();                                      // device pointer of the current device's sticky status word
 int gg_resident_blocks_dma(int variant);                    // same for the direct-to-LDS instantiations
 int gg_resident_blocks_fused();                             // the FUSE2 instance (variant 3)
 int gg_resident_blocks_bf3(int variant);                    // same for the bf16 x 3 instantiations (variants 2 and 4)
 size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off
+
+// ---- pre-split bf16 x 3 gather GEMM (bf3_gemm.hip): variants 11 (256 x 256) and 12 (256 x 128), 512 threads, one workgroup per CU
+int bf3p_variant_bm(int v);
+int bf3p_variant_bn(int v);
+size_t bf3p_sk_slab_floats(int v);
+int bf3p_init();
+int bf3p_launch(int variant, const GGArgs& args, int nblocks, hipStream_t stream);
 
 // ---- deep-factorized prior (entropy.hip, sga.hip) ----
 constexpr int kMaxW = 4;   // max hidden width

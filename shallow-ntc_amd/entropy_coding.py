@@ -9,7 +9,8 @@ Tables (host, float64, 16-bit precision: frequencies sum to 65536, every symbol 
     (mshyper/models.py:28-32; rounding the index is what TFC's compress() path does), pmf(v) = Phi((v+.5)/s) - Phi((v-.5)/s)
     on |v| <= L_k = the symbols with pmf >= 2^-17; rarer values are escaped.
   * z: one table per channel from the deep-factorized prior, pmf(v) = sigmoid(L(v+.5)) - sigmoid(L(v-.5)).
-Wire format v3 (little endian): b"SNTC" u16 version | u16 n | u32 H | u32 W | u16 C | u16 Cz | u16 hz | u16 wz | u16 h | u16 w |
+Wire format v3 (little endian): b"SNTC" u16 version (low byte 3; high byte = arithmetic of the transforms that rebuild mu / sigma:
+  0 fp32, 1 bf16x3 -- a decoder of the other arithmetic refuses the stream instead of decoding garbage) | u16 n | u32 H | u32 W | u16 C | u16 Cz | u16 hz | u16 wz | u16 h | u16 w |
   u16 segments_z | u16 segments_y | u8 lanes_z | u8 lanes_y | u32 len_words[n * segments_z] | u32 len_words[n * segments_y] |
   z payload | y payload; a stream (one per image and segment) = the lane states (8 .. 64 of them, fewer on short streams)
   + the interleaved 16-bit words (csrc/rans.hip).
@@ -32,6 +33,7 @@ PRECISION = 16
 TOTAL = 1 << PRECISION
 MAGIC = b"SNTC"
 VERSION = 3
+ARITH = {"fp32": 0, "bf16x3": 1}          # Model(precision=...): high byte of the version word
 SCALE_MIN, SCALE_MAX, NUM_SCALES = 0.11, 256.0, 64
 SCALE_FACTOR = (math.log(SCALE_MAX) - math.log(SCALE_MIN)) / (NUM_SCALES - 1.0)
 
@@ -249,7 +251,7 @@ class Codec:
             zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz, lz)
             yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables, sy, ly)
             zb, yb = zp.cpu().numpy().tobytes(), yp.cpu().numpy().tobytes()
-        head = MAGIC + struct.pack(self.HEAD, VERSION, n, H, W, y.shape[-1], z.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2],
+        head = MAGIC + struct.pack(self.HEAD, VERSION | (ARITH[m._precision] << 8), n, H, W, y.shape[-1], z.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2],
                                    sz, sy, lz, ly)
         return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
 
@@ -261,8 +263,13 @@ class Codec:
         if len(blob) < pos:
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
         ver, n, H, W, c, cz, hz, wz, h, w, sz, sy, lz, ly = struct.unpack_from(self.HEAD, blob, 4)
+        arith, ver = ver >> 8, ver & 0xff
         if ver != VERSION:
             raise capi.SntcError(capi.ERR_UNSUPPORTED, f"bitstream version {ver}")
+        if arith != ARITH[m._precision]:
+            names = {v: k for k, v in ARITH.items()}
+            raise capi.SntcError(capi.ERR_UNSUPPORTED, f"bitstream was written by a {names.get(arith, arith)!r} model, this model "
+                                 f"computes in {m._precision!r}: mu / sigma would not be reproduced bit for bit")
         # Nothing below trusts the header: every dimension is recomputed from (H, W) and THIS model, so a corrupt or crafted
         # blob cannot size an allocation or index a table-id tensor beyond what the model itself would produce.
         if not (1 <= n <= self.MAX_IMAGES and 1 <= H <= self.MAX_SIDE and 1 <= W <= self.MAX_SIDE):
@@ -292,5 +299,5 @@ class Codec:
             if tuple(hyper.shape) != (n, h, w, 2 * c):
                 raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents {(n, h, w, c)}")
             sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy, ly)
-            y_hat = ops.dequant_scale_normal(sym, hyper)
+            y_hat = ops.dequant_split3(sym, hyper) if m._synthesis.takes_s3(h, w) else ops.dequant_scale_normal(sym, hyper)
             return m._pixels(y_hat, (H, W))

@@ -93,7 +93,11 @@ class Model:
     def __init__(self, scheduled_num_steps=1500000, rd_lambda=0.01, offset_heuristic=True,
                  transform_config=EMPTY_DICT, optimizer_config=EMPTY_DICT,
                  latent_config=None, profile=False, device=None, prior_num_filters=(3, 3), seed=4321,
-                 quality_metrics=True):
+                 quality_metrics=True, precision="fp32"):
+        """``precision``: "fp32" (default: exact fp32 MFMA everywhere, the reference's arithmetic) or "bf16x3": the
+        convolutions that qualify (Cin % 16 == 0, at least one 256-row strip per image) run the split-precision contraction
+        on pre-split operands (csrc/bf3_gemm.hip; ~fp32 accuracy, not bit-identical to it).  An encoder and a decoder must
+        use the same precision: the bitstream header carries it."""
         capi.require_gpu()
         self._scheduled_num_steps = scheduled_num_steps
         self._rd_lambda = rd_lambda
@@ -107,6 +111,9 @@ class Model:
         self._transform_config = transform_config
         self._profile = profile
         self._prior_num_filters = tuple(prior_num_filters)
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16x3', not {precision!r}")
+        self._precision = precision
         self._seed = seed
         self._quality_metrics = quality_metrics     # MS-SSIM at eval (reference :321-331); LPIPS is not vendored
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -119,6 +126,7 @@ class Model:
     def _build_named(self, cfg, cin, seed_offset):
         cfg = dict(cfg)
         t = transform_builder.build(cfg.pop("cls"), **cfg)
+        t._precision = self._precision
         t._seed = self._seed + seed_offset
         t._cin = t._cin or cin
         return t
@@ -314,6 +322,7 @@ class Model:
             sse = ops.float_sse(x, recon)                                                         # unpad + 0-255 floats, unrounded
             rows = [bits_y if bits_z is None else bits_z, bits_y, sse]
             host = torch.stack(rows).cpu().numpy()
+            ops.check_conv_status()
         rd_loss, metrics = self._finish_metrics(x.shape, None if bits_z is None else host[0], host[1], host[2])
         metrics.record_image("reconstruction", recon)
         return rd_loss, metrics
@@ -337,6 +346,7 @@ class Model:
     def _finish_frame(self, pending):
         """Host side of a launched frame: one device -> host copy, then the reference's float32 metric arithmetic."""
         host = pending["dev"].cpu().numpy()
+        ops.check_conv_status()                      # the copy above synchronised the stream: a flagged stream-K launch raises here
         msssim = None
         if pending["quality"] is not None:
             sums, counts, single = pending["quality"]
@@ -468,6 +478,7 @@ class Model:
         if count == 1:
             return [self._finish_frame(pending)]
         host = pending["dev"].cpu().numpy()
+        ops.check_conv_status()
         msssim = None
         if pending["quality"] is not None:
             sums, counts, single = pending["quality"]
@@ -488,6 +499,7 @@ class Model:
             r = self._rate_and_reconstruction(self.infer_latent_rvs(x))
             sse, _ = ops.pixels_sse(x, r["recon"])
             host = torch.stack([r["bits_z"], r["bits_y"], sse.to(torch.float64)]).cpu().numpy()
+            ops.check_conv_status()
             msssim = self._msssim(x, r["recon"])
         out = []
         for i in range(x.shape[0]):
@@ -512,7 +524,10 @@ class Model:
         [n, H, W, 3] (and the per-image integer SSE against ``reference`` if given)."""
         with torch.cuda.device(self.device):
             hyper = self._hyper_synthesis(z_hat)
-            y_hat = ops.dequant_scale_normal(symbols, hyper)
+            if self._synthesis.takes_s3(symbols.shape[1], symbols.shape[2]):      # bf16x3: y_hat leaves the dequantisation pre-split
+                y_hat = ops.dequant_split3(symbols, hyper)
+            else:
+                y_hat = ops.dequant_scale_normal(symbols, hyper)
             return self._pixels(y_hat, image_hw, reference)
 
     def _pixels(self, y_hat, image_hw, reference=None):
@@ -594,6 +609,7 @@ class Model:
                 ops.adam_step(p, g, st["m"], st["v"], lr, t, self._optimizer_config.get("beta_1", 0.9),
                               self._optimizer_config.get("beta_2", 0.999), self._optimizer_config.get("epsilon", 1e-7))
             host = torch.stack([r["bits_z"], r["bits_y"], r["sse"]]).cpu().numpy()
+            ops.check_conv_status()
         _, metrics = self._finish_metrics(x.shape, host[0] if len(locs) == 2 else None, host[1], host[2])
         self._itinf_step += 1
         self.last_grads = tuple(grads)

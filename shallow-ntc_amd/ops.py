@@ -44,6 +44,37 @@ def _check_nhwc(x, c=None):
         raise ValueError(f"expected {c} channels, got {x.shape[-1]}")
 
 
+def _check_s3(x, c=None):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 6 and x.is_contiguous()
+            and tuple(x.shape[4:]) == (3, 16)):
+        raise ValueError("expected a contiguous bfloat16 CUDA tensor in format S3 [n, h, w, C / 16, 3, 16] (ops.split3), got "
+                         f"{type(x).__name__} {getattr(x, 'dtype', None)} {tuple(getattr(x, 'shape', ()))}")
+    if c is not None and x.shape[3] * 16 != c:
+        raise ValueError(f"expected {c} channels, got {x.shape[3] * 16}")
+
+
+def split3(x):
+    """fp32 NHWC -> format S3 (include/sntc.h): per pixel and 16-channel slab [hi | mid | lo] bfloat16, x = hi + mid + lo."""
+    _check_nhwc(x)
+    n, h, w, c = x.shape
+    if c % 16:
+        raise ValueError(f"format S3 needs a channel count divisible by 16, got {c}")
+    out = torch.empty((n, h, w, c // 16, 3, 16), dtype=torch.bfloat16, device=x.device)
+    capi.call("sntc_split3", _ptr(x), n * h * w, c, _ptr(out), _stream())
+    return out
+
+
+def dequant_split3(symbols, hyper, want_float=False):
+    """y_hat = symbols + mu in format S3 (the decoder's dequantisation fused with the split); also fp32 if asked."""
+    c = symbols.shape[-1]
+    _check_nhwc(hyper, 2 * c)
+    n, h, w, _ = symbols.shape
+    out = torch.empty((n, h, w, c // 16, 3, 16), dtype=torch.bfloat16, device=symbols.device)
+    y_hat = torch.empty(symbols.shape, dtype=torch.float32, device=symbols.device) if want_float else None
+    capi.call("sntc_dequant_split3", _ptr(symbols), _ptr(hyper), n * h * w, c, _ptr(out), _ptr(y_hat), _stream())
+    return (out, y_hat) if want_float else out
+
+
 class PlanGroup:
     """Plans re-packed together by one launch (sntc_plan_group): ``entries`` = [(ConvPlan, weight tensor, bias tensor or None)].
     The tensors must stay where they are (views of the trainer's flat store); ``update()`` re-reads them."""
@@ -97,8 +128,9 @@ class ConvPlan:
         if BF16X3_EXPERIMENT and cin % 16 == 0 and prologue == capi.PRO_NONE:
             bf16x3 = True
         self.bf16x3 = bool(bf16x3)
+        self.s3 = bf16x3 == "presplit"                  # the input arrives in format S3 (ops.split3): csrc/bf3_gemm.hip
         desc.reserved[0] = 1 if kernel_io_swapped else 0
-        desc.reserved[1] = 1 if bf16x3 else 0           # split-precision experiment, never a default
+        desc.reserved[1] = 2 if self.s3 else (1 if bf16x3 else 0)       # split precision, opt-in, never a default
         w = w.contiguous()
         b = None if bias is None else bias.contiguous()
         self._h = C.c_void_p()
@@ -178,14 +210,17 @@ class ConvPlan:
         return v.value, nb.value
 
     def __call__(self, x, res=None, aux=None, out=None):
-        _check_nhwc(x, self.cin)
-        n, h, w, _ = x.shape
+        if self.s3:
+            _check_s3(x, self.cin)
+        else:
+            _check_nhwc(x, self.cin)
+        n, h, w = x.shape[:3]
         ho, wo = self.out_hw(h, w)
         y = out if out is not None else torch.empty((n, ho, wo, self.cout), dtype=torch.float32, device=x.device)
         for t in (res, aux):
             if t is not None and tuple(t.shape) != tuple(y.shape):
                 raise ValueError(f"epilogue operand shape {tuple(t.shape)} != output shape {tuple(y.shape)}")
-        if x.numel() * 4 >= MAX_INPUT_BYTES and n > 1:
+        if x.numel() * x.element_size() >= MAX_INPUT_BYTES and n > 1:
             # the kernel addresses its input with 32-bit buffer offsets: split the batch (images are independent)
             half = n // 2
             r0 = None if res is None else res[:half]
@@ -208,6 +243,23 @@ class ConvPlan:
             prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 16 == 0,
                              kind=self.kind, k=self.k[0], s=self.stride, cin=self.cin, cout=self.cout, n=n, h=h, w=w))
         return y
+
+
+def check_conv_status():
+    """Call where the host synchronises anyway: raises if a stream-K launch since the last check gave up waiting for a
+    neighbour's hand-off (an oversubscribed device; include/sntc.h "Stream-K health").  The schedule is switched to the
+    static one for the rest of the process, so the caller can simply run the step again."""
+    flags = C.c_int(0)
+    capi.call("sntc_conv_status", C.byref(flags), _stream())
+    if flags.value:
+        capi.call("sntc_conv_set_stream_k", 0)
+        raise capi.SntcError(capi.ERR_HIP, "a stream-K hand-off timed out (the device is shared with other streams / processes): "
+                                           "the results since the last check are invalid; stream-K is now off, run the step again")
+
+
+def set_stream_k(enabled):
+    """Process-wide default of the persistent stream-K schedule (bit-identical results either way)."""
+    capi.call("sntc_conv_set_stream_k", int(bool(enabled)))
 
 
 def gdn_small(x, beta, gamma, inverse=False, alpha=1, epsilon=1.0):

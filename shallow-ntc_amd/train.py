@@ -681,6 +681,7 @@ class Trainer:
             clip = m._optimizer_config.get("global_clipnorm")
             # ONE device -> host copy of everything the step's control flow needs, BEFORE any state is touched
             host = torch.stack([out["bits_z"], out["bits_y"], out["sse"]]).cpu().numpy()
+            ops.check_conv_status()              # a flagged stream-K launch raises before the optimizer touches anything
             norm = math.sqrt(float(ops.sumsq(self.store.grad).item())) * inv_world
             n, h, w, c = x.shape
             bpp = float(host[0].mean() / (h * w) + host[1].mean() / (h * w))

@@ -234,6 +234,19 @@ def test_rdft_basis_is_a_parseval_frame_and_round_trips_kernels():
     assert (np.abs(r) > 1e-5).sum() == 1 and abs(np.abs(r).max() - np.sqrt(25 / 2)) < 1e-4
     with pytest.raises(ValueError):
         tc.rdft_to_kernel(np.zeros((25, 12), np.float32), (5, 5), 3, 4)          # square layout: not TFC's frame
+    # the two published-definition readings of the column order are permutations of each other (same frame, same shape):
+    # nothing but a TensorFlow-written bundle can tell them apart, which is why import / export warn (next test)
+    for shape in ((5, 5), (9, 9)):
+        a, b = tc.irdft_matrix(shape, "real_then_imag"), tc.irdft_matrix(shape, "interleaved")
+        assert a.shape == b.shape and not np.allclose(a, b)
+        np.testing.assert_allclose(a @ a.T, b @ b.T, atol=1e-12)
+        half = shape[1] // 2 + 1
+        perm = [(i // half) * 2 * half + (i % half) for i in range(shape[0] * half)]
+        perm += [p + half for p in perm]
+        np.testing.assert_allclose(a, b[:, perm], atol=0)
+    assert tc.RDFT_LAYOUT in tc.RDFT_LAYOUTS
+    with pytest.raises(ValueError):
+        tc.irdft_matrix((5, 5), "columns")
 
 
 @pytest.mark.parametrize("which", ["mbt2018", "bls2017"])
@@ -259,12 +272,15 @@ def test_signal_conv_checkpoints_round_trip(which, tmp_path):
             w[k] = (0.1 * rng.random(w[k].shape)).astype(np.float32)
         elif k.endswith("/bias"):
             w[k] = rng.standard_normal(w[k].shape).astype(np.float32)
-    prefix = tc.save_reference_checkpoint(tmp_path / "ckpt-7", w, tconf, step=7)
+    tc._rdft_warned.clear()
+    with pytest.warns(RuntimeWarning, match="NOT been verified against a TensorFlow-written bundle"):     # loud, once per direction
+        prefix = tc.save_reference_checkpoint(tmp_path / "ckpt-7", w, tconf, step=7)
     raw = tc.read_bundle(prefix)
     rdft_keys = [k for k in raw if "/rdft/" in k]
     assert len(rdft_keys) == sum(1 for k in w if k.endswith("/kernel") and k.split("/")[0] in ("analysis", "synthesis"))
     assert all(raw[k].shape[0] in (30, 90) for k in rdft_keys)          # 5x5 -> 2*5*3 rows, 9x9 -> 2*9*5 rows
-    got = tc.load_reference_checkpoint(prefix, tconf)
+    with pytest.warns(RuntimeWarning, match="import of tfc.SignalConv2D kernels"):
+        got = tc.load_reference_checkpoint(prefix, tconf)
     assert set(got) == set(w)
     for k in w:
         np.testing.assert_allclose(got[k], w[k], rtol=2e-6, atol=2e-6, err_msg=k)

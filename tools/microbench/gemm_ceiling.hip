@@ -154,6 +154,142 @@ __global__ void __launch_bounds__(256, 2) loop_bf3(const float* __restrict__ src
   if (s == 12345.678f) out[0] = s;
 }
 
+// The bf16 x 3 loop as a kernel would run it on PRE-SPLIT operands (activations stored by their producer as three bf16 planes,
+// 96 B per pixel and 16-channel slab, like the packed weights): stages go global -> LDS by direct-to-LDS loads (no staging
+// registers, no ds_write, no VALU), row-major [row][96 B] LDS image with the two 16-B halves of a plane swapped on rows
+// 8..15 (mod 16) -- applied on the SOURCE side, the DMA destination is linear -- so that fragment ds_read_b128 are
+// conflict-free; three ring slots, fragments double-buffered: in step j the loads of stage j+3 go into the slot stage j left,
+// stage j+1's fragments are read while stage j multiplies, and the step ends once stage j+2 has landed.
+template <int WM, int WN, int TM, int TN, bool DBUF>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) loop_bf3_dma(const float* __restrict__ src, float* out, int stages,
+                                                                                  unsigned src_bytes, unsigned row_stride) {
+  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, ROWS = BM + BN, SLOT = ROWS * 96;
+  constexpr int CH = (ROWS * 6 + NT - 1) / NT;               // 16-B chunks per thread and stage
+  extern __shared__ __attribute__((aligned(16))) char ringb[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, 0x00020000);
+  // row_stride == 0: the blocks form a GEMM grid (5 column tiles wide, XCD-aware: blocks b and b + 8 share an XCD and work on
+  // neighbouring tiles), A rows of 2880 B (480 channels, pre-split) shared by a strip's column tiles, B rows of 25920 B (K = 4320)
+  // shared by every strip -- the L2 reuse of a real layer.  Otherwise every block streams private rows `row_stride` apart.
+  const bool gemm = row_stride == 0;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_x = (gridDim.x + 7) >> 3;
+  const int nt = idx % 5, mt = xcd * ((per_x + 4) / 5) + idx / 5;
+  const unsigned strideA = gemm ? 2880u : row_stride, strideB = gemm ? 25920u : row_stride;
+  const unsigned baseB = gemm ? (96u << 20) : 0u;
+  unsigned off[CH];
+  bool isB[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int q = i * NT + tid, row = q / 6, part = q % 6, p = part >> 1, hs = (part & 1) ^ ((row >> 3) & 1);
+    isB[i] = row >= BM;
+    unsigned long long o;
+    if (!gemm) o = (unsigned long long)(blockIdx.x * ROWS + row) * row_stride;
+    else o = isB[i] ? baseB + (unsigned long long)(nt * BN + row - BM) * strideB : (unsigned long long)(mt * BM + row) * strideA;
+    off[i] = (unsigned)(o & (src_bytes - 1)) + p * 32 + hs * 16;
+  }
+  unsigned slabA = 0, slabB = 0;
+  auto issue = [&](int slot) {
+    char* base = ringb + slot * SLOT + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if ((ROWS * 6) % NT == 0 || (i * NT + wave * 64) < ROWS * 6)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + i * NT * 16), 16, (int)((off[i] + (isB[i] ? slabB : slabA)) & (src_bytes - 1)), 0, 0, 0);
+    slabA += 96u;
+    if (slabA + 96u > strideA) slabA = 0;
+    slabB += 96u;
+    if (slabB + 96u > strideB) slabB = 0;
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  struct Fr { bf16x8 a[3][TM], b[3][TN]; };
+  Fr F0, F1;
+  const int hoff = (h ^ ((l31 >> 3) & 1)) << 4;
+  auto rd = [&](Fr& F, int slot) {
+    const char* base = ringb + slot * SLOT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) F.a[p][i] = *reinterpret_cast<const bf16x8*>(base + (wm * TM * 32 + i * 32 + l31) * 96 + p * 32 + hoff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) F.b[p][j] = *reinterpret_cast<const bf16x8*>(base + (BM + wn * TN * 32 + j * 32 + l31) * 96 + p * 32 + hoff);
+    }
+  };
+  auto mm = [&](const Fr& F) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[PA[t]][i], F.b[PB[t]][j], acc[i][j], 0, 0, 0);
+  };
+  // my loads per stage (the last chunk round may not include this wave)
+  issue(0); issue(1); issue(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  rd(F0, 0);
+  int s0 = 0, s1 = 1;
+  auto step = [&](Fr& Fc, Fr& Fn) {
+    issue(s0);                        // stage j+3 into the slot whose fragments (stage j) are already in registers
+    if (DBUF) {
+      rd(Fn, s1);
+      mm(Fc);
+    } else {
+      mm(Fc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // stage j+2 (issued in the previous step) must have landed: leave only this step's loads in flight
+    if ((ROWS * 6) % NT == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH - 1) : "memory");     // conservative for the waves that issue CH
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!DBUF) rd(Fn, s1);
+    s0 = s1; s1 = s1 == 2 ? 0 : s1 + 1;
+  };
+  for (int st = 0; st < stages; st += 2) {
+    step(F0, DBUF ? F1 : F0);
+    step(DBUF ? F1 : F0, F0);
+  }
+  float s = 0;
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <class K>
+static void run_t(const char* label, K kern, int threads, int blocks, size_t lds, const float* src, float* out, unsigned src_bytes,
+                  double flop_per_stage_block, unsigned row_stride) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int stages = 20000;
+  float best = 1e30f, sum = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, src, out, rep == 0 ? 2000 : stages, src_bytes, row_stride);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep) { best = ms < best ? ms : best; sum += ms; }
+  }
+  hipError_t err = hipGetLastError();
+  const double tf = flop_per_stage_block * blocks * stages / (sum / 3) / 1e9;
+  printf("%-66s mean %.2f ms  %.1f TFLOP/s-equivalent = %.3f of 157.3 (best %.1f) %s\n", label, sum / 3, tf, tf / 157.3,
+         flop_per_stage_block * blocks * stages / best / 1e9, err == hipSuccess ? "" : hipGetErrorString(err));
+}
+
 template <class K>
 static void run(const char* label, K kern, size_t lds, const float* src, float* out, unsigned src_bytes, double flop_per_stage_block, unsigned row_stride = 1920) {
   hipEvent_t e0, e1;
@@ -198,8 +334,23 @@ int main() {
   run("  the same, gathered 64-B row slabs, 1 GiB, stride 1920", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 1920);
   run("  the same, gathered 64-B row slabs, 1 GiB, stride 768", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 768);
   run("  the same, gathered 64-B row slabs, 1 GiB, stride 384", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 384);
+  run("  the same, gathered 64-B row slabs, 1 GiB, stride 5120", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 5120);
+  run("  the same, gathered 64-B row slabs, 16 MiB, stride 5120", (loop_f32<3, 1>), lds, src, out, src_bytes, f, 5120);
+  run("  the same, gathered 64-B row slabs, 1 GiB, stride 17280", (loop_f32<3, 1>), lds, src, out, big_bytes, f, 17280);
+  run("  the same, gathered 64-B row slabs, 16 MiB, stride 4096", (loop_f32<3, 1>), lds, src, out, src_bytes, f, 4096);
   run("bf16x3 random, registers only (mode 8)", loop_bf3<8>, lds3, src, out, src_bytes, f);
   run("bf16x3 random, LDS fragment reads (mode 0)", loop_bf3<0>, lds3, src, out, src_bytes, f);
   run("bf16x3 random, fragment reads + barrier per stage (mode 1)", loop_bf3<1>, lds3, src, out, src_bytes, f);
+  // pre-split operands + direct-to-LDS staging: activations rows of 480 channels (2880 B), 1 GiB footprint
+  run_t("bf16x3 DMA 128x128 / 4 waves (64x64), frag dbuf, 2 WG/CU", (loop_bf3_dma<2, 2, 2, 2, true>), 256, 512, 3 * 256 * 96, src, out, big_bytes, 2.0 * 128 * 128 * 16, 2880);
+  run_t("bf16x3 DMA 128x128 / 4 waves (64x64), single frag, 2 WG/CU", (loop_bf3_dma<2, 2, 2, 2, false>), 256, 512, 3 * 256 * 96, src, out, big_bytes, 2.0 * 128 * 128 * 16, 2880);
+  run_t("bf16x3 DMA 256x128 / 8 waves (64x64), frag dbuf, 1 WG/CU", (loop_bf3_dma<4, 2, 2, 2, true>), 512, 256, 3 * 384 * 96, src, out, big_bytes, 2.0 * 256 * 128 * 16, 2880);
+  run_t("bf16x3 DMA 256x256 / 8 waves (64x128), single frag, 1 WG/CU", (loop_bf3_dma<4, 2, 2, 4, false>), 512, 256, 3 * 512 * 96, src, out, big_bytes, 2.0 * 256 * 256 * 16, 2880);
+  run_t("bf16x3 DMA 128x256 / 4 waves (64x128), single frag, 1-2 WG/CU", (loop_bf3_dma<2, 2, 2, 4, false>), 256, 512, 3 * 384 * 96, src, out, big_bytes, 2.0 * 128 * 256 * 16, 2880);
+  run_t("bf16x3 DMA 128x128, 16 MiB source", (loop_bf3_dma<2, 2, 2, 2, true>), 256, 512, 3 * 256 * 96, src, out, src_bytes, 2.0 * 128 * 128 * 16, 2880);
+  run_t("bf16x3 DMA 128x128 / 4 waves, GEMM-grid reuse", (loop_bf3_dma<2, 2, 2, 2, true>), 256, 512, 3 * 256 * 96, src, out, big_bytes, 2.0 * 128 * 128 * 16, 0);
+  run_t("bf16x3 DMA 256x128 / 8 waves, GEMM-grid reuse", (loop_bf3_dma<4, 2, 2, 2, true>), 512, 256, 3 * 384 * 96, src, out, big_bytes, 2.0 * 256 * 128 * 16, 0);
+  run_t("bf16x3 DMA 256x256 / 8 waves (64x128), GEMM-grid reuse", (loop_bf3_dma<4, 2, 2, 4, false>), 512, 256, 3 * 512 * 96, src, out, big_bytes, 2.0 * 256 * 256 * 16, 0);
+  run_t("bf16x3 DMA 128x256 / 4 waves (64x128), GEMM-grid reuse", (loop_bf3_dma<2, 2, 2, 4, false>), 256, 256, 3 * 384 * 96, src, out, big_bytes, 2.0 * 128 * 256 * 16, 0);
   return 0;
 }

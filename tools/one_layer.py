@@ -61,34 +61,49 @@ res = torch.randn((args.n, ho, wo, args.cout), device=dev, generator=g) if args.
 y = torch.empty((args.n, ho, wo, args.cout), device=dev)
 flops = plans[variants[0]].flops(args.n, h, w)
 times = {v: [] for v in variants}
-for rep in range(args.reps + 3):
+BURST = 6     # launches per measurement, back to back: a lone launch from an idle stream is timed with the host's own latency in it
+
+
+def timed_burst(fn):
+    fn()                                   # the burst's first launch hides the host latency of the rest
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(BURST):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / BURST
+
+
+for rep in range(args.reps + 2):
     for v in variants:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        plans[v](x, res=res, out=y)
-        e1.record()
-        torch.cuda.synchronize()
-        if rep >= 3:
-            times[v].append(e0.elapsed_time(e1))
+        ms = timed_burst(lambda: plans[v](x, res=res, out=y))
+        if rep >= 2:
+            times[v].append(ms)
 if args.bf16x3:
-    p3 = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE, bf16x3=True)
-    y3 = torch.empty_like(y)
     ref = plans[variants[0]](x, res=res).clone()
+    y3 = torch.empty_like(y)
+    p3 = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE, bf16x3=True)
     for v3 in (2, 4):
         p3.set_tile(v3)
-        ts = []
-        for rep in range(args.reps + 3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            p3(x, res=res, out=y3)
-            e1.record()
-            torch.cuda.synchronize()
-            if rep >= 3:
-                ts.append(e0.elapsed_time(e1))
+        ts = [timed_burst(lambda: p3(x, res=res, out=y3)) for _ in range(args.reps)]
         err = float((y3 - ref).abs().max() / ref.abs().max())
         vv, nb = p3.launch_info(args.n, h, w)
-        print(f"bf16x3 variant {vv} blocks {nb}: median {np.median(ts):.4f} ms  {flops / np.median(ts) / 1e9:.1f} TFLOP/s-equivalent; "
+        print(f"bf16x3 (split while staging) variant {vv} blocks {nb}: median {np.median(ts):.4f} ms  {flops / np.median(ts) / 1e9:.1f} TFLOP/s-equivalent; "
               f"max |bf16x3 - fp32| / max |fp32| = {err:.2e}")
+    ps = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE, bf16x3="presplit")
+    xs = ops.split3(x)
+    for v3 in (11, 12, 13, 14):
+        ps.set_tile(v3)
+        for static, order in ((False, None), (True, None)):
+            ps.set_stream_k(not static, dma=order)
+            ts = [timed_burst(lambda: ps(xs, res=res, out=y3)) for _ in range(args.reps)]
+            err = float((y3 - ref).abs().max() / ref.abs().max())
+            vv, nb = ps.launch_info(args.n, h, w)
+            print(f"bf16x3 pre-split variant {vv} {'static ' if static else 'stream-K col-major' if order is None else 'stream-K strip-major'} blocks {nb}: median {np.median(ts):.4f} ms  "
+                  f"{flops / np.median(ts) / 1e9:.1f} TFLOP/s-equivalent; max |bf16x3 - fp32| / max |fp32| = {err:.2e}")
+    ts = [timed_burst(lambda: ops.split3(x)) for _ in range(args.reps)]
+    print(f"split3 of the input: median {np.median(ts):.4f} ms ({x.numel() * 10 / np.median(ts) / 1e6:.0f} GB/s)")
 for v in variants:
     t = np.array(times[v])
     vv, nb = plans[v].launch_info(args.n, h, w)
