@@ -237,6 +237,53 @@ def loss_and_grads(transform_config, params, x, noise_z, noise_y, rd_lambda, num
                 grads={k: (np.zeros(tuple(leaves[k].shape)) if g is None else g.numpy()) for k, g in zip(leaves, grads)})
 
 
+
+# ---- the SGA objective (itinf_train_step's loss, mshyper/models.py:260-268,285-291,397-404) -------------------------------
+def sga_round(mu, tau, gumbel, offset=None, epsilon=1e-5):
+    """common/latent_rvs_utils.py:8-48 in float64 autograd form; ``gumbel`` [..., 2] is the (fixed) Gumbel noise of the
+    RelaxedOneHotCategorical sample: w = softmax((logits + g) / tau), out = w0 floor(mu) + w1 ceil(mu)."""
+    if offset is not None:
+        return sga_round(mu - offset, tau, gumbel, None, epsilon) + offset
+    fl, ce = torch.floor(mu).detach(), torch.ceil(mu).detach()
+    l0 = -torch.atanh(torch.clamp(mu - fl, -1 + epsilon, 1 - epsilon)) / tau
+    l1 = -torch.atanh(torch.clamp(ce - mu, -1 + epsilon, 1 - epsilon)) / tau
+    w = torch.softmax(torch.stack([(l0 + gumbel[..., 0]) / tau, (l1 + gumbel[..., 1]) / tau], dim=-1), dim=-1)
+    return w[..., 0] * fl + w[..., 1] * ce
+
+
+def sga_loss_and_grads(transform_config, params, x, z_loc, y_loc, tau, gumbel_z, gumbel_y, rd_lambda, num_filters=(3, 3)):
+    """loss = bpp + lambda * MSE(0-255 floats, unrounded) of frame_loss_given_latent_rvs(training=True) under the 'sga' method
+    with the Gumbel noise held fixed, and d loss / d (z_loc, y_loc) by float64 autograd -- the two tensors
+    itinf_train_step differentiates with respect to (mshyper/models.py:397-399).  Latents NHWC, noise NHWC + [2]."""
+    eff = {k: torch.tensor(np.asarray(v, np.float64)) for k, v in params.items()}
+    z = torch.tensor(np.asarray(z_loc, np.float64), requires_grad=True)
+    y = torch.tensor(np.asarray(y_loc, np.float64), requires_grad=True)
+    gz, gy = torch.tensor(np.asarray(gumbel_z, np.float64)), torch.tensor(np.asarray(gumbel_y, np.float64))
+    xt = as_input(x)
+    n, _, h, w = xt.shape
+    b = y.shape[-1]
+    hs = dict(transform_config.get("hyper_synthesis", dict(cls="HyperSynthesis", bottleneck_size=b)))
+    sy = dict(transform_config["synthesis"])
+    hyper_synthesis = T.build(hs.pop("cls"), cin=z.shape[-1], **hs)
+    synthesis = T.build(sy.pop("cls"), cin=b, **sy)
+    nl = len(num_filters) + 1
+    mats = [eff[f"prior/matrix_{k}"] for k in range(nl)]
+    biases = [eff[f"prior/bias_{k}"] for k in range(nl)]
+    factors = [eff[f"prior/factor_{k}"] for k in range(nl - 1)]
+    z_t = sga_round(z, tau, gz)                                                        # offset 0
+    bits_z = noisy_deep_factorized_bits(z_t, mats, biases, factors).sum(dim=(1, 2, 3))
+    hyper = hyper_synthesis(T.sub_params(eff, "hyper_synthesis/"), z_t.permute(0, 3, 1, 2), be=_SELF)
+    mu, raw = hyper[:, :b].permute(0, 2, 3, 1), hyper[:, b:].permute(0, 2, 3, 1)
+    y_t = sga_round(y, tau, gy, offset=mu)
+    bits_y = noisy_normal_bits(y_t - mu, raw).sum(dim=(1, 2, 3))
+    recon = synthesis(T.sub_params(eff, "synthesis/"), y_t.permute(0, 3, 1, 2), be=_SELF)[:, :, :h, :w]
+    bpp = bits_z.mean() / (h * w) + bits_y.mean() / (h * w)
+    mse = ((255.0 * (xt - recon)) ** 2).mean(dim=(1, 2, 3)).mean()
+    loss = bpp + rd_lambda * mse
+    g_z, g_y = torch.autograd.grad(loss, [z, y])
+    return dict(loss=float(loss.detach()), bpp=float(bpp.detach()), mse=float(mse.detach()), g_z=g_z.numpy(), g_y=g_y.numpy(),
+                bits_z=bits_z.detach().numpy(), bits_y=bits_y.detach().numpy())
+
 # ---- optimizer arithmetic (tf.keras.optimizers.Adam + global_clipnorm, common/schedule.py:155-176) --------
 def adam_update(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-7):
     m = beta1 * m + (1 - beta1) * grad

@@ -214,3 +214,48 @@ def test_out_layer_adjoint_stream_kernel(ch, n, hh, wh, dev):
     ref = h.grad.permute(0, 2, 3, 1).numpy()
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() < 2e-5 * scale and np.abs(via_gemm - ref).max() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("name", ["two_layer_syn2", "jpegl"])
+def test_sga_gradients_at_full_width_against_float64_autograd(name, dev):
+    """BASELINE configs[4] / [3] at their REAL widths (320-channel latents, 320 -> 320 -> 480 -> 640 hyper-synthesis, 13x13 / 8
+    two-layer or 18x18 / 16 JPEG-like synthesis), one 128 x 128 image: the loss and EVERY component of d loss / d z_loc and
+    d loss / d y_loc (1,280 + 20,480 values) against float64 autograd of the oracle loss under the same Gumbel noise -- not a
+    few finite-difference samples on a reduced net."""
+    from oracle import train_ref
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    cfg = configs.CONFIGS[name](rd_lambda=0.02)
+    cfg.update(configs.itinf())
+    model = Model(device=dev, quality_metrics=False, **cfg)
+    w = dict(model.get_weights())
+    rng = np.random.default_rng(8)
+    for k in list(w):                                        # every path carries gradient: biases, spread scales, live prior
+        if k.endswith("/bias"):
+            w[k] = (0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif k.endswith("/beta"):
+            w[k] = (1 + 0.5 * rng.random(w[k].shape)).astype(np.float32)
+        elif k.startswith("prior/"):
+            w[k] = (w[k] + 0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    b = w["hyper_synthesis/layer_2/bias"].copy()
+    b[320:] = rng.uniform(-1, 2.5, size=320)
+    w["hyper_synthesis/layer_2/bias"] = b.astype(np.float32)
+    model.set_weights(w)
+    x = data_lib.normalize_image(data_lib.synthetic_images(1, 128, 128, seed=3))
+    z0 = (2.0 * rng.standard_normal((1, 2, 2, 320))).astype(np.float32)
+    y0 = (3.0 * rng.standard_normal((1, 8, 8, 320))).astype(np.float32)
+    gz, gy = gumbel(rng, z0.shape), gumbel(rng, y0.shape)
+    tau, lam = 0.4, 0.02
+    model.initialize_itinf(x)
+    r = model._sga.loss_and_grads(t(x, dev), t(z0, dev), t(y0, dev), tau, lam, noise_z=t(gz, dev), noise_y=t(gy, dev))
+    ref = train_ref.sga_loss_and_grads(cfg["transform_config"], w, x, z0, y0, tau, gz, gy, lam)
+    bpp = (r["bits_z"].cpu().numpy().mean() + r["bits_y"].cpu().numpy().mean()) / (128 * 128)
+    mse = (r["sse"].cpu().numpy() / (128 * 128 * 3)).mean()
+    assert abs(bpp - ref["bpp"]) < 2e-5 * ref["bpp"] and abs(mse - ref["mse"]) < 2e-5 * ref["mse"], (bpp, ref["bpp"], mse, ref["mse"])
+    for got, want, label in ((r["g_z"].cpu().numpy(), ref["g_z"], "z"), (r["g_y"].cpu().numpy(), ref["g_y"], "y")):
+        assert np.abs(want).max() > 0
+        # float32 kernels against float64 autograd: relative to the tensor's scale; the steep SGA derivative near integers
+        # amplifies float32 rounding of (mu - floor mu), hence the per-element relative term
+        err = np.abs(got - want)
+        assert (err <= 2e-4 * np.abs(want) + 2e-5 * np.abs(want).max()).all(), (label, float(err.max()), float(np.abs(want).max()))

@@ -165,3 +165,35 @@ def test_float64_library_backend_equals_the_tap_loop_oracle():
     s2 = a["symbols_y"].copy()
     s2[0, 0, 0, 0] += 1
     assert abs(m.frame_loss(p, x, m.infer_latents(p, x), force_symbols=s2)["bpp"] - a["bpp"]) > 1e-6
+
+
+def test_sga_autograd_oracle_equals_the_numpy_oracle():
+    """oracle/train_ref.sga_loss_and_grads (float64 autograd of the SGA objective, the reference of the full-width gradient
+    test) gives the NumPy oracle's loss value, and its gradients equal central finite differences of that oracle loss."""
+    from oracle import model_np, train_ref
+    tc = dict(analysis=dict(cls="ElicAnalysis", channels=(16, 16, 16, 32)),
+              synthesis=dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5),
+                             activation_type="igdn", res_type="conv"))
+    m = model_np.Model(tc, rd_lambda=0.02)
+    w = m.init_params(3)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.5, 0.5, (1, 64, 64, 3))
+    z0, y0 = 2 * rng.standard_normal((1, 1, 1, 32)), 3 * rng.standard_normal((1, 4, 4, 32))
+    g = lambda s: -np.log(-np.log(rng.uniform(1e-6, 1 - 1e-6, size=s + (2,))))
+    gz, gy = g(z0.shape), g(y0.shape)
+    sga = dict(tau=0.4, gumbel_z=gz, gumbel_y=gy)
+    a = m.frame_loss(w, x, (z0, y0), sga=sga)
+    b = train_ref.sga_loss_and_grads(tc, w, x, z0, y0, 0.4, gz, gy, 0.02)
+    assert abs(a["rd_loss"] - b["loss"]) < 1e-9 * abs(a["rd_loss"]) and abs(a["bpp"] - b["bpp"]) < 1e-9 * a["bpp"]
+    h = 1e-5
+    for idx in [(0, 1, 2, 3), (0, 3, 0, 17), (0, 0, 3, 31)]:
+        yp, ym = y0.copy(), y0.copy()
+        yp[idx] += h
+        ym[idx] -= h
+        fd = (m.frame_loss(w, x, (z0, yp), sga=sga)["rd_loss"] - m.frame_loss(w, x, (z0, ym), sga=sga)["rd_loss"]) / (2 * h)
+        assert abs(fd - b["g_y"][idx]) <= 1e-5 * abs(fd) + 1e-9, (idx, fd, b["g_y"][idx])
+    zp, zm = z0.copy(), z0.copy()
+    zp[0, 0, 0, 5] += h
+    zm[0, 0, 0, 5] -= h
+    fd = (m.frame_loss(w, x, (zp, y0), sga=sga)["rd_loss"] - m.frame_loss(w, x, (zm, y0), sga=sga)["rd_loss"]) / (2 * h)
+    assert abs(fd - b["g_z"][0, 0, 0, 5]) <= 1e-5 * abs(fd) + 1e-9
