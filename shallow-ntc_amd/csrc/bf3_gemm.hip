@@ -76,10 +76,9 @@ struct Piece {
 
 }  // namespace
 
-// BAUX: cache policy of the WEIGHT loads (buffer_load aux bits: 0 default, 2 = nt).  The taps of a channel slab re-read almost the
-// same activation rows stage after stage (a 3x3 / stride-1 layer: 354 distinct rows for 9 x 256 fetched); streaming the weight
-// tile past the 32 KB vector L1 with the non-temporal hint leaves those rows in it.
-template <int WM, int WN, int TM, int TN, int BAUX = 0>
+// (Tried: weight loads with the non-temporal hint, so that the activation rows the taps of a slab re-read would stay in the 32 KB
+// vector L1: 190 -> 178 TFLOP/s-equivalent on the 480 -> 640 layer, dropped.)
+template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int NW = WM * WN;
@@ -88,11 +87,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   constexpr int A_CH = BM * 6 / NT;                       // 16-B chunks of A per thread and stage
   constexpr int B_CH = (BN * 6 + NT - 1) / NT;            // of B (the last round may cover only the first waves)
   static_assert(BM * 6 % NT == 0, "A chunks must divide evenly over the threads");
-  constexpr int EPW = 32 * 64;                            // floats of epilogue staging per wave (32 rows x 64 columns)
-  static_assert(3 * SLOT >= NW * EPW * 4, "epilogue staging must fit in the ring");
+  constexpr int EPW = 32 * 32;                            // floats of epilogue staging per wave (one 32 x 32 accumulator tile)
+  static_assert(SLOT >= NW * EPW * 4, "epilogue staging must fit in ring slot 2 (slots 0 and 1 take the next piece's first stages)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
-  int4* rinfo = reinterpret_cast<int4*>(smem + 3 * SLOT);         // [BM] (n, qy, qx, valid) of the current tile
+  int4* rinfo_all = reinterpret_cast<int4*>(smem + 3 * SLOT);     // [2][BM] (n, qy, qx, valid) of the current / next tile
   typedef __attribute__((address_space(3))) void lds_void;
 
   const int tid = threadIdx.x;
@@ -235,7 +234,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     a_part[i] = (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4));
   }
   int ld_stage = 0, ld_t = 0, ld_cc = 0, ld_ty = 0, ld_tx = 0, g_T = 1, g_tw = 1;
-  int m0 = 0, n0 = 0;
+  int n0 = 0;
   const int my_b = [&]() {                       // B instructions this wave issues per stage
     int nb = 0;
 #pragma unroll
@@ -253,8 +252,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
       a_off[i] = (a_img[i] + pix) | (ok ? 0u : kOOR);
     }
   };
-  auto write_rinfo = [&](const Piece& p) {
+  auto write_rinfo = [&](const Piece& p, int rb) {
     KArgs& a = kargs();
+    int4* rinfo = rinfo_all + rb * BM;
     const int mbase = p.mt * BM;
     const int q0y = a.g[p.gi].q0y, q0x = a.g[p.gi].q0x;
     for (int r = tid; r < BM; r += NT) {
@@ -270,13 +270,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
       rinfo[r] = ri;
     }
   };
-  auto init_loader = [&](const Piece& p) {
+  auto init_loader = [&](const Piece& p, int rb) {
     KArgs& a = kargs();
+    const int4* rinfo = rinfo_all + rb * BM;
     const auto& G = a.g[p.gi];
     g_T = G.T;
     g_tw = G.tw;
     ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 6, 0x00020000);
-    m0 = p.mt * BM;
     n0 = p.nt * BN;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       if ((BN * 6) % NT == 0 || i * NT + wave * 64 < BN * 6)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(bb + i * NT * 16), 16, (int)b_off[i], (int)wsoff, 0, BAUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(bb + i * NT * 16), 16, (int)b_off[i], (int)wsoff, 0, 0);
     // next stage: channel slab outermost, taps inside (k = cc * T * 16 + t * 16 + c), branch-free
     ++ld_stage;
     const int row_end = (ld_tx + 1 == g_tw) ? 1 : 0;
@@ -367,14 +367,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   using I1 = std::integral_constant<int, 1>;
 
   // ---------------------------------------------------------------- the piece loop
+  int rb = 0;
+  write_rinfo(P, rb);
+  __syncthreads();
+  init_loader(P, rb);
+  if (P.k1 - P.k0 > 0) issue(0);
+  if (P.k1 - P.k0 > 1) issue(1);
   while (true) {
-    write_rinfo(P);
-    __syncthreads();
-    init_loader(P);
     const int n = P.k1 - P.k0;
-    if (n > 0) issue(0);
-    if (n > 1) issue(1);
-
     if (P.consume >= 0) {
       if (tid == 0) {
         int spins = 0;
@@ -410,7 +410,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
 
-    // stage 0 must have landed before the first step; stage 1 may still fly
+    // stage 0 must have landed before the first step; stage 1 may still fly.  (Everything older than the two stage issues --
+    // the previous piece's epilogue stores were issued AFTER them -- only makes this wait longer, never shorter.)
     if (n > 1) wait_stages(I1{});
     else wait_stages(I0{});
     __builtin_amdgcn_s_barrier();
@@ -438,10 +439,21 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     if (n - j == 2) { step(No{}, Yes{}); ++j; }
     if (n - j == 1) { step(No{}, No{}); ++j; }
 
+    // ---- the next piece's first two stages go in flight (ring slots 0 and 1) before this piece's results are stored
     Piece Q;
     const bool more = next_piece(&Q);
+    const int n0d = n0;
+    const int4* rinfo = rinfo_all + rb * BM;
+    __syncthreads();                  // every wave has read its last fragments: the whole ring is free
+    if (more) {
+      write_rinfo(Q, rb ^ 1);
+      __syncthreads();
+      init_loader(Q, rb ^ 1);
+      if (Q.k1 - Q.k0 > 0) issue(0);
+      if (Q.k1 - Q.k0 > 1) issue(1);
+    }
 
-    // ---- finish the piece
+    // ---- finish the piece that just ran
     KArgs& a = kargs();
     const auto& Gd = a.g[P.gi];
     if (P.publish) {
@@ -464,22 +476,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
         __hip_atomic_store(a.sk_flags + wl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      // each wave transposes its accumulators through a private LDS slice (the ring is idle: every wave passed its last
-      // fragment read before the barrier below) so that a lane owns 4 consecutive channels of one pixel
-      __syncthreads();
-      float* stage = reinterpret_cast<float*>(ring) + wave * EPW;
+      // each wave transposes one 32 x 32 accumulator tile at a time through a private 4 KB slice of ring slot 2, so that a
+      // lane owns 4 consecutive channels of one pixel (16-B bias / residual reads and stores)
+      float* stage = reinterpret_cast<float*>(ring + 2 * SLOT) + wave * EPW;
+      const int c4 = (lane & 7) << 2;
+      const int rsub = lane >> 3;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j0 = 0; j0 < TN; j0 += 2) {
+        for (int j2 = 0; j2 < TN; ++j2) {
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              stage[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + jj * 32 + l31] = acc[i][j0 + jj][r];
-          const int c4 = (lane & 15) << 2;
-          const int rsub = lane >> 4;
-          const int col = n0 + (wn * TN + j0) * 32 + c4;
+          for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j2][r];
+          const int col = n0d + (wn * TN + j2) * 32 + c4;
           const bool col_ok = col < Gd.Ncol;
           unsigned ce = 0;
           f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -490,14 +498,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
           const int ch = ce & 0xffff;
           const int oyo = (int)((ce >> 24) & 0xff) - 128;
           const int oxo = (int)((ce >> 16) & 0xff) - 128;
-          for (int rp = 0; rp < 32; rp += 4) {
+          for (int rp = 0; rp < 32; rp += 8) {
             const int rloc = rp + rsub;
             const int4 ri = rinfo[(wm * TM + i) * 32 + rloc];
             const int oy = ri.y * a.sO + oyo;
             const int ox = ri.z * a.sO + oxo;
             if (!col_ok || !ri.w || (unsigned)oy >= (unsigned)a.Ho || (unsigned)ox >= (unsigned)a.Wo) continue;
             const size_t idx = (((size_t)ri.x * a.Ho + oy) * a.Wo + ox) * a.Cout + ch;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * 64 + c4) + bv;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * 32 + c4) + bv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_of(v[e], a.act);
             if (a.epi != SNTC_EPI_STORE) v = epi_of(v, a.epi, *reinterpret_cast<const f32x4*>(a.res + idx), a.aux, idx);
@@ -506,9 +514,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
         }
     }
     if (!more) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // epilogue staging reads done before the next piece's stages land in the ring
     P = Q;
+    rb ^= 1;
   }
 }
 
@@ -555,17 +562,15 @@ static const void* bf3p_kernel(int v) {
   switch (v) {
     case 11: return reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4>);
     case 12: return reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2>);
-    case 13: return reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4, 2>);      // experiment: 11 with nt weight loads
-    case 14: return reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2, 2>);      // experiment: 12 with nt weight loads
     default: return nullptr;
   }
 }
 
 int bf3p_variant_bm(int v) { return 256; }
-int bf3p_variant_bn(int v) { return (v == 11 || v == 13) ? 256 : 128; }
-size_t bf3p_sk_slab_floats(int v) { return (size_t)((v == 11 || v == 13) ? 8 : 4) * 16 * 512; }
+int bf3p_variant_bn(int v) { return v == 11 ? 256 : 128; }
+size_t bf3p_sk_slab_floats(int v) { return (size_t)(v == 11 ? 8 : 4) * 16 * 512; }
 
-static size_t bf3p_lds_bytes(int v) { return (size_t)3 * (bf3p_variant_bm(v) + bf3p_variant_bn(v)) * 96 + bf3p_variant_bm(v) * sizeof(int4); }
+static size_t bf3p_lds_bytes(int v) { return (size_t)3 * (bf3p_variant_bm(v) + bf3p_variant_bn(v)) * 96 + 2 * bf3p_variant_bm(v) * sizeof(int4); }
 
 static std::once_flag g_bf3p_once[16];
 static int g_bf3p_rc[16];
@@ -576,7 +581,7 @@ int bf3p_init() {
   if (dev < 0 || dev >= 16) return fail(SNTC_ERR_UNSUPPORTED, "device index beyond the residency tables");
   std::call_once(g_bf3p_once[dev], [&] {
     g_bf3p_rc[dev] = SNTC_OK;
-    for (int v : {11, 12, 13, 14}) {
+    for (int v : {11, 12}) {
       hipError_t e = hipFuncSetAttribute(bf3p_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf3p_lds_bytes(v));
       if (e != hipSuccess) g_bf3p_rc[dev] = hip_fail(e, "bf3p_init");
     }

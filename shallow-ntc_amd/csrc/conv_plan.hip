@@ -143,7 +143,7 @@ struct sntc_conv_plan {
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_tile: null plan");
-  if (variant < 0 || variant > (p->s3 ? 14 : kNumVariants) || (p->s3 && variant != 0 && variant < 11))
+  if (variant < 0 || variant > (p->s3 ? 12 : kNumVariants) || (p->s3 && variant != 0 && variant < 11))
     return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_tile: unknown tile variant");
   p->tile = variant;
   return SNTC_OK;
@@ -559,8 +559,8 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   const int msteps = max_steps(p);
   const int cus = std::max(8, gg_num_cus());
   double best_cost = 1e300;
-  for (int v : {11, 12, 13, 14}) {
-    if (p->tile >= 11 ? v != p->tile : v > 12) continue;
+  for (int v : {11, 12}) {
+    if (p->tile >= 11 && v != p->tile) continue;
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
@@ -570,7 +570,10 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     s.units = units;
     const int64_t fit = msteps > 0 ? units / msteps : 0;
     const int workers = (int)(std::min<int64_t>(cus, fit) & ~7LL);
-    s.sk = !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 && 2 * workers >= cus;
+    // many short tiles (the 13x13 / 8 synthesis: 1482 tiles of 20 ... 80 stages on 256 CUs) balance by themselves and run
+    // faster one workgroup per tile (160 vs 145 TFLOP/s-equivalent); few long ones need the stream-K cut (191 vs 155)
+    s.sk = !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 &&
+           2 * workers >= cus && units >= 64 * tiles;
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles;
     double cost = macs;
@@ -580,7 +583,7 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
       const double rounds = (double)tiles / cus;
       cost *= rounds < 1.0 ? 1.0 / rounds : std::ceil(rounds) / rounds;
     }
-    cost /= ((v == 11 || v == 13) ? 1.0 : 0.84);          // measured loop rates, tools/microbench/gemm_ceiling.hip: 276 vs 232 TFLOP/s-equivalent
+    cost /= (v == 11 ? 1.0 : 0.84);          // measured loop rates, tools/microbench/gemm_ceiling.hip: 276 vs 232 TFLOP/s-equivalent
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
@@ -616,8 +619,13 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // of stages (an idle slot costs less than a second, half-empty round of whole tiles); a multiple of 8 (XCD dealing)
     const int64_t fit = msteps > 0 ? units / msteps : 0;
     const int workers = (int)(std::min<int64_t>(resident, fit) & ~7LL);
+    // ... and only where tiles are long: with fewer than 64 stages per tile on average (3x3 96 -> 96: 54, the 1x1 layers:
+    // 6 ... 20, the 13x13 / 8 synthesis: 52) the pieces' own bookkeeping outweighs the tile quantisation it removes -- one
+    // workgroup per tile measured +6 % on the 3x3 96 -> 96 layers, +4 ... 6 % on the 1x1 layers, +57 % on 320 -> 160 at 1/16
+    // resolution, +4 % on the synthesis; long tiles (5x5 / 2: 300 stages, hyper-synthesis: 80 ... 270) keep stream-K (+6 ... 25 %)
+    const bool short_tiles = units < 64 * tiles;
     s.sk = ksplit == 1 && !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) &&
-           workers >= 8 && 2 * workers >= resident;
+           workers >= 8 && 2 * workers >= resident && !short_tiles;
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles * ksplit;
     double cost = macs;
