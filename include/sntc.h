@@ -94,6 +94,12 @@ typedef struct sntc_conv_desc {
                         *   2: the INPUT is pre-split too -- format S3, see sntc_split3 -- and the launch runs the 256-wide
                         *      direct-to-LDS kernel of csrc/bf3_gemm.hip; output fp32 NHWC; Cout % 4 == 0, epilogues
                         *      STORE / ADD / GATE / MASK_*; no split-K;
+                        * reserved[2] == 1: ROW-PACKED small-Cin convolution (the RGB first layer: Keras Conv2D 5x5 / 2, Cin = 3,
+                        *   common/elic.py:147, common/transforms.py:183): kw * Cin <= 16, fp32, no prologue.  The caller applies
+                        *   the SAME padding itself (sntc_pad_zero) and the plan convolves VALID on that tensor: every kernel row
+                        *   is one 16-deep K stage whose 64-B activation slab is ONE contiguous 16-B-per-lane read starting at
+                        *   the window's first pixel -- the vector loader of the wide layers instead of 75 dword gathers per
+                        *   output; out size = (padded - k) / stride + 1;
                         * the rest must be 0 */
 } sntc_conv_desc;
 
@@ -148,7 +154,8 @@ int sntc_conv_forward_fused(const sntc_conv_plan* first, const sntc_conv_plan* s
 int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
 /* Schedule switches of THIS plan (tests / profiling).  flags bit 0: 1 (default) lets large launches run on the persistent
  * stream-K workers, 0 forces the static schedule (one workgroup per tile); bit 2 set: bit 1 selects the stage path --
- * 1 direct-to-LDS (buffer_load ... lds), 0 register staging; bit 2 clear: the library default.  Every combination
+ * 1 direct-to-LDS (buffer_load ... lds), 0 register staging; bit 2 clear: the library default; bit 3: stream-K also for launches of
+ * short tiles (< 64 K stages on average), which by default run one workgroup per tile because that is faster.  Every combination
  * produces bit-identical outputs (each element is the same k-ordered fma chain); the switches exist so that a test can
  * assert exactly that. */
 int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int flags);
@@ -210,6 +217,9 @@ int sntc_two_layer_tail_pixels(const float* t, int n, int hh, int wh, int ch, in
  * ------------------------------------------------------------------------------------------ */
 /* Reflect-pad bottom/right: y[n,hp,wp,c] from x[n,h,w,c]  (hp>=h, wp>=w, pads < size). */
 int sntc_pad_reflect(const float* x, int n, int h, int w, int c, int hp, int wp, float* y, void* stream);
+/* y[n, hp, wp, c] <- x[n, h, w, c] placed at (top, left), zeros elsewhere: the explicit form of Keras SAME padding for a
+ * row-packed plan (sntc_conv_desc.reserved[2]).  hp >= top + h, wp >= left + w. */
+int sntc_pad_zero(const float* x, int n, int h, int w, int c, int top, int left, int hp, int wp, float* y, void* stream);
 /* Crop top-left: y[n,h,w,c] from x[n,hp,wp,c]. */
 int sntc_crop(const float* x, int n, int hp, int wp, int c, int h, int w, float* y, void* stream);
 /* Quantise both images to uint8 the reference's way ((v+.5)*255, round-half-even, saturate) and

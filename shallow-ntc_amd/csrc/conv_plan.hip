@@ -19,14 +19,21 @@ struct PackDesc {
   float* wp;
   const int* taps;
   const unsigned* cols;
-  int T, Cin, Cout, K, Ncol, kw, s, pt, pl, phase_mode, slab_major, out_major, bf3;
+  int T, Cin, Cout, K, Ncol, kw, s, pt, pl, phase_mode, slab_major, out_major, bf3, rowpack;
 };
 
 __device__ __forceinline__ void pack_element(const PackDesc& d, size_t idx) {
   const int col = (int)(idx / d.K);
   const int k = (int)(idx - (size_t)col * d.K);
   float v = 0.0f;
-  if (k < d.T * d.Cin) {
+  if (d.rowpack) {
+    // row-packed first layer: K stage t = kernel row ky, its 16 slots = the kw * Cin values (kx, c) of that row, then zeros
+    const int t = k >> 4, ci = k & 15;
+    if (t < d.T && ci < d.kw * d.Cin) {
+      const int kx = ci / d.Cin, c = ci - kx * d.Cin;
+      v = d.w[((size_t)(t * d.kw + kx) * d.Cin + c) * d.Cout + (d.cols[col] & 0xffff)];
+    }
+  } else if (k < d.T * d.Cin) {
     // K order (csrc/gather_gemm.hip): Cin % 16 == 0 -> channel slab outermost, k = cc * T * 16 + t * 16 + c;
     // otherwise (dword gather path) tap-major, k = t * Cin + ci
     int t, ci;
@@ -65,8 +72,8 @@ __device__ __forceinline__ void pack_element(const PackDesc& d, size_t idx) {
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                     const int* __restrict__ taps, const unsigned* __restrict__ cols,
                                     int T, int Cin, int Cout, int K, int Ncol, int kind, int kw, int s,
-                                    int pt, int pl, int phase_mode, int slab_major, int out_major, int bf3) {
-  const PackDesc d{w, wp, taps, cols, T, Cin, Cout, K, Ncol, kw, s, pt, pl, phase_mode, slab_major, out_major, bf3};
+                                    int pt, int pl, int phase_mode, int slab_major, int out_major, int bf3, int rowpack) {
+  const PackDesc d{w, wp, taps, cols, T, Cin, Cout, K, Ncol, kw, s, pt, pl, phase_mode, slab_major, out_major, bf3, rowpack};
   const size_t total = (size_t)Ncol * K;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x)
@@ -134,10 +141,12 @@ struct sntc_conv_plan {
   float* bias = nullptr;
   int tile = 0;             // forced gather-GEMM tile variant of THIS plan (0 = heuristic): profiling / tests only
   bool bf3 = false;         // desc.reserved[1]: bf16 x 3 split precision (weights packed as three bf16 planes)
+  bool rowpack = false;     // desc.reserved[2] == 1: small-Cin forward convolution on a caller-padded input, one kernel ROW per K stage
   bool s3 = false;          // desc.reserved[1] == 2: the INPUT arrives pre-split too (format S3, 6 B per element): csrc/bf3_gemm.hip
   bool out_major = false;   // kernel array is [kh, kw, Cout, Cin] (Keras Conv2DTranspose; any kind with desc.kernel_io_swapped)
   int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
+  bool force_stream_k = false;  // ignore the short-tile rule: stream-K wherever the launch is large enough (tests)
   float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (fusable_second plans only)
 };
 
@@ -161,6 +170,7 @@ static bool plan_dma(const sntc_conv_plan* p) {
 extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int flags) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_schedule: null plan");
   p->no_stream_k = (flags & 1) == 0;
+  p->force_stream_k = (flags & 8) != 0;
   p->dma = (flags & 4) ? ((flags & 2) ? 1 : 0) : -1;      // bit 2: "bit 1 is meaningful"; bit 1: direct-to-LDS staging on / off
   return SNTC_OK;
 }
@@ -204,7 +214,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
   if (!p->phase_mode) {
     HostGrp hg;
     for (int ky = 0; ky < d.kh; ++ky)
-      for (int kx = 0; kx < d.kw; ++kx) hg.taps.push_back((ky << 16) | kx);
+      for (int kx = 0; kx < (p->rowpack ? 1 : d.kw); ++kx) hg.taps.push_back((ky << 16) | kx);
     for (int ch = 0; ch < d.cout; ++ch) hg.cols.push_back(enc(0, 0, ch));
     groups.push_back(std::move(hg));
   } else {
@@ -257,7 +267,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     for (int t = 0; t < G.T; ++t) G.tw = std::max(G.tw, (hg.taps[t] & 0xffff) + 1);
     for (int t = 0; t < G.T; ++t)     // the kernel walks taps arithmetically: (t / tw, t % tw)
       if (hg.taps[t] != (((t / G.tw) << 16) | (t % G.tw))) return fail(SNTC_ERR_UNSUPPORTED, "tap table is not a dense row-major grid");
-    G.K = ((G.T * d.cin + kStage - 1) / kStage) * kStage;
+    G.K = p->rowpack ? G.T * kStage : ((G.T * d.cin + kStage - 1) / kStage) * kStage;
     if ((int64_t)G.Ncol * G.K * 4 >= (1LL << 31)) return fail(SNTC_ERR_UNSUPPORTED, "packed weights of one phase group must be < 2 GiB");
     SNTC_HIP(hipMalloc(&G.taps, sizeof(int) * std::max(1, G.T)));
     SNTC_HIP(hipMalloc(&G.cols, sizeof(unsigned) * G.Ncol));
@@ -270,7 +280,7 @@ static int build_plan(sntc_conv_plan* p, const float* weight, const float* bias,
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, weight, G.wp, G.taps, G.cols,
-                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0);
+                         G.T, d.cin, d.cout, G.K, G.Ncol, d.kind, d.kw, s, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0, p->rowpack ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) {
@@ -309,7 +319,12 @@ extern "C" int sntc_conv_plan_create(const sntc_conv_desc* desc, const float* we
     p->pt = d.kh / 2;
     p->pl = d.kw / 2;
   }
-  p->vec = (d.cin % kStage) == 0;
+  p->rowpack = d.reserved[2] == 1;
+  if (p->rowpack && (d.kind != SNTC_CONV2D || d.kw * d.cin > kStage || d.prologue != SNTC_PRO_NONE || d.reserved[1] != 0)) {
+    delete p;
+    return fail(SNTC_ERR_UNSUPPORTED, "row-packed plans: Keras Conv2D with kw * Cin <= 16 (the RGB first layer), fp32, no prologue");
+  }
+  p->vec = p->rowpack || (d.cin % kStage) == 0;
   // Keras Conv2DTranspose stores [kh, kw, Cout, Cin]; everything else [kh, kw, Cin, Cout] -- unless the caller says the
   // array is the channel-transposed one (the adjoint of a SignalConv2D layer runs on the layer's own kernel array)
   p->out_major = (d.kind == SNTC_CONV2D_TRANSPOSE) != (d.reserved[0] != 0);
@@ -346,7 +361,7 @@ extern "C" int sntc_conv_plan_update(sntc_conv_plan* p, const float* weight, con
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     if (total > 0)
       hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, weight, G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K,
-                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0);
+                         G.Ncol, d.kind, d.kw, d.stride, p->pt, p->pl, p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0, p->rowpack ? 1 : 0);
     SNTC_HIP(hipGetLastError());
   }
   if (bias) SNTC_HIP(hipMemcpyAsync(p->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, s));
@@ -384,7 +399,7 @@ extern "C" int sntc_plan_group_create(sntc_conv_plan* const* plans, const float*
       auto& G = p->g[gi];
       PackJob j{};
       j.d = PackDesc{weights[i], G.wp, G.taps, G.cols, G.T, d.cin, d.cout, G.K, G.Ncol, d.kw, d.stride, p->pt, p->pl,
-                     p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0};
+                     p->phase_mode ? 1 : 0, p->vec ? 1 : 0, p->out_major ? 1 : 0, p->bf3 ? 1 : 0, p->rowpack ? 1 : 0};
       j.kind = 0;
       if ((size_t)G.Ncol * G.K > 0) jobs.push_back(j);
     }
@@ -448,6 +463,12 @@ static int geometry(const sntc_conv_plan* p, int h, int w, Geo* g) {
   const sntc_conv_desc& d = p->d;
   const int s = d.stride;
   if (h < 1 || w < 1) return fail(SNTC_ERR_BAD_SHAPE, "empty image");
+  if (p->rowpack) {                       // VALID on the caller-padded input (sntc_pad_zero): every tap of every output is in range
+    if (h < d.kh || w < d.kw) return fail(SNTC_ERR_BAD_SHAPE, "row-packed plan: padded input smaller than the kernel");
+    const int ho = (h - d.kh) / s + 1, wo = (w - d.kw) / s + 1;
+    *g = Geo{ho, wo, ho, wo, s, 1, 0, 0, 1};
+    return SNTC_OK;
+  }
   if (!p->up) {
     g->Ho = (h + s - 1) / s;
     g->Wo = (w + s - 1) / s;
@@ -573,7 +594,7 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     // many short tiles (the 13x13 / 8 synthesis: 1482 tiles of 20 ... 80 stages on 256 CUs) balance by themselves and run
     // faster one workgroup per tile (160 vs 145 TFLOP/s-equivalent); few long ones need the stream-K cut (191 vs 155)
     s.sk = !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 &&
-           2 * workers >= cus && units >= 64 * tiles;
+           2 * workers >= cus && (units >= 64 * tiles || p->force_stream_k);
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles;
     double cost = macs;
@@ -623,7 +644,7 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // 6 ... 20, the 13x13 / 8 synthesis: 52) the pieces' own bookkeeping outweighs the tile quantisation it removes -- one
     // workgroup per tile measured +6 % on the 3x3 96 -> 96 layers, +4 ... 6 % on the 1x1 layers, +57 % on 320 -> 160 at 1/16
     // resolution, +4 % on the synthesis; long tiles (5x5 / 2: 300 stages, hyper-synthesis: 80 ... 270) keep stream-K (+6 ... 25 %)
-    const bool short_tiles = units < 64 * tiles;
+    const bool short_tiles = units < 64 * tiles && !p->force_stream_k;
     s.sk = ksplit == 1 && !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) &&
            workers >= 8 && 2 * workers >= resident && !short_tiles;
     s.workers = s.sk ? workers : 0;
@@ -632,7 +653,7 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // a launch of about one workgroup per CU or fewer has nothing but its own pipeline to hide the memory latency behind:
     // one image alone (Model.evaluate's reference flow), the hyper transforms.  Such a launch runs the deep-ring instance
     // (six stages in flight per workgroup instead of two) where the plan allows direct-to-LDS staging at all.  Same bits.
-    s.deep = !fused && !s.sk && p->dma != 0 && p->vec && !pro && !p->bf3 && gg_resident_blocks_deep(v) > 0 &&
+    s.deep = !fused && !s.sk && p->dma != 0 && p->vec && !p->rowpack && !pro && !p->bf3 && gg_resident_blocks_deep(v) > 0 &&
              tiles * ksplit <= (int64_t)kDeepBlocksPerCU * gg_num_cus();
     if (s.sk) {
       cost *= (double)resident / workers;

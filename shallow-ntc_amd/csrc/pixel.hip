@@ -1,5 +1,6 @@
 // pixel.hip -- the HBM-bound ends of the path: reflect pad / crop, uint8 quantisation + squared
 // error, small-channel GDN1, and the fused tail of the two-layer synthesis.
+#include <algorithm>
 #include "sntc_internal.h"
 
 namespace sntc {
@@ -21,6 +22,21 @@ __global__ void pad_reflect_kernel(const float* __restrict__ x, int h, int w, in
     const int sj = j < w ? j : 2 * w - 2 - j;
     y[i] = x[((b * h + sr) * w + sj) * c + k];
   }
+}
+
+// y[n,hp,wp,c] <- x[n,h,w,c] placed at (top, left), zeros elsewhere (the explicit form of a convolution's SAME padding).
+// One block row per output image row: a row is one contiguous run of floats, shifted by left * c -- no per-element division.
+__global__ void __launch_bounds__(256) pad_zero_kernel(const float* __restrict__ x, int h, int w, int c, int top, int left, int hp, int wp,
+                                                       float* __restrict__ y) {
+  const int64_t row = blockIdx.y;                      // (image, padded row)
+  const int64_t b = row / hp;
+  const int r = (int)(row - b * hp) - top;
+  const bool row_ok = (unsigned)r < (unsigned)h;
+  const int lo = left * c, hi = (left + w) * c, len = wp * c;
+  const float* src = x + ((b * h + (row_ok ? r : 0)) * (int64_t)w) * c - lo;
+  float* dst = y + row * (int64_t)len;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += gridDim.x * blockDim.x)
+    dst[j] = (row_ok && j >= lo && j < hi) ? src[j] : 0.0f;
 }
 
 __global__ void crop_kernel(const float* __restrict__ x, int hp, int wp, int c, int h, int w, float* __restrict__ y,
@@ -280,6 +296,17 @@ extern "C" int sntc_pad_reflect(const float* x, int n, int h, int w, int c, int 
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_pad_reflect: reflect padding needs pad < size");
   const int64_t total = (int64_t)n * hp * wp * c;
   hipLaunchKernelGGL(pad_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, h, w, c, hp, wp, y, total);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
+extern "C" int sntc_pad_zero(const float* x, int n, int h, int w, int c, int top, int left, int hp, int wp, float* y, void* stream) {
+  if (!x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_pad_zero: null argument");
+  if (n < 1 || h < 1 || w < 1 || c < 1 || top < 0 || left < 0 || hp < h + top || wp < w + left)
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_pad_zero: bad sizes");
+  if ((int64_t)n * hp > 0x7fffffffLL / 1 || (int64_t)wp * c > 0x7fffffffLL) return fail(SNTC_ERR_BAD_SHAPE, "sntc_pad_zero: tensor too large");
+  const int bx = std::max(1, std::min(8, (wp * c + 1023) / 1024));
+  hipLaunchKernelGGL(pad_zero_kernel, dim3(bx, (unsigned)(n * hp)), dim3(256), 0, (hipStream_t)stream, x, h, w, c, top, left, hp, wp, y);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }

@@ -7,6 +7,7 @@ allocator.  No torch compute op is used on the hot path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -22,6 +23,7 @@ WGRAD_STREAM = None         # training: the side stream the weight / bias gradie
 FUSE_RESIDUAL_TAIL = True   # ResidualBlock (c = 192): 3x3 and 1x1 + skip in one launch (bit-identical; False: two launches)
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
+ROW_PACKED_FIRST_LAYER = not os.environ.get("SNTC_NO_ROWPACK")    # Cin = 3 analysis layers run as row-packed plans (False: the generic dword-gather path, for the A/B)
 FORCE_TILE = 0   # tools/profile_layers.py --variant: every plan created afterwards is pinned to this tile variant
 BF16X3_EXPERIMENT = False   # bench.py regions.decode_bf16x3 only: plans created while this is set use the split-precision
                             # contraction wherever it applies (Cin % 16 == 0, no prologue); never set by the product paths
@@ -111,7 +113,7 @@ class ConvPlan:
     """One packed convolution (sntc_conv_plan): Conv2D / Conv2DTranspose / SignalConv2D (+GDN pool)."""
 
     def __init__(self, kind, weight, bias, stride, act=None, prologue=capi.PRO_NONE, epilogue=capi.EPI_STORE,
-                 kernel_io_swapped=False, bf16x3=False):
+                 kernel_io_swapped=False, bf16x3=False, rowpack=False):
         """``kernel_io_swapped``: ``weight`` has its two channel axes swapped with respect to the kind's own layout -- the
         input-gradient plan of a tfc.SignalConv2D layer (the adjoint kind) packs straight from the layer's kernel array."""
         capi.require_gpu()
@@ -131,6 +133,7 @@ class ConvPlan:
         self.s3 = bf16x3 == "presplit"                  # the input arrives in format S3 (ops.split3): csrc/bf3_gemm.hip
         desc.reserved[0] = 1 if kernel_io_swapped else 0
         desc.reserved[1] = 2 if self.s3 else (1 if bf16x3 else 0)       # split precision, opt-in, never a default
+        desc.reserved[2] = 1 if rowpack else 0          # row-packed small-Cin layer on a caller-padded input (RowPackedConv)
         w = w.contiguous()
         b = None if bias is None else bias.contiguous()
         self._h = C.c_void_p()
@@ -156,10 +159,11 @@ class ConvPlan:
         """Force this plan's gather-GEMM tile variant (0 = heuristic); profiling / tests."""
         capi.call("sntc_conv_plan_set_tile", self._h, int(variant))
 
-    def set_stream_k(self, enabled, dma=None):
+    def set_stream_k(self, enabled, dma=None, force=False):
         """``enabled`` False forces the static one-workgroup-per-tile schedule for this plan; ``dma`` True / False forces the
-        direct-to-LDS / register stage path (None: library default).  Tests: identical bits every way."""
-        flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0)))
+        direct-to-LDS / register stage path (None: library default); ``force``: stream-K even where the default picks one
+        workgroup per tile because the tiles are short.  Tests: identical bits every way."""
+        flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0))) | (8 if force else 0)
         capi.call("sntc_conv_plan_set_schedule", self._h, flags)
 
     def fusable_with(self, second):
@@ -302,6 +306,44 @@ def two_layer_tail_pixels(t, ch, has_res, act_kind, beta, gamma, w2, b2, h, w, r
     capi.call("sntc_two_layer_tail_pixels", _ptr(t), n, hh, wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma), _ptr(w2),
               _ptr(b2), k2, s2, cout, h, w, _ptr(reference), _ptr(px), _ptr(sse), _stream())
     return px, sse
+
+
+def pad_zero(x, top, left, bottom, right):
+    """Zero padding on the two spatial axes (the explicit form of a convolution's SAME padding)."""
+    _check_nhwc(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h + top + bottom, w + left + right, c), dtype=torch.float32, device=x.device)
+    capi.call("sntc_pad_zero", _ptr(x), n, h, w, c, top, left, h + top + bottom, w + left + right, _ptr(y), _stream())
+    return y
+
+
+class RowPackedConv:
+    """Keras Conv2D(k, s, SAME) with kw * Cin <= 16 -- the RGB first layer of every analysis transform (common/elic.py:147,
+    common/transforms.py:183) -- as a row-packed plan: the image is zero-padded once (SAME), then each kernel row is one
+    16-deep K stage read with the vector loader (include/sntc.h, sntc_conv_desc.reserved[2]).  Same products as the generic
+    path, in another order of summation (k = row-major inside a kernel row either way; the zero slots add exact zeros)."""
+
+    def __init__(self, weight, bias, stride, act=None):
+        self.k, self.stride = int(weight.shape[0]), int(stride)
+        self.plan = ConvPlan("conv", weight, bias, stride, act, rowpack=True)
+        self.cin, self.cout = self.plan.cin, self.plan.cout
+
+    def _pads(self, size):
+        out = -(-size // self.stride)
+        total = max((out - 1) * self.stride + self.k - size, 0)
+        return total // 2, total - total // 2
+
+    def out_hw(self, h, w):
+        return -(-h // self.stride), -(-w // self.stride)
+
+    def flops(self, n, h, w):
+        ho, wo = self.out_hw(h, w)
+        return 2 * n * ho * wo * self.k * self.k * self.cin * self.cout
+
+    def __call__(self, x, res=None, aux=None):
+        _check_nhwc(x, self.cin)
+        (pt, pb), (pl, pr) = self._pads(x.shape[1]), self._pads(x.shape[2])
+        return self.plan(pad_zero(x, pt, pl, pb, pr), res, aux)
 
 
 def pad_reflect(x, hp, wp):

@@ -99,7 +99,7 @@ def test_presplit_kernel_against_float64(kind, k, s, cin, cout, n, h, w, act, ep
     for variant in (11, 12):
         ps.set_tile(variant)
         for sk in (True, False):
-            ps.set_stream_k(sk)
+            ps.set_stream_k(sk, force=sk)
             y = ps(xs, res=rd)
             outs.append(y)
             e3 = rel_err(y.cpu().numpy(), ref)
@@ -143,7 +143,7 @@ def test_stream_k_chain_at_full_width(dev):
     for variant in (11, 12):
         ps.set_tile(variant)
         for sk in (True, False):
-            ps.set_stream_k(sk)
+            ps.set_stream_k(sk, force=sk)
             outs.append(ps(xs))
     for y in outs[1:]:
         assert torch.equal(y, outs[0])

@@ -284,6 +284,7 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
     plan = ops.ConvPlan(kind, wk, b, s, "relu" if epi else None, capi.PRO_NONE, capi.EPI_ADD if epi else capi.EPI_STORE)
     ho, wo = plan.out_hw(h, w)
     res = torch.randn((n, ho, wo, cout), device=dev, generator=g) if epi else None
+    plan.set_stream_k(True, force=True)        # short-tile shapes default to one workgroup per tile since round 3: force the cut
     v_auto, blocks = plan.launch_info(n, h, w)
     y_sk = plan(x, res=res).clone()
     plan.set_stream_k(False)
@@ -291,7 +292,7 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
     y_static = plan(x, res=res).clone()
     assert blocks_static > blocks, "the shape was meant to run on the persistent workers"      # stream-K really ran
     assert torch.equal(y_sk, y_static)
-    plan.set_stream_k(True)
+    plan.set_stream_k(True, force=True)
     for variant in (1, 2, 3, 4, 5, 8, 9, 10):
         plan.set_tile(variant)
         assert torch.equal(plan(x, res=res), y_static), variant
@@ -299,9 +300,9 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
     for variant in (1, 2, 3, 4, 5, 8, 9):
         plan.set_tile(variant)
         for sk in (True, False):
-            plan.set_stream_k(sk, dma=True)
+            plan.set_stream_k(sk, dma=True, force=sk)
             assert torch.equal(plan(x, res=res), y_static), (variant, sk, "dma")
-            plan.set_stream_k(sk, dma=False)
+            plan.set_stream_k(sk, dma=False, force=sk)
             assert torch.equal(plan(x, res=res), y_static), (variant, sk, "registers")
     plan.set_stream_k(True)
     plan.set_tile(0)

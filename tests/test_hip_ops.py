@@ -452,3 +452,32 @@ def test_bf16x3_split_precision_plan(kind, k, s, cin, cout, dev):
         assert e3 < 3e-6 and e3 < 4 * e32 + 1e-7, (variant, e3, e32)
     with pytest.raises(Exception):
         ops.ConvPlan("conv", dev_t(rng.standard_normal((5, 5, 3, 16)).astype(np.float32), dev), None, 2, bf16x3=True)   # Cin % 16 != 0
+
+
+@pytest.mark.parametrize("k,s,cin,cout,n,h,w,act", [(5, 2, 3, 192, 2, 64, 96, None), (5, 2, 3, 64, 1, 37, 41, "relu"),
+                                                  (5, 2, 3, 32, 3, 16, 18, "leaky_relu"), (3, 1, 4, 48, 1, 19, 23, None),
+                                                  (5, 2, 1, 32, 1, 33, 20, None)])
+def test_row_packed_first_layer(k, s, cin, cout, n, h, w, act, dev):
+    """The RGB first layer as a row-packed plan (zero-pad once, one kernel row per 16-deep K stage, vector loads at 4-byte
+    aligned addresses) == the float64 oracle's Keras SAME convolution, to the generic dword-gather path's own accuracy, for even
+    and odd sizes (asymmetric SAME pads), and through the transforms that use it."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(k * 10 + cin + h)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wk = (rng.standard_normal((k, k, cin, cout)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, wk, b, s)
+    if act == "relu":
+        ref = O.relu(ref)
+    elif act == "leaky_relu":
+        ref = O.leaky_relu(ref)
+    rp = ops.RowPackedConv(dev_t(wk, dev), dev_t(b, dev), s, act)
+    gen = ops.ConvPlan("conv", dev_t(wk, dev), dev_t(b, dev), s, act)
+    y = rp(dev_t(x, dev))
+    assert tuple(y.shape) == ref.shape == tuple(gen(dev_t(x, dev)).shape)
+    e_rp, e_gen = rel_err(y.cpu().numpy(), ref), rel_err(gen(dev_t(x, dev)).cpu().numpy(), ref)
+    assert e_rp < 2e-6 and e_rp < 4 * e_gen + 2e-7, (e_rp, e_gen)
+    alone = rp(dev_t(x[:1], dev))
+    assert torch.equal(alone, y[:1])
+    with pytest.raises(Exception):
+        ops.ConvPlan("conv", dev_t(rng.standard_normal((5, 5, 4, 16)).astype(np.float32), dev), None, 2, rowpack=True)   # 5 * 4 > 16
