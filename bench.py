@@ -476,6 +476,8 @@ def main():
                 shape = {8: "1, 1, 2, 2", 9: "2, 2, 2, 2", 10: "2, 4, 4, 1"}.get(e["variant"], f"1, {e['variant']}, 4, 1")
                 # <..., BF3, DMA, DEEP, FUSE2>: the default fp32 register-staged instance, or the fused ResidualBlock tail
                 name = f"gg_kernel<{shape}, {vec}, false, false, 0, {'true' if '+1x1' in e['kind'] else 'false'}>"
+                if e["variant"] >= 11:                                      # the pre-split bf16 x 3 kernel (csrc/bf3_gemm.hip)
+                    name = f"bf3_kernel<4, 2, 2, {4 if e['variant'] == 11 else 2}>"
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
                 k["flops"] += e["flops"]
@@ -492,7 +494,7 @@ def main():
         import hashlib
         traffic, traffic_src, traffic_stale = None, None, None
         cur_sha = hashlib.sha256((ROOT / "shallow-ntc_amd/csrc/gather_gemm.hip").read_bytes()).hexdigest()[:16]
-        for f in sorted((ROOT / "profiles").glob("*_pmc_summary.json"), reverse=True):
+        for f in sorted(f for f in (ROOT / "profiles").glob("*_pmc_summary.json") if "encode" not in f.name)[::-1]:
             summ = json.loads(f.read_text())
             for kn, e in summ.items():
                 if kn != "_meta" and name in kn and "hbm_side_bytes_per_launch" in e:
@@ -511,10 +513,26 @@ def main():
         if not args.decode_only:             # the same table for the analysis side (ELIC encoder: MFMA utilisation)
             enc = kernel_table(lambda: [model.encode(x) for _ids, x, _hw in batches], 1)
             tot_ms, tot_fl = sum(v["ms"] for v in enc.values()), sum(v["flops"] for v in enc.values())
+            # counters of the same kernels from the committed encode-side passes (profiles/r*_encode_pmc_summary.json: separate
+            # rocprofv3 --pmc runs of tools/profile_layers.py), with the same staleness flag as `traffic` above
+            enc_pmc, enc_src, enc_stale = {}, None, None
+            for f in sorted((ROOT / "profiles").glob("*_encode_pmc_summary.json"), reverse=True):
+                enc_pmc, enc_src = json.loads(f.read_text()), f"profiles/{f.name}"
+                enc_stale = enc_pmc.get("_meta", {}).get("gather_gemm_sha16") != cur_sha
+                break
+
+            def counters(n):
+                for kn, e in enc_pmc.items():
+                    if kn != "_meta" and n in kn:
+                        return dict(traffic=e.get("hbm_side_bytes_per_launch"), mfma_busy_over_simd_cycles=e.get("mfma_busy_over_simd_cycles"),
+                                    lds_bank_conflict_cycles=e.get("counters_mean_per_launch", {}).get("SQ_LDS_BANK_CONFLICT"))
+                return {}
+
             roofline["encode_kernels"] = dict(
                 conv_tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                conv_ms_per_step=round(tot_ms, 3),
-                by_kernel={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms_per_step=round(v["ms"], 3))
+                conv_ms_per_step=round(tot_ms, 3), counters_source=enc_src, counters_stale=enc_stale,
+                by_kernel={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms_per_step=round(v["ms"], 3),
+                                   launches=v["launches"], **counters(n))
                            for n, v in sorted(enc.items(), key=lambda kv: -kv[1]["ms"])})
 
     # ---- CPU baseline: the torch-CPU port of the same decode on this box's host cores ---------------

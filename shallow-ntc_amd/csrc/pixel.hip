@@ -151,6 +151,9 @@ __global__ void __launch_bounds__(256) gdn_small_kernel(const float* __restrict_
 // oy = 2 qy + phi_y - 1, ox = 2 qx + phi_x - 1 (phi in {0,1}): phase 0 uses ky in {0,2,4} from rows
 // qy, qy-1, qy-2; phase 1 uses ky in {1,3} from rows qy, qy-1.  The 18 x 18 x CH input tile of h
 // lives in LDS, so the half-resolution activation is read from HBM once.
+constexpr int tail_px(int ch) { return (ch / 4) % 2 ? ch : ch + 4; }              // 12 -> 12, 24 -> 28, 48 -> 52 words
+constexpr int tail_row(int ch) { return (18 * tail_px(ch) + 63) / 64 * 64; }     // 256, 512, 960 words
+
 template <int CH>
 __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __restrict__ t, int hh, int wh, int has_res,
                                                              int act_kind, const float* __restrict__ beta,
@@ -162,9 +165,14 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
   // (unpad_images), (v + .5) * 255, round half to even, saturate -> uint8 [n, oh, ow, 3]; with ref (float [n, oh, ow, 3])
   // also the per-image integer squared error of the two quantised images (mse_psnr), one u64 atomic per workgroup.
   constexpr int TQ = 16, TH = TQ + 2;
+  // LDS image of the tile: pixel stride PX words with PX / 4 odd (so the 16 pixels of a row sit on 16 different 16-B bank
+  // slots), row stride ROW a multiple of 64 words (so the second row a ds_read_b128 lane group touches -- lanes {0-3, 12-15}
+  // read row ty, lanes {20-27} row ty + 1 -- lands on exactly the slots the first one leaves free): conflict-free fragment
+  // reads (round 2 measured 6.1 M SQ_LDS_BANK_CONFLICT cycles per launch with the dense [18][18][CH] image)
+  constexpr int PX = tail_px(CH), ROW = tail_row(CH);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sh = reinterpret_cast<float*>(smem);   // [TH][TH][CH]
-  float* sg = sh + TH * TH * CH;                 // [CH][CH]
+  float* sh = reinterpret_cast<float*>(smem);   // [TH][ROW], pixel lx of row ly at ly * ROW + lx * PX
+  float* sg = sh + TH * ROW;                     // [CH][CH]
   float* sb = sg + CH * CH;                      // [CH]
   const int img = blockIdx.z;
   const int qy0 = blockIdx.y * TQ, qx0 = blockIdx.x * TQ;
@@ -179,7 +187,7 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
   for (int p = threadIdx.x; p < TH * TH; p += 256) {
     const int ly = p / TH, lx = p - ly * TH;
     const int iy = qy0 - 2 + ly, ix = qx0 - 2 + lx;
-    float* dst = sh + p * CH;
+    float* dst = sh + ly * ROW + lx * PX;
     if ((unsigned)iy < (unsigned)hh && (unsigned)ix < (unsigned)wh) {
       const float* src = t + (((int64_t)img * hh + iy) * wh + ix) * c2;
       float v[CH];
@@ -236,7 +244,7 @@ __global__ void __launch_bounds__(256) two_layer_tail_kernel(const float* __rest
 #pragma unroll
         for (int jx = 0; jx < 3 - px; ++jx) {
           const int ky = py + 2 * jy, kx = px + 2 * jx;
-          const float* hp = sh + ((ty + 2 - jy) * TH + (tx + 2 - jx)) * CH;
+          const float* hp = sh + (ty + 2 - jy) * ROW + (tx + 2 - jx) * PX;
           // compile-time offsets from a kernel-argument pointer: the weights arrive by scalar loads (SGPRs),
           // not through LDS -- 3/4 of the LDS reads of this loop were weight reads
           const float* wp = w2 + (ky * 5 + kx) * 3 * CH;
@@ -378,7 +386,7 @@ template <int CH>
 static int launch_tail(const float* t, int n, int hh, int wh, int has_res, int act_kind, const float* beta,
                        const float* gamma, const float* w2, const float* b2, float* x_hat, int oh, int ow, const float* ref,
                        uint8_t* px, unsigned long long* sse, hipStream_t s) {
-  const size_t lds = sizeof(float) * (18 * 18 * CH + CH * CH + CH);
+  const size_t lds = sizeof(float) * (18 * tail_row(CH) + CH * CH + CH);
   static thread_local int attr_dev = -1;
   int dev = 0;
   SNTC_HIP(hipGetDevice(&dev));

@@ -131,6 +131,7 @@ class ConvPlan:
             bf16x3 = True
         self.bf16x3 = bool(bf16x3)
         self.s3 = bf16x3 == "presplit"                  # the input arrives in format S3 (ops.split3): csrc/bf3_gemm.hip
+        self.rowpack = bool(rowpack)
         desc.reserved[0] = 1 if kernel_io_swapped else 0
         desc.reserved[1] = 2 if self.s3 else (1 if bf16x3 else 0)       # split precision, opt-in, never a default
         desc.reserved[2] = 1 if rowpack else 0          # row-packed small-Cin layer on a caller-padded input (RowPackedConv)
@@ -244,7 +245,7 @@ class ConvPlan:
         if prof is not None:
             e1.record()
             v, nb = self.launch_info(n, h, w)
-            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 16 == 0,
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 16 == 0 or self.rowpack,
                              kind=self.kind, k=self.k[0], s=self.stride, cin=self.cin, cout=self.cout, n=n, h=h, w=w))
         return y
 

@@ -1,12 +1,22 @@
-# rocprofv3 evidence for profiles/: kernel stats + PMC passes of the decode-only bench, kernel stats + SQ pass of the layer table
+# rocprofv3 evidence for profiles/ (round 3): kernel stats + PMC passes of the decode-only bench AND of the encode-side layer
+# table, the layer tables (Kodak batch and W1), the loop-ceiling microbench, the default bench line.  Program directly after `--`.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02; mkdir -p $O
-B="python3 $R/bench.py --decode-only --streams 1 --steps 20 --warmup 3"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/decode_only_bench.json 2> $O/stats.err
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 > /dev/null 2> $O/pmc_sq.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 > /dev/null 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/layers_stats -- python3 $R/tools/profile_layers.py --reps 5 > $O/layer_table.txt 2> $O/layers.err
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/layers_pmc -- python3 $R/tools/profile_layers.py --reps 3 > /dev/null 2> $O/layers_pmc.err
-cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-ls -R $O | head -50
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r03; rm -rf $O; mkdir -p $O
+SQ="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"
+# ---- decode (the headline region): one stream, so that a kernel's duration is its own
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec_stats -- python3 $R/bench.py --decode-only --streams 1 --steps 20 --warmup 3 > $O/decode_only_bench.json 2> $O/dec_stats.err
+rocprofv3 --pmc $SQ --output-format csv -d $O/dec_pmc_sq -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 > /dev/null 2> $O/dec_pmc_sq.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/dec_pmc_fetch -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 > /dev/null 2> $O/dec_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/dec_pmc_write -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 > /dev/null 2> $O/dec_pmc_write.err
+# ---- encode (ELIC analysis + hyper transforms): the layer table script launches every layer of encode and decode
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc_stats -- python3 $R/tools/profile_layers.py --reps 5 > $O/layer_table.txt 2> $O/enc_stats.err
+rocprofv3 --pmc $SQ --output-format csv -d $O/enc_pmc_sq -- python3 $R/tools/profile_layers.py --reps 3 > /dev/null 2> $O/enc_pmc_sq.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/enc_pmc_fetch -- python3 $R/tools/profile_layers.py --reps 3 > /dev/null 2> $O/enc_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/enc_pmc_write -- python3 $R/tools/profile_layers.py --reps 3 > /dev/null 2> $O/enc_pmc_write.err
+# ---- un-profiled: layer tables, microbench, default bench
+cd $R
+python3 tools/profile_layers.py --reps 5 > $O/layer_table_unprofiled.txt 2>&1
+python3 tools/profile_layers.py --reps 5 --batch 64 --hw 256 256 > $O/layer_table_w1.txt 2>&1
+tools/microbench/gemm_ceiling > $O/gemm_ceiling.txt 2>&1
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+find $O -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head; ls $O
