@@ -4,6 +4,7 @@
 (``record.jsonl``, as the reference's custom writer also keeps, custom_writers.py:89-128); TensorBoard summaries and
 the tf.data input pipeline are not reproduced -- ``train_dataset`` is any iterable of NHWC float batches."""
 import json
+import logging
 import re
 import time
 from pathlib import Path
@@ -12,6 +13,9 @@ from typing import Any, Mapping, NamedTuple
 TRAIN_COLLECTION = "train"            # :79-81
 VAL_COLLECTION = "val"
 CHECKPOINTS_DIR_NAME = "checkpoints"
+
+
+log = logging.getLogger(__name__)
 
 
 class Metrics(NamedTuple):
@@ -92,6 +96,8 @@ def simple_train_eval_loop(train_eval_config, workdir, model, train_dataset, val
         prefix = warm if not warm.is_dir() else (eval_lib.latest_checkpoint(warm) if list(warm.glob("ckpt-*.index"))
                                                   else eval_lib.latest_checkpoint(warm / TRAIN_COLLECTION / CHECKPOINTS_DIR_NAME))
         model.set_weights(tf_checkpoint.load_reference_checkpoint(prefix, model._transform_config))
+        log.info("warm start: variables restored from %s (step stays %d; the reference also restores its global_step and Adam "
+                 "slots from a warm checkpoint: continue in the same workdir to keep them)", prefix, int(model._step))
     # restore_or_initialize (:190): a workdir that already holds a checkpoint continues from it -- variables, step (hence
     # the lr / lambda schedules and Adam's bias correction) and, when this build wrote it, the Adam moments
     own = workdir / TRAIN_COLLECTION / CHECKPOINTS_DIR_NAME
@@ -101,7 +107,13 @@ def simple_train_eval_loop(train_eval_config, workdir, model, train_dataset, val
         model._step = int(re.search(r"ckpt-(\d+)", Path(prefix).name).group(1))
         from ..train import Trainer
         model.trainer = Trainer(model, seed=model._seed)
-        model.trainer.restore_optimizer(prefix)
+        if warm:
+            log.warning("the workdir's own checkpoint %s overrides the warm start", prefix)
+        if model.trainer.restore_optimizer(prefix):
+            log.info("resumed from %s: variables, step %d, Adam moments", prefix, int(model._step))
+        else:
+            log.warning("resumed from %s at step %d WITHOUT optimizer state (no %s.optimizer.npz: a checkpoint of the reference, or "
+                        "variables only): Adam continues with fresh moments", prefix, int(model._step), Path(prefix).name)
     rows = []
 
     def evaluate_fn(step):                                     # :214-229
@@ -123,7 +135,7 @@ def simple_train_eval_loop(train_eval_config, workdir, model, train_dataset, val
         if evaluating:
             evaluate_fn(step)
         if saving:
-            model.trainer.save_checkpoint(workdir)
+            model.trainer.save_checkpoint(workdir, max_to_keep=int(_cfg(config, "max_ckpts_to_keep", 1)))
     if eval_every > 0:                                         # :254-258 final evaluation
         model.trainer.sync_model()
         evaluate_fn(step)

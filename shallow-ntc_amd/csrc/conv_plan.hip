@@ -8,6 +8,7 @@
 // (phase, channel) pairs: N = phases*Cout, K = taps*Cin -- no zero stuffing, no col2im.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <vector>
 #include "sntc_internal.h"
 
@@ -667,7 +668,9 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // measured MFMA rate of each tile shape on exact-fit layers, relative to 128 x 128 (tools/ab_layers.sh, round 2): a wave
     // that owns more accumulators reads fewer LDS bytes and stages fewer global bytes per MFMA, and the chip holds a
     // higher clock for it; 256 x 128 leaves one wave per SIMD and stalls on every barrier
-    static const double kRate[kNumVariants + 1] = {0, 0.86, 0.93, 0.97, 1.00, 0.97, 0.90, 0.85, 0.90, 1.02, 0.40};
+    // (round 3, back-to-back launches: 128 x 96 beats 128 x 128 by 3.5 % on the 320 -> 480 layer whose 480 columns it fits exactly,
+    // where the old 0.97 let the stream-K worker count tip the choice the other way)
+    static const double kRate[kNumVariants + 1] = {0, 0.86, 0.93, 1.00, 1.00, 0.97, 0.90, 0.85, 0.90, 1.02, 0.40};
     cost /= kRate[v];
     if (cost < best_cost) { best_cost = cost; best = s; }
   }

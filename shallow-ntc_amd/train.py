@@ -743,7 +743,7 @@ class Trainer:
         """Load the trained variables into the inference ``Model`` (validation / checkpoint)."""
         self.m.set_weights(self.export_weights(), _from_trainer=True)
 
-    def save_checkpoint(self, workdir, model_config=None):
+    def save_checkpoint(self, workdir, model_config=None, max_to_keep=1):
         """``workdir/train/checkpoints/ckpt-<step>`` in the reference's TensorBundle layout (+ ``config.json``), i.e. what
         ``common/eval_lib.py:load_latest_ckpt`` -- here and in the reference -- restores (train_lib.py:123-126,248-250,326-336).
         Variables only; the Adam moments stay in this process."""
@@ -763,12 +763,22 @@ class Trainer:
         np.savez(ckdir / f"ckpt-{self.step_count}.optimizer.npz", step=np.int64(self.step_count),
                  m=self.store.m.cpu().numpy(), v=self.store.v.cpu().numpy(),
                  layout=np.array(json.dumps({k: [int(o), list(map(int, shp))] for k, (o, shp) in self.store.offsets.items()})))
-        # tf.train.CheckpointManager's state file: what tf.train.latest_checkpoint (reference eval_lib.py:42-44) reads
+        # tf.train.CheckpointManager's state file: what tf.train.latest_checkpoint (reference eval_lib.py:42-44) reads.
+        # CheckpointManager(max_to_keep=train_eval_config.get('max_ckpts_to_keep', 1)), train_lib.py:124-126: the newest N by
+        # step stay and are all listed; only files of checkpoints THIS naming scheme wrote (ckpt-<digits>.*) are ever removed.
+        import os
+        import re
         name = f"ckpt-{self.step_count}"
-        (ckdir / "checkpoint").write_text(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
-        for old in ckdir.glob("ckpt-*"):                       # CheckpointManager(max_to_keep=1), train_lib.py:124-126
-            if not old.name.startswith(name + "."):
-                old.unlink()
+        steps = sorted({int(m.group(1)) for f in ckdir.glob("ckpt-*") if (m := re.fullmatch(r"ckpt-(\d+)\..+", f.name))})
+        keep = steps[-max(1, int(max_to_keep)):]
+        for f in ckdir.glob("ckpt-*"):
+            m = re.fullmatch(r"ckpt-(\d+)\..+", f.name)
+            if m and int(m.group(1)) not in keep:
+                f.unlink()
+        state = f'model_checkpoint_path: "{name}"\n' + "".join(f'all_model_checkpoint_paths: "ckpt-{k}"\n' for k in keep)
+        tmp = ckdir / "checkpoint.tmp"
+        tmp.write_text(state)
+        os.replace(tmp, ckdir / "checkpoint")                  # the state file changes atomically, after the bundle is complete
         return prefix
 
     def restore_optimizer(self, prefix):

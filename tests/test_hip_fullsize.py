@@ -309,3 +309,49 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
     one = plan(x[2:3].contiguous(), res=None if res is None else res[2:3].contiguous())
     assert torch.equal(one, y_static[2:3])
     torch.cuda.synchronize()
+
+
+def test_concurrent_stream_k_launches_and_the_status_word(dev):
+    """Stream-K needs every worker of a launch resident; four streams each launching stream-K layers oversubscribe the device
+    (the advisor's scenario).  The launches must complete, give the bits of the static schedule, and leave the sticky status
+    word clear; a flagged hand-off would raise in check_conv_status instead of trapping the context.  The process-wide switch
+    puts every later call on the static schedule (fewer, smaller launches: more blocks than resident workers)."""
+    from shallow_ntc_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    layers = []
+    for kind, k, s, cin, cout, n, h, w in [("convT", 3, 1, 480, 640, 6, 32, 48), ("convT", 5, 2, 320, 480, 6, 16, 24),
+                                          ("conv", 5, 2, 192, 192, 4, 128, 192), ("convT", 3, 1, 480, 640, 4, 32, 48)]:
+        x = torch.randn((n, h, w, cin), device=dev, generator=g)
+        wk = torch.randn((k, k, cout, cin) if kind == "convT" else (k, k, cin, cout), device=dev, generator=g) * 0.05
+        plan = ops.ConvPlan(kind, wk, None, s)
+        plan.set_stream_k(False)
+        ref = plan(x).clone()
+        plan.set_stream_k(True, force=True)
+        _, blocks_sk = plan.launch_info(n, h, w)
+        layers.append((plan, x, ref, blocks_sk))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    outs = []
+    for rep in range(6):
+        for (plan, x, ref, _), st in zip(layers, streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append((plan(x), ref))
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    ops.check_conv_status()                         # no hand-off timed out
+    for y, ref in outs:
+        assert torch.equal(y, ref)
+    try:
+        ops.set_stream_k(False)
+        changed = 0
+        for plan, x, ref, blocks_sk in layers:
+            n, h, w = x.shape[:3]
+            _, blocks = plan.launch_info(n, h, w)
+            changed += blocks != blocks_sk           # one workgroup per tile now (another tile shape may be picked with it)
+            assert torch.equal(plan(x), ref)
+        assert changed >= 2
+    finally:
+        ops.set_stream_k(True)

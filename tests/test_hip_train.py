@@ -469,6 +469,19 @@ def test_train_eval_loop_and_itinf_loop_drivers(dev, tmp_path):
     assert 'model_checkpoint_path: "ckpt-12"' in (tmp_path / "train" / "checkpoints" / "checkpoint").read_text()
     restored = eval_lib.load_latest_ckpt(tmp_path, device=dev)
     assert restored._step == 12
+    # max_ckpts_to_keep > 1 (reference train_lib.py:124-126): the newest N by step stay and are all listed; files that are not
+    # ckpt-<step>.* of this naming scheme (say, a reference-written side file) are never deleted
+    keep_dir = tmp_path / "keep2"
+    (keep_dir / "train" / "checkpoints").mkdir(parents=True)
+    (keep_dir / "train" / "checkpoints" / "ckpt-notes.txt").write_text("not ours to delete")
+    model2 = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=9,
+                   optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
+    train_lib.simple_train_eval_loop(dict(num_steps=9, log_metrics_every_steps=100, checkpoint_every_steps=3, max_ckpts_to_keep=2),
+                                     keep_dir, model2, forever(), batches[:1])
+    ck = keep_dir / "train" / "checkpoints"
+    assert sorted(p.name for p in ck.glob("*.index")) == ["ckpt-6.index", "ckpt-9.index"] and (ck / "ckpt-notes.txt").exists()
+    state = (ck / "checkpoint").read_text()
+    assert 'model_checkpoint_path: "ckpt-9"' in state and state.count("all_model_checkpoint_paths") == 2 and not (ck / "checkpoint.tmp").exists()
     a = restored.validation_step(batches[0]).scalars_float
     b = model.validation_step(batches[0]).scalars_float
     assert a["bpp"] == b["bpp"] and a["psnr"] == b["psnr"]
