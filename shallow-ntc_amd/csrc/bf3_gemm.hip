@@ -14,7 +14,13 @@
 //  * LDS image of a stage: row-major [row][96 B]; the two 16-B halves of a plane are swapped on rows 8..15 (mod 16), applied on
 //    the SOURCE side (the DMA destination is linear), which makes the fragment ds_read_b128 conflict-free;
 //  * three ring slots: in step j the loads of stage j+2 go into the slot stage j-1 left, stage j multiplies, and the step ends
-//    once stage j+1 has landed (counted vmcnt) -- one barrier per 16-deep stage.
+//    once stage j+1 has landed (counted vmcnt) -- one barrier per 16-deep stage;
+//  * HALO instances (stride-1 sampling on a macro grid equal to the input grid: the 3x3 / 1 layer, the phase groups of the
+//    stride-2 transposed layers): the T taps of one 16-channel slab read the SAME activation rows shifted by whole pixels, so
+//    the workgroup stages ONE patch of BM + (th - 1) W + tw - 1 consecutive pixels per slab (two or three patch buffers) and
+//    only the weights per stage -- 142 KB instead of 324 KB per nine stages of the 480 -> 640 layer; a fragment row of tap
+//    (ty, tx) is patch row r + sy W + sx, zeroed in registers where the tap leaves the image (the loop then reaches the LDS
+//    read ceiling of the microbench: 280 against 232 TFLOP/s-equivalent at 256 x 128).
 //
 // Not bit-identical to the fp32 path (dropped terms ~2^-24 relative, other summation order inside an MFMA); the parity tests
 // hold it to the same 2e-5-vs-float64 bar.  Reference: the arithmetic of tf.nn.conv2d / conv2d_transpose behind
@@ -78,20 +84,24 @@ struct Piece {
 
 // (Tried: weight loads with the non-temporal hint, so that the activation rows the taps of a slab re-read would stay in the 32 KB
 // vector L1: 190 -> 178 TFLOP/s-equivalent on the 480 -> 640 layer, dropped.)
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool HALO, bool DBUF>
 __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int SLOT = (BM + BN) * 96;                    // bytes per ring slot
+  constexpr int P_R = kBf3PatchRounds;                    // HALO: a patch is at most P_R chunk rounds (426 rows at 512 threads)
+  constexpr int PAREA = HALO ? 2 * P_R * NT * 16 : 0;     // HALO: the patch buffers (two of <= P_R rounds or three of <= 3), 80 KB
+  constexpr int SLOT = (HALO ? BN : BM + BN) * 96;        // bytes per ring slot (HALO: weights only)
+  constexpr int NS = (HALO && DBUF) ? kBf3DeepRing : 3;   // ring slots
   constexpr int A_CH = BM * 6 / NT;                       // 16-B chunks of A per thread and stage
   constexpr int B_CH = (BN * 6 + NT - 1) / NT;            // of B (the last round may cover only the first waves)
   static_assert(BM * 6 % NT == 0, "A chunks must divide evenly over the threads");
   constexpr int EPW = 32 * 32;                            // floats of epilogue staging per wave (one 32 x 32 accumulator tile)
-  static_assert(SLOT >= NW * EPW * 4, "epilogue staging must fit in ring slot 2 (slots 0 and 1 take the next piece's first stages)");
+  static_assert(HALO || SLOT >= NW * EPW * 4, "epilogue staging must fit in ring slot 2 (slots 0 and 1 take the next piece's first stages)");
+  static_assert(!HALO || PAREA - P_R * NT * 16 >= NW * EPW * 4, "epilogue staging must fit behind the next piece's first patch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ring = smem;
-  int4* rinfo_all = reinterpret_cast<int4*>(smem + 3 * SLOT);     // [2][BM] (n, qy, qx, valid) of the current / next tile
+  char* ring = smem + PAREA;
+  int4* rinfo_all = reinterpret_cast<int4*>(smem + PAREA + NS * SLOT);     // [2][BM] (n, qy, qx, valid) of the current / next tile
   typedef __attribute__((address_space(3))) void lds_void;
 
   const int tid = threadIdx.x;
@@ -222,16 +232,19 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   __amdgpu_buffer_rsrc_t ws = xs;
   // chunk q = i * NT + tid of a stage lands at LDS byte 16 q (linear DMA destination): row q / 6, part q % 6 = (plane, half
   // position); the lane fetches the source half that belongs there: position ^ ((row >> 3) & 1)
-  int a_row[A_CH];
-  unsigned a_part[A_CH];              // byte offset of the lane's chunk inside the 96-B block of a (pixel, slab)
-  int a_iy0[A_CH], a_ix0[A_CH];
-  unsigned a_img[A_CH], a_off[A_CH];
+  constexpr int A_N = HALO ? 1 : A_CH;
+  int a_row[A_N];
+  unsigned a_part[A_N];               // byte offset of the lane's chunk inside the 96-B block of a (pixel, slab)
+  int a_iy0[A_N], a_ix0[A_N];
+  unsigned a_img[A_N], a_off[A_N];
   unsigned b_off[B_CH];
+  if (!HALO) {
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    const int q = i * NT + tid, row = q / 6, part = q - row * 6;
-    a_row[i] = row;
-    a_part[i] = (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4));
+    for (int i = 0; i < A_N; ++i) {
+      const int q = i * NT + tid, row = q / 6, part = q - row * 6;
+      a_row[i] = row;
+      a_part[i] = (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4));
+    }
   }
   int ld_stage = 0, ld_t = 0, ld_cc = 0, ld_ty = 0, ld_tx = 0, g_T = 1, g_tw = 1;
   int n0 = 0;
@@ -239,12 +252,24 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     int nb = 0;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) nb += (i * NT + wave * 64 < BN * 6) ? 1 : 0;
-    return nb;
+    return __builtin_amdgcn_readfirstlane(nb);
   }();
+  // HALO: the patch of one channel slab = pixels [tile's first pixel + dmin, ... + BM + span) of the flattened [N H W] input
+  constexpr int P_N = HALO ? P_R : 1;
+  unsigned p_off[P_N];                 // per chunk round: byte offset of the lane's chunk at slab 0, or out of range
+  int h_rounds = 0, h_pbytes = 0, h_nbufs = 2, h_th = 1;
+  int h_shift0 = 0, h_coljump = 1, h_rowjump = 1, h_zero96 = 0;   // tap walk in patch rows; byte offset of the patch's zero row
+  int rd_t = 0, rd_tx = 0, rd_shift = 0, rd_buf = 0;              // read pointer: tap, its column, its row shift, its slab's buffer
+  int r_row[TM];                       // the lane's fragment rows inside the tile
+  unsigned r_bits[TM];                 // bit t: tap t of the current group stays inside the image for that row
+#pragma unroll
+  for (int i = 0; i < TM; ++i) r_row[i] = (wm * TM + i) * 32 + l31;
+  int issued = 0;                      // DMA instructions this wave has issued for the current piece (the marks below count in it)
 
   auto set_tap = [&](int ty, int tx) {
+    if (HALO) return;
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
+    for (int i = 0; i < A_N; ++i) {
       const int iy = a_iy0[i] + ty * a.tstep;
       const int ix = a_ix0[i] + tx * a.tstep;
       const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -278,12 +303,55 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     g_tw = G.tw;
     ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.wp), 0, G.Ncol * G.K * 6, 0x00020000);
     n0 = p.nt * BN;
+    if (HALO) {
+      g_T = __builtin_amdgcn_readfirstlane(g_T);
+      g_tw = __builtin_amdgcn_readfirstlane(g_tw);
+      h_th = __builtin_amdgcn_readfirstlane(g_T / g_tw);
+      const int W = a.W, H = a.H, ts = a.tstep;
+      const int prows = BM + (h_th - 1) * W + g_tw - 1;
+      const int zrow = g_T > 1 ? 1 : 0;                                          // the zero row behind the patch (a 1-tap group never needs it)
+      h_rounds = __builtin_amdgcn_readfirstlane(((prows + zrow) * 6 + NT - 1) / NT);      // <= P_R (host check)
+      h_pbytes = h_rounds * NT * 16;
+      h_nbufs = h_rounds * 3 <= 2 * P_R ? 3 : 2;
+      h_zero96 = prows * 96;
+      h_coljump = ts;
+      h_rowjump = ts * (W - g_tw + 1);
+      h_shift0 = ts < 0 ? (h_th - 1) * W + g_tw - 1 : 0;
+      // tap (ty, tx) of row m reads pixel m + (q0y + offy + ty tstep) W + q0x + offx + tx tstep (sA = 1, macro grid = input grid)
+      const int dmin = (G.q0y + a.offy - (ts < 0 ? h_th - 1 : 0)) * W + G.q0x + a.offx - (ts < 0 ? g_tw - 1 : 0);
+      const int gbase = p.mt * BM + dmin;
+      const unsigned total = (unsigned)(a.N * H * W);
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int4 ri = rinfo[a_row[i]];
-      a_iy0[i] = ri.y * a.sA + a.offy;
-      a_ix0[i] = ri.z * a.sA + a.offx;
-      a_img[i] = ri.w ? (unsigned)ri.x * (unsigned)(a.H * a.W) * (unsigned)a.Cin * 6u + a_part[i] : kOOR;
+      for (int i = 0; i < P_N; ++i) {
+        const int q = i * NT + tid, row = q / 6, part = q - row * 6;
+        const int gp = gbase + row;
+        const bool ok = row < prows && (unsigned)gp < total;
+        p_off[i] = ok ? (unsigned)gp * (unsigned)a.Cin * 6u + (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4)) : kOOR;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int4 ri = rinfo[r_row[i]];
+        unsigned bits = 0;
+        if (g_T == 1) {
+          bits = 1u;                        // rows past M read rows past the input: zero-filled by the DMA
+        } else if (ri.w) {
+          int t = 0;
+          for (int ty = 0; ty < h_th; ++ty)
+            for (int tx = 0; tx < g_tw; ++tx, ++t) {
+              const bool ok = (unsigned)(ri.y + a.offy + ty * ts) < (unsigned)H && (unsigned)(ri.z + a.offx + tx * ts) < (unsigned)W;
+              bits |= (ok ? 1u : 0u) << t;
+            }
+        }
+        r_bits[i] = bits;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_N; ++i) {
+        const int4 ri = rinfo[a_row[i]];
+        a_iy0[i] = ri.y * a.sA + a.offy;
+        a_ix0[i] = ri.z * a.sA + a.offx;
+        a_img[i] = ri.w ? (unsigned)ri.x * (unsigned)(a.H * a.W) * (unsigned)a.Cin * 6u + a_part[i] : kOOR;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {   // rows past Ncol re-read the last column (finite, discarded)
@@ -291,34 +359,52 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
       const int brow = min(n0 + row, G.Ncol - 1);
       b_off[i] = (unsigned)brow * (unsigned)(G.K / kStage) * 96u + (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4));
     }
-    ld_stage = p.k0;
-    ld_cc = p.k0 / g_T;
-    ld_t = p.k0 - ld_cc * g_T;
-    ld_ty = ld_t / g_tw;
+    ld_stage = __builtin_amdgcn_readfirstlane(p.k0);
+    ld_cc = __builtin_amdgcn_readfirstlane(p.k0 / g_T);
+    ld_t = ld_stage - ld_cc * g_T;
+    ld_ty = __builtin_amdgcn_readfirstlane(ld_t / g_tw);
     ld_tx = ld_t - ld_ty * g_tw;
     set_tap(ld_ty, ld_tx);
+  };
+  auto issue_b = [&](int slot) {                // this wave's share of one stage of weights
+    const unsigned wsoff = (unsigned)__builtin_amdgcn_readfirstlane(ld_stage) * 96u;
+    char* bb = ring + slot * SLOT + wave * 1024 + (HALO ? 0 : BM * 96);
+    if (!SNTC_DBG(a, 1)) {
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i)
+        if ((BN * 6) % NT == 0 || i * NT + wave * 64 < BN * 6)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(bb + i * NT * 16), 16, (int)b_off[i], (int)wsoff, 0, 0);
+    }
+    issued += my_b;
   };
   auto issue = [&](int slot) {                  // this wave's share of one stage, L2 / HBM -> LDS
     char* base = ring + slot * SLOT + wave * 1024;
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(ld_cc) * 96u;
+    if (!HALO) {
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(base + i * NT * 16), 16, (int)a_off[i], (int)soff, 0, 0);
-    const unsigned wsoff = (unsigned)__builtin_amdgcn_readfirstlane(ld_stage) * 96u;
-    char* bb = base + BM * 96;
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i)
-      if ((BN * 6) % NT == 0 || i * NT + wave * 64 < BN * 6)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(bb + i * NT * 16), 16, (int)b_off[i], (int)wsoff, 0, 0);
+      for (int i = 0; i < A_N; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(base + i * NT * 16), 16, (int)a_off[i], (int)soff, 0, 0);
+    }
+    issue_b(slot);
     // next stage: channel slab outermost, taps inside (k = cc * T * 16 + t * 16 + c), branch-free
     ++ld_stage;
-    const int row_end = (ld_tx + 1 == g_tw) ? 1 : 0;
-    const int tap_end = (ld_t + 1 == g_T) ? 1 : 0;
-    ld_tx = row_end ? 0 : ld_tx + 1;
-    ld_ty = tap_end ? 0 : ld_ty + row_end;
-    ld_t = tap_end ? 0 : ld_t + 1;
-    ld_cc += tap_end;
-    set_tap(ld_ty, ld_tx);
+    if (!HALO) {
+      const int row_end = (ld_tx + 1 == g_tw) ? 1 : 0;
+      const int tap_end = (ld_t + 1 == g_T) ? 1 : 0;
+      ld_tx = row_end ? 0 : ld_tx + 1;
+      ld_ty = tap_end ? 0 : ld_ty + row_end;
+      ld_t = tap_end ? 0 : ld_t + 1;
+      ld_cc += tap_end;
+      set_tap(ld_ty, ld_tx);
+    }
+  };
+  auto issue_patch = [&](int cc, int buf) {     // HALO: this wave's share of the patch of channel slab cc
+    char* base = smem + buf * h_pbytes + wave * 1024;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(cc) * 96u;
+#pragma unroll
+    for (int i = 0; i < P_N; ++i)
+      if (i < h_rounds && !SNTC_DBG(a, 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(base + i * NT * 16), 16, (int)p_off[i], (int)soff, 0, 0);
+    issued += h_rounds;
   };
   // leave at most `stages` of this wave's stages in flight
   auto wait_stages = [&](auto S) {
@@ -331,11 +417,39 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(s * (A_CH + B_CH - 1)) : "memory");
     }
   };
+  // HALO: leave at most n of this wave's DMA instructions in flight (n is wave-uniform)
+  // (a jump into a table of s_waitcnt: the compiler turns a switch / an if-tree over thirteen asm statements into ~50 scalar
+  // instructions of flag juggling per call, and this runs once per 16-deep stage)
+  auto wait_vm = [&](int n) {
+    const int off = min(n, 12) * 8 + 12;       // table entry = s_waitcnt + s_branch; 12 bytes from the s_getpc result to the table
+    asm volatile(
+        "s_getpc_b64 s[94:95]\n"
+        "s_add_u32 s94, s94, %0\n"
+        "s_addc_u32 s95, s95, 0\n"
+        "s_setpc_b64 s[94:95]\n"
+        "s_waitcnt vmcnt(0)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(1)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(2)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(3)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(4)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(5)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(6)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(7)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(8)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(9)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(10)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(11)\n s_branch .Lvm_done%=\n"
+        "s_waitcnt vmcnt(12)\n"
+        ".Lvm_done%=:\n"
+        :
+        : "s"(off)
+        : "memory", "s94", "s95", "scc");
+  };
 
   // ---------------------------------------------------------------- fragments + MFMA
   const int hoff = (h ^ ((l31 >> 3) & 1)) << 4;
   const int fa = (wm * TM * 32 + l31) * 96 + hoff;
-  const int fb = (BM + wn * TN * 32 + l31) * 96 + hoff;
+  const int fb = ((HALO ? 0 : BM) + wn * TN * 32 + l31) * 96 + hoff;
   struct Frag {
     bf16x8 a[3][TM];
     bf16x8 b[3][TN];
@@ -348,6 +462,35 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
       for (int i = 0; i < TM; ++i) F.a[p][i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 32 * 96 + p * 32);
 #pragma unroll
       for (int j = 0; j < TN; ++j) F.b[p][j] = *reinterpret_cast<const bf16x8*>(base + fb + j * 32 * 96 + p * 32);
+    }
+  };
+  // HALO: the fragments of the stage the read pointer (rd_buf, rd_t, rd_shift) stands on.  A row of tap t is patch row
+  // r + shift(t); where the tap leaves the image for that row (bit t of r_bits clear) the lane reads the patch's zero row instead
+  auto read_frag_halo = [&](Frag& F, int slot) {
+    const int pbo = rd_buf * h_pbytes;
+    const char* base = ring + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int prow = r_row[i] + rd_shift;
+      int off = prow * 96 + ((h ^ ((prow >> 3) & 1)) << 4);
+      off = ((r_bits[i] >> rd_t) & 1u) ? off : h_zero96;
+      const char* src = smem + pbo + off;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.a[p][i] = *reinterpret_cast<const bf16x8*>(src + p * 32);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) F.b[p][j] = *reinterpret_cast<const bf16x8*>(base + fb + j * 32 * 96 + p * 32);
+  };
+  auto advance_read = [&](bool slab_end) {
+    if (slab_end) {
+      rd_t = 0; rd_tx = 0; rd_shift = h_shift0;
+      rd_buf = rd_buf + 1 == h_nbufs ? 0 : rd_buf + 1;
+    } else {
+      ++rd_t;
+      if (++rd_tx == g_tw) { rd_tx = 0; rd_shift += h_rowjump; }
+      else rd_shift += h_coljump;
     }
   };
   f32x16 acc[TM][TN];
@@ -366,15 +509,49 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
+  // HALO pipeline state.  Marks are values of `issued` right after a group of loads went out; a load has landed once at most
+  // issued - mark younger instructions are in flight (vector memory returns in order).
+  int mBc = 0, mBn = 0, mBn2 = 0;      // weights of the current / next / next-but-one stage
+  int mPc = 0, mP1 = 0, mP2 = 0;       // patch of the current / next / next-but-one slab
+  int nP = 0, nP_buf = 0, c_last = 0;  // next slab to stage, its buffer, the piece's last slab
+  int pm[NS - 1];                      // marks of the weights the prologue issued (stages 0 .. NS - 2)
+  // first loads of a piece: (HALO) the patches of its first slabs, then the first NS - 1 stages' weights (ring slots 0 ...)
+  auto start_piece = [&](const Piece& p, int rb) {
+    init_loader(p, rb);
+    const int n = __builtin_amdgcn_readfirstlane(p.k1 - p.k0);
+    if (HALO) {
+      issued = 0;
+      const int c0 = ld_cc;
+      c_last = __builtin_amdgcn_readfirstlane((p.k1 - 1) / g_T);
+      rd_t = ld_t; rd_tx = ld_tx; rd_buf = 0;
+      rd_shift = h_shift0 + ld_ty * (h_rowjump + (g_tw - 1) * h_coljump) + ld_tx * h_coljump;
+      issue_patch(c0, 0);
+      mPc = issued;
+      if (h_nbufs == 3 && c0 + 1 <= c_last) issue_patch(c0 + 1, 1);
+      mP1 = issued;
+      mP2 = issued;
+      nP = c0 + h_nbufs - 1;
+      nP_buf = h_nbufs - 1;
+#pragma unroll
+      for (int q = 0; q < NS - 1; ++q) {                   // weights of the first NS - 1 stages
+        if (q < n) issue(q);
+        pm[q] = issued;
+      }
+      mBc = pm[0];
+      mBn = pm[1];
+    } else {
+      if (n > 0) issue(0);
+      if (n > 1) issue(1);
+    }
+  };
+
   // ---------------------------------------------------------------- the piece loop
   int rb = 0;
   write_rinfo(P, rb);
   __syncthreads();
-  init_loader(P, rb);
-  if (P.k1 - P.k0 > 0) issue(0);
-  if (P.k1 - P.k0 > 1) issue(1);
+  start_piece(P, rb);
   while (true) {
-    const int n = P.k1 - P.k0;
+    const int n = __builtin_amdgcn_readfirstlane(P.k1 - P.k0);
     if (P.consume >= 0) {
       if (tid == 0) {
         int spins = 0;
@@ -410,34 +587,155 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
 
-    // stage 0 must have landed before the first step; stage 1 may still fly.  (Everything older than the two stage issues --
-    // the previous piece's epilogue stores were issued AFTER them -- only makes this wait longer, never shorter.)
-    if (n > 1) wait_stages(I1{});
-    else wait_stages(I0{});
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-
     Frag F;
     int s_cur = 0, s_n1 = 1, s_n2 = 2;
-    auto step = [&](auto LD, auto MORE) {
-      if (decltype(LD)::value) issue(s_n2);              // stage j+2 into the slot stage j-1 left at the last barrier
-      read_frag(F, s_cur);
-      mfma6(F);
+    if (HALO && DBUF) {
+      // Fragments double-buffered: step j multiplies stage j from registers while it READS stage j+1 and the DMA fills the
+      // slot stage j left with stage j+3 (step -1 only reads).  A wave issues in order and its 24 MFMAs of a stage keep the
+      // matrix pipe busy for 768 cycles: everything else a step does (DMA issue, fragment addresses and reads, tap masks, the
+      // pipeline bookkeeping) is spread BETWEEN the six MFMA groups so that it issues in their shadow instead of after them
+      // (with the bookkeeping behind the MFMAs the loop ran at 0.70 of the microbench's rate).
+      // Stage 0's weights and its slab's patch must have landed first.  (Everything younger that is not counted in `issued`
+      // -- the previous piece's epilogue stores, the hand-off loads above -- only makes a wait longer, never shorter.)
+      Frag G;
+      wait_vm(issued - max(mBc, mPc));
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // stage j+1 has landed; stage j+2 (issued above) may still fly
-      if (decltype(LD)::value) wait_stages(I1{});
+      int mq[NS - 2];                                      // marks of the weights of stages j+2 ... j+NS-1
+#pragma unroll
+      for (int q = 0; q < NS - 2; ++q) mq[q] = pm[q + 1];
+      int s_rd = 0, s_is = NS - 1;                         // ring slot of the stage being read (j+1) / of stage j: free, takes stage j+NS
+      auto mf = [&](const Frag& Fc, auto T_) {             // the TM x TN MFMAs of one of the six cross terms
+        constexpr int t = decltype(T_)::value;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        if (!SNTC_DBG(a, 64)) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j2 = 0; j2 < TN; ++j2)
+              acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Fc.a[PA[t]][i], Fc.b[PB[t]][j2], acc[i][j2], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+      using T3 = std::integral_constant<int, 3>; using T4 = std::integral_constant<int, 4>; using T5 = std::integral_constant<int, 5>;
+      auto step = [&](auto EDGE_, int j, Frag& Fc, Frag& Fn) {
+        constexpr bool EDGE = decltype(EDGE_)::value;      // first / last steps of a piece: some of the parts below are absent
+        const bool mm = !EDGE || j >= 0, rd = !EDGE || j + 1 < n;
+        if (!EDGE || j + NS < n) issue(s_is);
+        const int mnew = issued;
+        __builtin_amdgcn_sched_barrier(0);
+        if (mm) mf(Fc, T0{});
+        if (rd && ((EDGE && j < 0) || rd_t == 0) && nP <= c_last) {   // reading a slab's first stage: its predecessor's buffer is free
+          issue_patch(nP, nP_buf);
+          if (h_nbufs == 3) mP2 = issued;
+          else mP1 = issued;
+          ++nP;
+          nP_buf = nP_buf + 1 == h_nbufs ? 0 : nP_buf + 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mm) mf(Fc, T1{});
+        if (rd && (!SNTC_DBG(a, 8) || j < 1)) read_frag_halo(Fn, s_rd);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mm) { mf(Fc, T2{}); mf(Fc, T3{}); }
+        const bool slab_end = rd && rd_t + 1 == g_T;
+        const int need = slab_end ? max(mq[0], mP1) : mq[0];
+        const int allowed = issued - need;
+        s_rd = s_rd + 1 == NS ? 0 : s_rd + 1;
+        s_is = s_is + 1 == NS ? 0 : s_is + 1;
+#pragma unroll
+        for (int q = 0; q + 1 < NS - 2; ++q) mq[q] = mq[q + 1];
+        mq[NS - 3] = mnew;
+        if (rd) {
+          advance_read(slab_end);
+          if (slab_end) mP1 = mP2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mm) { mf(Fc, T4{}); mf(Fc, T5{}); }
+        if (!EDGE || j + 2 < n) {
+          // stage j+2's weights -- and its patch, if it opens the next slab -- have landed; younger loads may still fly
+          wait_vm(allowed);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!SNTC_DBG(a, 4)) __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using Edge = std::integral_constant<bool, true>;
+      using Fast = std::integral_constant<bool, false>;
+      int j = -1;
+      step(Edge{}, j, G, F);                               // reads stage 0 into F
+      for (j = 0; j + NS + 1 < n; j += 2) {
+        step(Fast{}, j, F, G);
+        step(Fast{}, j + 1, G, F);
+      }
+      for (; j < n; j += 2) {
+        step(Edge{}, j, F, G);
+        if (j + 1 < n) step(Edge{}, j + 1, G, F);
+      }
+    } else if (HALO) {
+      // stage 0's weights and its slab's patch must have landed.  (Everything younger that is not counted in `issued` -- the
+      // previous piece's epilogue stores, the hand-off loads above -- only makes a wait longer, never shorter.)
+      wait_vm(issued - max(mBc, mPc));
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < n; ++j) {
+        if (j + 2 < n) {                                   // weights of stage j+2 into the slot stage j-1 left at the last barrier
+          issue(s_n2);
+          mBn2 = issued;
+        }
+        if ((j == 0 || rd_t == 0) && nP <= c_last) {       // first stage of a slab: the patch of slab + (buffers - 1) into the
+          issue_patch(nP, nP_buf);                         // buffer the previous slab left at the last barrier
+          if (h_nbufs == 3) mP2 = issued;
+          else mP1 = issued;
+          ++nP;
+          nP_buf = nP_buf + 1 == h_nbufs ? 0 : nP_buf + 1;
+        }
+        read_frag_halo(F, s_cur);
+        mfma6(F);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool slab_end = rd_t + 1 == g_T;
+        if (j + 1 < n) {
+          // stage j+1's weights -- and its patch, if it opens the next slab -- have landed; younger loads may still fly
+          const int need = slab_end ? max(mBn, mP1) : mBn;
+          wait_vm(issued - need);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = s_cur; s_cur = s_n1; s_n1 = s_n2; s_n2 = t;
+        mBn = mBn2;
+        advance_read(slab_end);
+        if (slab_end) { mPc = mP1; mP1 = mP2; }
+      }
+    } else {
+      // stage 0 must have landed before the first step; stage 1 may still fly.  (Everything older than the two stage issues --
+      // the previous piece's epilogue stores were issued AFTER them -- only makes this wait longer, never shorter.)
+      if (n > 1) wait_stages(I1{});
       else wait_stages(I0{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (decltype(MORE)::value) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      const int t = s_cur; s_cur = s_n1; s_n1 = s_n2; s_n2 = t;
-    };
-    using Yes = std::integral_constant<bool, true>;
-    using No = std::integral_constant<bool, false>;
-    int j = 0;
-    for (; j + 2 < n; ++j) step(Yes{}, Yes{});
-    if (n - j == 2) { step(No{}, Yes{}); ++j; }
-    if (n - j == 1) { step(No{}, No{}); ++j; }
+
+      auto step = [&](auto LD, auto MORE) {
+        if (decltype(LD)::value) issue(s_n2);              // stage j+2 into the slot stage j-1 left at the last barrier
+        read_frag(F, s_cur);
+        mfma6(F);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage j+1 has landed; stage j+2 (issued above) may still fly
+        if (decltype(LD)::value) wait_stages(I1{});
+        else wait_stages(I0{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (decltype(MORE)::value) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = s_cur; s_cur = s_n1; s_n1 = s_n2; s_n2 = t;
+      };
+      using Yes = std::integral_constant<bool, true>;
+      using No = std::integral_constant<bool, false>;
+      int j = 0;
+      for (; j + 2 < n; ++j) step(Yes{}, Yes{});
+      if (n - j == 2) { step(No{}, Yes{}); ++j; }
+      if (n - j == 1) { step(No{}, No{}); ++j; }
+    }
 
     // ---- the next piece's first two stages go in flight (ring slots 0 and 1) before this piece's results are stored
     Piece Q;
@@ -448,9 +746,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     if (more) {
       write_rinfo(Q, rb ^ 1);
       __syncthreads();
-      init_loader(Q, rb ^ 1);
-      if (Q.k1 - Q.k0 > 0) issue(0);
-      if (Q.k1 - Q.k0 > 1) issue(1);
+      start_piece(Q, rb ^ 1);
     }
 
     // ---- finish the piece that just ran
@@ -478,7 +774,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     } else {
       // each wave transposes one 32 x 32 accumulator tile at a time through a private 4 KB slice of ring slot 2, so that a
       // lane owns 4 consecutive channels of one pixel (16-B bias / residual reads and stores)
-      float* stage = reinterpret_cast<float*>(ring + 2 * SLOT) + wave * EPW;
+      // (HALO: of the tail of the patch area, behind the next piece's first patches)
+      float* stage = reinterpret_cast<float*>(HALO ? smem + PAREA - NW * EPW * 4 : ring + 2 * SLOT) + wave * EPW;
       const int c4 = (lane & 7) << 2;
       const int rsub = lane >> 3;
 #pragma unroll
@@ -558,10 +855,10 @@ __global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------
 // variants + launch (ids continue csrc/gather_gemm.hip's: 11 = 256 x 256, 12 = 256 x 128; both 512 threads, one workgroup per CU)
 // ---------------------------------------------------------------------------------------------
-static const void* bf3p_kernel(int v) {
+static const void* bf3p_kernel(int v, bool halo) {
   switch (v) {
-    case 11: return reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4>);
-    case 12: return reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2>);
+    case 11: return halo ? reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4, true, false>) : reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4, false, false>);
+    case 12: return halo ? reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2, true, true>) : reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2, false, false>);
     default: return nullptr;
   }
 }
@@ -570,7 +867,12 @@ int bf3p_variant_bm(int v) { return 256; }
 int bf3p_variant_bn(int v) { return v == 11 ? 256 : 128; }
 size_t bf3p_sk_slab_floats(int v) { return (size_t)(v == 11 ? 8 : 4) * 16 * 512; }
 
-static size_t bf3p_lds_bytes(int v) { return (size_t)3 * (bf3p_variant_bm(v) + bf3p_variant_bn(v)) * 96 + 2 * bf3p_variant_bm(v) * sizeof(int4); }
+static size_t bf3p_lds_bytes(int v, bool halo) {
+  const size_t rinfo = 2 * bf3p_variant_bm(v) * sizeof(int4);
+  if (halo) return (size_t)2 * kBf3PatchRounds * 512 * 16 + (size_t)(v == 12 ? kBf3DeepRing : 3) * bf3p_variant_bn(v) * 96 + rinfo;
+  return (size_t)3 * (bf3p_variant_bm(v) + bf3p_variant_bn(v)) * 96 + rinfo;
+}
+int bf3p_patch_rows_max() { return kBf3PatchRounds * 512 / 6; }
 
 static std::once_flag g_bf3p_once[16];
 static int g_bf3p_rc[16];
@@ -581,22 +883,27 @@ int bf3p_init() {
   if (dev < 0 || dev >= 16) return fail(SNTC_ERR_UNSUPPORTED, "device index beyond the residency tables");
   std::call_once(g_bf3p_once[dev], [&] {
     g_bf3p_rc[dev] = SNTC_OK;
-    for (int v : {11, 12}) {
-      hipError_t e = hipFuncSetAttribute(bf3p_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf3p_lds_bytes(v));
-      if (e != hipSuccess) g_bf3p_rc[dev] = hip_fail(e, "bf3p_init");
-    }
+    for (int v : {11, 12})
+      for (bool halo : {false, true}) {
+        hipError_t e = hipFuncSetAttribute(bf3p_kernel(v, halo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf3p_lds_bytes(v, halo));
+        if (e != hipSuccess) g_bf3p_rc[dev] = hip_fail(e, "bf3p_init");
+      }
   });
   return g_bf3p_rc[dev];
 }
 
 int bf3p_launch(int variant, const GGArgs& args, int nblocks, hipStream_t stream) {
-  const void* fn = bf3p_kernel(variant);
+  const bool halo = args.halo != 0;
+  const void* fn = bf3p_kernel(variant, halo);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown pre-split bf16 x 3 tile variant");
   int rc = bf3p_init();
   if (rc) return rc;
   GGArgs a = args;
+#ifdef SNTC_DIAG
+  if (const char* e = getenv("SNTC_GG_DBG")) a.dbg = atoi(e);   // diagnostic builds only (make DIAG=1): results are WRONG with it
+#endif
   void* params[] = {&a};
-  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(512), params, bf3p_lds_bytes(variant), stream);
+  hipError_t e = hipLaunchKernel(fn, dim3(nblocks), dim3(512), params, bf3p_lds_bytes(variant, halo), stream);
   if (e != hipSuccess) return hip_fail(e, "pre-split bf16 x 3 gather-GEMM launch");
   return SNTC_OK;
 }

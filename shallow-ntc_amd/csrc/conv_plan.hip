@@ -148,6 +148,7 @@ struct sntc_conv_plan {
   int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
   bool force_stream_k = false;  // ignore the short-tile rule: stream-K wherever the launch is large enough (tests)
+  bool no_halo = false;     // pre-split plans: stage every tap's activation rows separately even where one patch per slab would do (A/B)
   float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (fusable_second plans only)
 };
 
@@ -172,6 +173,7 @@ extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int flags) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_schedule: null plan");
   p->no_stream_k = (flags & 1) == 0;
   p->force_stream_k = (flags & 8) != 0;
+  p->no_halo = (flags & 16) != 0;
   p->dma = (flags & 4) ? ((flags & 2) ? 1 : 0) : -1;      // bit 2: "bit 1 is meaningful"; bit 1: direct-to-LDS staging on / off
   return SNTC_OK;
 }
@@ -605,7 +607,9 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
       const double rounds = (double)tiles / cus;
       cost *= rounds < 1.0 ? 1.0 / rounds : std::ceil(rounds) / rounds;
     }
-    cost /= (v == 11 ? 1.0 : 0.84);          // measured loop rates, tools/microbench/gemm_ceiling.hip: 276 vs 232 TFLOP/s-equivalent
+    // measured on the 480 -> 640 layer, padding aside: 256 x 128 (fragments double-buffered, bookkeeping inside the MFMA shadows)
+    // 225 TFLOP/s-equivalent, 256 x 256 (single fragment set: 128 accumulators leave no room for a second) 245 on its padded tile
+    cost /= (v == 11 ? 1.0 : 0.92);
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
@@ -777,6 +781,15 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   a.ups = (int)unit0;
   if (p->s3) {
     a.order = p->dma == 0 ? 1 : 0;        // sntc_conv_plan_set_schedule's stage-path bit doubles as the unit-order A/B switch here
+    // patch staging: the taps of a slab sample the input at unit stride on a macro grid that IS the input grid, and every
+    // group's patch (tile rows + the tap window's reach in flattened pixels + a zero row) fits the patch buffers; <= 32 taps (the
+    // kernel keeps one validity bit per tap and row)
+    bool halo = !p->no_halo && g.sA == 1 && g.Qh == h && g.Qw == w;
+    for (int gi = 0; halo && gi < p->ngroups; ++gi) {
+      const int th = p->g[gi].T / p->g[gi].tw;
+      halo = p->g[gi].T <= 32 && bm + (th - 1) * w + p->g[gi].tw - 1 + (p->g[gi].T > 1 ? 1 : 0) <= bf3p_patch_rows_max();
+    }
+    a.halo = halo ? 1 : 0;
     return bf3p_launch(v, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
   }
   rc = gg_launch(v, p->vec, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);

@@ -86,6 +86,8 @@ struct GGArgs {
   int Cout2;
   int dma;             // 1: direct-to-LDS staging (buffer_load ... lds, four ring slots) where the instantiation exists
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
+  int halo;            // bf3_gemm.hip: 1 = patch staging (one activation patch per channel slab shared by its taps); needs sA == 1,
+                       // Qh == H, Qw == W and every group's patch within bf3p_patch_rows_max()
   int order;           // bf3_gemm.hip stream-K unit order: 0 column tile outermost (default), 1 strip-major (as gather_gemm.hip)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
                        // 8 skip fragment reads, 16 skip the epilogue's stores, 32 its residual loads, 64 the MFMAs, 128 the fused
@@ -112,6 +114,9 @@ int gg_resident_blocks_bf3(int variant);                    // same for the bf16
 size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off
 
 // ---- pre-split bf16 x 3 gather GEMM (bf3_gemm.hip): variants 11 (256 x 256) and 12 (256 x 128), 512 threads, one workgroup per CU
+constexpr int kBf3PatchRounds = 5;     // patch staging: at most 5 rounds of 512 16-B chunks = 426 rows of 96 B
+constexpr int kBf3DeepRing = 3;        // weight ring slots of the patch-staging 256 x 128 instance (fragments double-buffered)
+int bf3p_patch_rows_max();
 int bf3p_variant_bm(int v);
 int bf3p_variant_bn(int v);
 size_t bf3p_sk_slab_floats(int v);

@@ -160,11 +160,12 @@ class ConvPlan:
         """Force this plan's gather-GEMM tile variant (0 = heuristic); profiling / tests."""
         capi.call("sntc_conv_plan_set_tile", self._h, int(variant))
 
-    def set_stream_k(self, enabled, dma=None, force=False):
+    def set_stream_k(self, enabled, dma=None, force=False, halo=True):
         """``enabled`` False forces the static one-workgroup-per-tile schedule for this plan; ``dma`` True / False forces the
         direct-to-LDS / register stage path (None: library default); ``force``: stream-K even where the default picks one
-        workgroup per tile because the tiles are short.  Tests: identical bits every way."""
-        flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0))) | (8 if force else 0)
+        workgroup per tile because the tiles are short; ``halo`` False (pre-split plans): stage every tap's activation rows
+        separately instead of one patch per channel slab.  Tests: identical bits every way."""
+        flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0))) | (8 if force else 0) | (0 if halo else 16)
         capi.call("sntc_conv_plan_set_schedule", self._h, flags)
 
     def fusable_with(self, second):

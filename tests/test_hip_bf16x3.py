@@ -71,8 +71,9 @@ CASES = [  # kind, k, s, cin, cout, n, h, w, act, epilogue
 
 @pytest.mark.parametrize("kind,k,s,cin,cout,n,h,w,act,epi", CASES)
 def test_presplit_kernel_against_float64(kind, k, s, cin, cout, n, h, w, act, epi, dev):
-    """Pre-split plan == float64 oracle to the fp32 path's own accuracy, for both tile shapes, static and stream-K schedules
-    (bit-identical to each other: every output is the same chain of MFMA terms), and image-alone == image-in-batch."""
+    """Pre-split plan == float64 oracle to the fp32 path's own accuracy, for both tile shapes, static and stream-K schedules,
+    patch and per-tap staging (bit-identical to each other: every output is the same chain of MFMA terms), and image-alone ==
+    image-in-batch."""
     from shallow_ntc_amd import _capi as capi
     from shallow_ntc_amd import ops
     rng = np.random.default_rng(k * 100 + cin + cout)
@@ -98,12 +99,12 @@ def test_presplit_kernel_against_float64(kind, k, s, cin, cout, n, h, w, act, ep
     outs = []
     for variant in (11, 12):
         ps.set_tile(variant)
-        for sk in (True, False):
-            ps.set_stream_k(sk, force=sk)
+        for sk, halo in ((True, True), (False, True), (True, False), (False, False)):
+            ps.set_stream_k(sk, force=sk, halo=halo)      # halo: one activation patch per channel slab where the geometry allows
             y = ps(xs, res=rd)
             outs.append(y)
             e3 = rel_err(y.cpu().numpy(), ref)
-            assert e3 < 5e-6 and e3 < 4 * e32 + 2e-7, (variant, sk, e3, e32)
+            assert e3 < 5e-6 and e3 < 4 * e32 + 2e-7, (variant, sk, halo, e3, e32)
     for y in outs[1:]:
         assert torch.equal(y, outs[0])
     ps.set_tile(0)
@@ -129,7 +130,8 @@ def test_presplit_plan_limits(dev):
 
 def test_stream_k_chain_at_full_width(dev):
     """The real 480 -> 640 hyper-synthesis layer at Kodak batch size: stream-K (256 workers, every tile cut between two of
-    them) == one workgroup per tile, bit for bit, for both tiles; and the sticky status word stays clear."""
+    them) == one workgroup per tile, patch staging == per-tap staging, bit for bit, for both tiles; and the sticky status word
+    stays clear."""
     from shallow_ntc_amd import ops
     g = torch.Generator(device=dev)
     g.manual_seed(3)
@@ -142,8 +144,8 @@ def test_stream_k_chain_at_full_width(dev):
     outs = []
     for variant in (11, 12):
         ps.set_tile(variant)
-        for sk in (True, False):
-            ps.set_stream_k(sk, force=sk)
+        for sk, halo in ((True, True), (False, True), (True, False), (False, False)):
+            ps.set_stream_k(sk, force=sk, halo=halo)
             outs.append(ps(xs))
     for y in outs[1:]:
         assert torch.equal(y, outs[0])

@@ -266,6 +266,136 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) loop_bf3
   if (s == 12345.678f) out[0] = s;
 }
 
+
+// A-halo reuse (stride-1 k x k layers): the TAPS taps of one 16-channel slab read the SAME activation rows shifted by whole
+// pixels, so the block stages one patch of BM + EXTRA rows per slab (double-buffered) and only the weights per stage.
+template <int WM, int WN, int TM, int TN, bool DBUF, int TAPS, int EXTRA>
+__global__ void __launch_bounds__(WM * WN * 64, 2) loop_bf3_halo(const float* __restrict__ src, float* out, int stages, unsigned src_bytes, unsigned) {
+  constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32, PROWS = BM + EXTRA, PBYTES = PROWS * 96, BBYTES = BN * 96;
+  constexpr int CHA = (PROWS * 6 + NT - 1) / NT, CHB = (BN * 6 + NT - 1) / NT;
+  constexpr int MINA = (PROWS * 6) / NT, MINB = (BN * 6) / NT;
+  extern __shared__ __attribute__((aligned(16))) char ringb[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, 0x00020000);
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_x = (gridDim.x + 7) >> 3;
+  const int nt = idx % 5, mt = xcd * ((per_x + 4) / 5) + idx / 5;
+  const unsigned strideA = 2880u, strideB = 25920u, baseB = 96u << 20;
+  unsigned offA[CHA], offB[CHB];
+#pragma unroll
+  for (int i = 0; i < CHA; ++i) {
+    const int q = i * NT + tid, row = q / 6, part = q % 6, p = part >> 1, hs = (part & 1) ^ ((row >> 3) & 1);
+    offA[i] = (unsigned)(((unsigned long long)(mt * BM + row) * strideA) & (src_bytes - 1)) + p * 32 + hs * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < CHB; ++i) {
+    const int q = i * NT + tid, row = q / 6, part = q % 6, p = part >> 1, hs = (part & 1) ^ ((row >> 3) & 1);
+    offB[i] = (unsigned)((baseB + (unsigned long long)(nt * BN + row) * strideB) & (src_bytes - 1)) + p * 32 + hs * 16;
+  }
+  char* const patch = ringb;
+  char* const bring = ringb + 2 * PBYTES;
+  unsigned slabA = 0, slabB = 0;
+  auto issueA = [&](int buf) {
+    char* base = patch + buf * PBYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < CHA; ++i)
+      if ((PROWS * 6) % NT == 0 || (i * NT + wave * 64) < PROWS * 6)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + i * NT * 16), 16, (int)((offA[i] + slabA) & (src_bytes - 1)), 0, 0, 0);
+    slabA += 96u;
+    if (slabA + 96u > strideA) slabA = 0;
+  };
+  auto issueB = [&](int slot) {
+    char* base = bring + slot * BBYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < CHB; ++i)
+      if ((BN * 6) % NT == 0 || (i * NT + wave * 64) < BN * 6)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + i * NT * 16), 16, (int)((offB[i] + slabB) & (src_bytes - 1)), 0, 0, 0);
+    slabB += 96u;
+    if (slabB + 96u > strideB) slabB = 0;
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  struct Fr { bf16x8 a[3][TM], b[3][TN]; };
+  Fr F0, F1;
+  const int hoffB = (h ^ ((l31 >> 3) & 1)) << 4;
+  auto rd = [&](Fr& F, int slot, int buf, int tap) {
+    const char* pb = patch + buf * PBYTES;
+    const char* bb = bring + slot * BBYTES;
+    const int shift = (tap / 3) * 48 + tap % 3;        // a 3 x 3 window on a 48-pixel-wide map
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int prow = wm * TM * 32 + i * 32 + l31 + shift;
+        F.a[p][i] = *reinterpret_cast<const bf16x8*>(pb + prow * 96 + p * 32 + ((h ^ ((prow >> 3) & 1)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) F.b[p][j] = *reinterpret_cast<const bf16x8*>(bb + (wn * TN * 32 + j * 32 + l31) * 96 + p * 32 + hoffB);
+    }
+  };
+  auto mm = [&](const Fr& F) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[PA[t]][i], F.b[PB[t]][j], acc[i][j], 0, 0, 0);
+  };
+  auto waitcnt = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+  };
+  issueA(0); issueB(0); issueB(1); issueB(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  rd(F0, 0, 0, 0);
+  int s0 = 0, s1 = 1, buf = 0;
+  for (int st = 0; st < stages; st += 2 * TAPS) {
+#pragma unroll
+    for (int u = 0; u < 2 * TAPS; ++u) {
+      const int p = u % TAPS;                 // tap of the stage being multiplied
+      Fr& Fc = (DBUF && (u & 1)) ? F1 : F0;
+      Fr& Fn = (DBUF && !(u & 1)) ? F1 : F0;
+      const int ntap = (p + 1) % TAPS, nbuf = ntap == 0 ? buf ^ 1 : buf;
+      issueB(s0);
+      if (p == 0) issueA(buf ^ 1);            // the next slab's patch, while this slab's nine taps run
+      if (DBUF) { rd(Fn, s1, nbuf, ntap); mm(Fc); } else mm(Fc);
+      __builtin_amdgcn_sched_barrier(0);
+      waitcnt(MINB + (p == 0 ? MINA : 0) + (p == 1 ? MINA : 0));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!DBUF) rd(Fn, s1, nbuf, ntap);
+      s0 = s1; s1 = s1 == 2 ? 0 : s1 + 1;
+      buf = nbuf;
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  if (s == 12345.678f) out[0] = s;
+}
+
 template <class K>
 static void run_t(const char* label, K kern, int threads, int blocks, size_t lds, const float* src, float* out, unsigned src_bytes,
                   double flop_per_stage_block, unsigned row_stride) {
@@ -352,5 +482,8 @@ int main() {
   run_t("bf16x3 DMA 256x128 / 8 waves, GEMM-grid reuse", (loop_bf3_dma<4, 2, 2, 2, true>), 512, 256, 3 * 384 * 96, src, out, big_bytes, 2.0 * 256 * 128 * 16, 0);
   run_t("bf16x3 DMA 256x256 / 8 waves (64x128), GEMM-grid reuse", (loop_bf3_dma<4, 2, 2, 4, false>), 512, 256, 3 * 512 * 96, src, out, big_bytes, 2.0 * 256 * 256 * 16, 0);
   run_t("bf16x3 DMA 128x256 / 4 waves (64x128), GEMM-grid reuse", (loop_bf3_dma<2, 2, 2, 4, false>), 256, 256, 3 * 384 * 96, src, out, big_bytes, 2.0 * 128 * 256 * 16, 0);
+  run_t("bf16x3 HALO 256x128 / 8 waves, 9 taps per patch, GEMM grid", (loop_bf3_halo<4, 2, 2, 2, true, 9, 98>), 512, 256, 2 * (256 + 98) * 96 + 3 * 128 * 96, src, out, big_bytes, 2.0 * 256 * 128 * 16, 0);
+  run_t("bf16x3 HALO 256x256 / 8 waves, 9 taps per patch, GEMM grid", (loop_bf3_halo<4, 2, 2, 4, false, 9, 98>), 512, 256, 2 * (256 + 98) * 96 + 3 * 256 * 96, src, out, big_bytes, 2.0 * 256 * 256 * 16, 0);
+  run_t("bf16x3 HALO 128x128 / 4 waves, 9 taps per patch, GEMM grid", (loop_bf3_halo<2, 2, 2, 2, true, 9, 98>), 256, 512, 2 * (128 + 98) * 96 + 3 * 128 * 96, src, out, big_bytes, 2.0 * 128 * 128 * 16, 0);
   return 0;
 }

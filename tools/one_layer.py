@@ -95,12 +95,12 @@ if args.bf16x3:
     xs = ops.split3(x)
     for v3 in (11, 12):
         ps.set_tile(v3)
-        for static, order in ((False, None), (True, None)):
-            ps.set_stream_k(not static, dma=order)
+        for static, halo in ((False, True), (True, True), (False, False), (True, False)):
+            ps.set_stream_k(not static, force=not static, halo=halo)
             ts = [timed_burst(lambda: ps(xs, res=res, out=y3)) for _ in range(args.reps)]
             err = float((y3 - ref).abs().max() / ref.abs().max())
             vv, nb = ps.launch_info(args.n, h, w)
-            print(f"bf16x3 pre-split variant {vv} {'static ' if static else 'stream-K col-major' if order is None else 'stream-K strip-major'} blocks {nb}: median {np.median(ts):.4f} ms  "
+            print(f"bf16x3 pre-split variant {vv} {'static  ' if static else 'stream-K'} {'patch  ' if halo else 'per-tap'} blocks {nb}: median {np.median(ts):.4f} ms  "
                   f"{flops / np.median(ts) / 1e9:.1f} TFLOP/s-equivalent; max |bf16x3 - fp32| / max |fp32| = {err:.2e}")
     ts = [timed_burst(lambda: ops.split3(x)) for _ in range(args.reps)]
     print(f"split3 of the input: median {np.median(ts):.4f} ms ({x.numel() * 10 / np.median(ts) / 1e6:.0f} GB/s)")

@@ -1,16 +1,10 @@
-R=${GRAFT_REPO_ROOT:-.}; O=$R/gpurun_out/r03_p8; mkdir -p $O
-cd $R
-run() { timeout 300 python3 $R/tools/one_layer.py "$@" --reps 8 2>&1 | grep -v "amdgpu.ids" >> $O/layers.txt; }
-: > $O/layers.txt
-for st in "" "--static"; do
-run --kind conv --k 3 --s 1 --cin 96 --cout 96 --n 18 --hw 256 384 $st
-run --kind conv --k 1 --s 1 --cin 192 --cout 96 --n 18 --hw 256 384 $st
-run --kind conv --k 1 --s 1 --cin 96 --cout 192 --n 18 --hw 256 384 --epi $st
-run --kind conv --k 3 --s 1 --cin 96 --cout 96 --n 18 --hw 128 192 $st
-run --kind conv --k 1 --s 1 --cin 192 --cout 96 --n 18 --hw 128 192 $st
-run --kind conv --k 1 --s 1 --cin 192 --cout 192 --n 18 --hw 128 192 $st
-run --kind conv --k 5 --s 2 --cin 192 --cout 192 --n 18 --hw 128 192 $st
-run --kind conv --k 1 --s 1 --cin 320 --cout 160 --n 18 --hw 32 48 $st
-run --kind conv --k 3 --s 1 --cin 160 --cout 160 --n 18 --hw 32 48 $st
-done
-cat $O/layers.txt
+#!/bin/bash
+mkdir -p gpurun_out/r03_p8
+timeout 900 python -m pytest tests/test_hip_bf16x3.py tests/test_hip_entry_points.py -x -q -m gpu > gpurun_out/r03_p8/t.log 2>&1; grep -E "passed|failed|Error|assert" gpurun_out/r03_p8/t.log | head
+python bench.py > gpurun_out/r03_p8/bench.json 2> gpurun_out/r03_p8/bench.err; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r03_p8/bench.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"])
+for k,v in d.get("regions",{}).items():
+    print(k, {kk: vv for kk,vv in v.items() if kk in ("ms","median_ms","speedup_over_fp32","mpx_s","roofline")})
+PY
