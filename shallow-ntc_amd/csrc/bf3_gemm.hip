@@ -307,32 +307,46 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
       g_T = __builtin_amdgcn_readfirstlane(g_T);
       g_tw = __builtin_amdgcn_readfirstlane(g_tw);
       h_th = __builtin_amdgcn_readfirstlane(g_T / g_tw);
-      const int W = a.W, H = a.H, ts = a.tstep;
-      const int prows = BM + (h_th - 1) * W + g_tw - 1;
-      const int zrow = g_T > 1 ? 1 : 0;                                          // the zero row behind the patch (a 1-tap group never needs it)
+      // Rows are macro pixels (n, qy, qx) of the [Qh, Qw] grid, flattened; with sA = 1 tap (ty, tx) of row m reads the input
+      // pixel at macro position m + (q0y + offy + ty tstep) Qw + q0x + offx + tx tstep -- when that position lies inside the
+      // image ([H, W] <= [Qh, Qw]; the grids are equal except for the transposed layers whose phases do not share one origin).
+      const int W = a.W, H = a.H, ts = a.tstep, Qw = a.Qw;
+      const int prows = BM + (h_th - 1) * Qw + g_tw - 1;
+      // a row whose tap leaves the image reads the zero row behind the patch; a 1-tap group keeps its patch at 3 rounds (three
+      // buffers: its patch changes every stage) and masks the data instead (-1), or not at all if it is a plain 1x1 (-2)
+      const int zrow = g_T > 1 ? 1 : 0;
       h_rounds = __builtin_amdgcn_readfirstlane(((prows + zrow) * 6 + NT - 1) / NT);      // <= P_R (host check)
       h_pbytes = h_rounds * NT * 16;
       h_nbufs = h_rounds * 3 <= 2 * P_R ? 3 : 2;
-      h_zero96 = prows * 96;
+      const bool plain = G.q0y == 0 && G.q0x == 0 && a.offy == 0 && a.offx == 0 && a.Qh == a.H && Qw == a.W;
+      h_zero96 = g_T > 1 ? prows * 96 : plain ? -2 : -1;
       h_coljump = ts;
-      h_rowjump = ts * (W - g_tw + 1);
-      h_shift0 = ts < 0 ? (h_th - 1) * W + g_tw - 1 : 0;
-      // tap (ty, tx) of row m reads pixel m + (q0y + offy + ty tstep) W + q0x + offx + tx tstep (sA = 1, macro grid = input grid)
-      const int dmin = (G.q0y + a.offy - (ts < 0 ? h_th - 1 : 0)) * W + G.q0x + a.offx - (ts < 0 ? g_tw - 1 : 0);
+      h_rowjump = ts * (Qw - g_tw + 1);
+      h_shift0 = ts < 0 ? (h_th - 1) * Qw + g_tw - 1 : 0;
+      const int dmin = (G.q0y + a.offy - (ts < 0 ? h_th - 1 : 0)) * Qw + G.q0x + a.offx - (ts < 0 ? g_tw - 1 : 0);
       const int gbase = p.mt * BM + dmin;
-      const unsigned total = (unsigned)(a.N * H * W);
+      const bool same_grid = a.Qh == H && Qw == W;
+      const unsigned total = (unsigned)a.M;
 #pragma unroll
       for (int i = 0; i < P_N; ++i) {
         const int q = i * NT + tid, row = q / 6, part = q - row * 6;
         const int gp = gbase + row;
-        const bool ok = row < prows && (unsigned)gp < total;
-        p_off[i] = ok ? (unsigned)gp * (unsigned)a.Cin * 6u + (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4)) : kOOR;
+        bool ok = row < prows && (unsigned)gp < total;
+        unsigned pix = (unsigned)gp;
+        if (!same_grid && ok) {                                  // macro position -> input pixel, if it has one
+          const int per = a.Qh * Qw;
+          const int n = gp / per, rem = gp - n * per;
+          const int y = rem / Qw, x = rem - y * Qw;
+          ok = y < H && x < W;
+          pix = (unsigned)((n * H + y) * W + x);
+        }
+        p_off[i] = ok ? pix * (unsigned)a.Cin * 6u + (unsigned)((part >> 1) * 32 + (((part & 1) ^ ((row >> 3) & 1)) << 4)) : kOOR;
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int4 ri = rinfo[r_row[i]];
         unsigned bits = 0;
-        if (g_T == 1) {
+        if (h_zero96 == -2) {
           bits = 1u;                        // rows past M read rows past the input: zero-filled by the DMA
         } else if (ri.w) {
           int t = 0;
@@ -369,7 +383,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
   auto issue_b = [&](int slot) {                // this wave's share of one stage of weights
     const unsigned wsoff = (unsigned)__builtin_amdgcn_readfirstlane(ld_stage) * 96u;
     char* bb = ring + slot * SLOT + wave * 1024 + (HALO ? 0 : BM * 96);
-    if (!SNTC_DBG(a, 1)) {
+    if (!SNTC_DBG(a, 1) || issued < 40) {      // (diagnostic: after the first stages the LDS keeps stale but real data)
 #pragma unroll
       for (int i = 0; i < B_CH; ++i)
         if ((BN * 6) % NT == 0 || i * NT + wave * 64 < BN * 6)
@@ -403,7 +417,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(cc) * 96u;
 #pragma unroll
     for (int i = 0; i < P_N; ++i)
-      if (i < h_rounds && !SNTC_DBG(a, 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(base + i * NT * 16), 16, (int)p_off[i], (int)soff, 0, 0);
+      if (i < h_rounds && (!SNTC_DBG(a, 2) || issued < 40)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(base + i * NT * 16), 16, (int)p_off[i], (int)soff, 0, 0);
     issued += h_rounds;
   };
   // leave at most `stages` of this wave's stages in flight
@@ -473,10 +487,20 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     for (int i = 0; i < TM; ++i) {
       const int prow = r_row[i] + rd_shift;
       int off = prow * 96 + ((h ^ ((prow >> 3) & 1)) << 4);
-      off = ((r_bits[i] >> rd_t) & 1u) ? off : h_zero96;
+      const bool in = (r_bits[i] >> rd_t) & 1u;
+      off = (in || h_zero96 < 0) ? off : h_zero96;
       const char* src = smem + pbo + off;
 #pragma unroll
       for (int p = 0; p < 3; ++p) F.a[p][i] = *reinterpret_cast<const bf16x8*>(src + p * 32);
+      if (h_zero96 == -1) {                 // 1-tap group with an offset origin: no zero row, mask the data
+        const unsigned keep = in ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          u32x4 v = __builtin_bit_cast(u32x4, F.a[p][i]);
+          v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+          F.a[p][i] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -589,7 +613,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
 
     Frag F;
     int s_cur = 0, s_n1 = 1, s_n2 = 2;
-    if (HALO && DBUF) {
+    if constexpr (HALO && DBUF) {
       // Fragments double-buffered: step j multiplies stage j from registers while it READS stage j+1 and the DMA fills the
       // slot stage j left with stage j+3 (step -1 only reads).  A wave issues in order and its 24 MFMAs of a stage keep the
       // matrix pipe busy for 768 cycles: everything else a step does (DMA issue, fragment addresses and reads, tap masks, the
@@ -605,28 +629,57 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
 #pragma unroll
       for (int q = 0; q < NS - 2; ++q) mq[q] = pm[q + 1];
       int s_rd = 0, s_is = NS - 1;                         // ring slot of the stage being read (j+1) / of stage j: free, takes stage j+NS
-      auto mf = [&](const Frag& Fc, auto T_) {             // the TM x TN MFMAs of one of the six cross terms
-        constexpr int t = decltype(T_)::value;
+      // MFMA number q of a stage (q = term * TM * TN + i * TN + j; smallest terms first) and a scheduling fence behind it
+      auto mf = [&](const Frag& Fc, bool on, int q) {      // q is a literal / an unrolled loop index: everything below folds
+        const int t = q / (TM * TN), i = (q / TN) % TM, j2 = q % TN;
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-        if (!SNTC_DBG(a, 64)) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j2 = 0; j2 < TN; ++j2)
-              acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Fc.a[PA[t]][i], Fc.b[PB[t]][j2], acc[i][j2], 0, 0, 0);
-        }
+        if (on && !SNTC_DBG(a, 64))
+          acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Fc.a[PA[t]][i], Fc.b[PB[t]][j2], acc[i][j2], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
-      using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
-      using T3 = std::integral_constant<int, 3>; using T4 = std::integral_constant<int, 4>; using T5 = std::integral_constant<int, 5>;
       auto step = [&](auto EDGE_, int j, Frag& Fc, Frag& Fn) {
         constexpr bool EDGE = decltype(EDGE_)::value;      // first / last steps of a piece: some of the parts below are absent
-        const bool mm = !EDGE || j >= 0, rd = !EDGE || j + 1 < n;
+        const bool mm = !EDGE || j >= 0, rd = (!EDGE || j + 1 < n) && (!SNTC_DBG(a, 8) || j < 1);
+        // An MFMA keeps the matrix pipe busy for 32 cycles and the SIMD's vector issue for 8 of them; what fits beside it is a
+        // handful of VALU / scalar instructions, or ONE ds_read_b128 (two waves per SIMD: the LDS array takes two per gap and
+        // SIMD before it, not the MFMA, sets the pace), or one DMA piece.  So the step's other work goes out in slices of that
+        // size, one behind each MFMA: fragment addresses and the twelve fragment reads of stage j+1 first, then the DMA
+        // pieces of stage j+NS (and of the next patch), then the pipeline bookkeeping.
+        static_assert(TM == 2 && TN == 2, "the slices below are laid out for a 64 x 64 wave tile (24 MFMAs per stage)");
+        const char* src[TM];
+        bool in[TM];
+        const char* bsrc = ring + s_rd * SLOT + fb;
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int prow = r_row[i] + rd_shift;
+          int off = prow * 96 + ((h ^ ((prow >> 3) & 1)) << 4);
+          in[i] = (r_bits[i] >> rd_t) & 1u;
+          off = (in[i] || h_zero96 < 0) ? off : h_zero96;
+          src[i] = smem + rd_buf * h_pbytes + off;
+          __builtin_amdgcn_sched_barrier(0);
+          mf(Fc, mm, q++);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            if (rd) Fn.a[p][i] = *reinterpret_cast<const bf16x8*>(src[i] + p * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            mf(Fc, mm, q++);
+          }
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < TN; ++j2)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            if (rd) Fn.b[p][j2] = *reinterpret_cast<const bf16x8*>(bsrc + j2 * 32 * 96 + p * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            mf(Fc, mm, q++);
+          }
+        // q == 14: weights of stage j+NS into the slot stage j left
         if (!EDGE || j + NS < n) issue(s_is);
         const int mnew = issued;
         __builtin_amdgcn_sched_barrier(0);
-        if (mm) mf(Fc, T0{});
+        mf(Fc, mm, q++);
         if (rd && ((EDGE && j < 0) || rd_t == 0) && nP <= c_last) {   // reading a slab's first stage: its predecessor's buffer is free
           issue_patch(nP, nP_buf);
           if (h_nbufs == 3) mP2 = issued;
@@ -635,24 +688,40 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
           nP_buf = nP_buf + 1 == h_nbufs ? 0 : nP_buf + 1;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (mm) mf(Fc, T1{});
-        if (rd && (!SNTC_DBG(a, 8) || j < 1)) read_frag_halo(Fn, s_rd);
-        __builtin_amdgcn_sched_barrier(0);
-        if (mm) { mf(Fc, T2{}); mf(Fc, T3{}); }
+        mf(Fc, mm, q++);
         const bool slab_end = rd && rd_t + 1 == g_T;
         const int need = slab_end ? max(mq[0], mP1) : mq[0];
         const int allowed = issued - need;
+        __builtin_amdgcn_sched_barrier(0);
+        mf(Fc, mm, q++);
         s_rd = s_rd + 1 == NS ? 0 : s_rd + 1;
         s_is = s_is + 1 == NS ? 0 : s_is + 1;
 #pragma unroll
-        for (int q = 0; q + 1 < NS - 2; ++q) mq[q] = mq[q + 1];
+        for (int k = 0; k + 1 < NS - 2; ++k) mq[k] = mq[k + 1];
         mq[NS - 3] = mnew;
+        __builtin_amdgcn_sched_barrier(0);
+        mf(Fc, mm, q++);
         if (rd) {
           advance_read(slab_end);
           if (slab_end) mP1 = mP2;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (mm) { mf(Fc, T4{}); mf(Fc, T5{}); }
+        mf(Fc, mm, q++);
+        if (rd && h_zero96 == -1) {         // 1-tap group with an offset origin: no zero row, mask the data
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const unsigned keep = in[i] ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              u32x4 v = __builtin_bit_cast(u32x4, Fn.a[p][i]);
+              v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+              Fn.a[p][i] = __builtin_bit_cast(bf16x8, v);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (; q < TM * TN * 6; ++q) mf(Fc, mm, q);
         if (!EDGE || j + 2 < n) {
           // stage j+2's weights -- and its patch, if it opens the next slab -- have landed; younger loads may still fly
           wait_vm(allowed);
@@ -673,7 +742,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
         step(Edge{}, j, F, G);
         if (j + 1 < n) step(Edge{}, j + 1, G, F);
       }
-    } else if (HALO) {
+    } else if constexpr (HALO) {
       // stage 0's weights and its slab's patch must have landed.  (Everything younger that is not counted in `issued` -- the
       // previous piece's epilogue stores, the hand-off loads above -- only makes a wait longer, never shorter.)
       wait_vm(issued - max(mBc, mPc));

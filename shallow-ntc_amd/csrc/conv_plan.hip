@@ -781,13 +781,13 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   a.ups = (int)unit0;
   if (p->s3) {
     a.order = p->dma == 0 ? 1 : 0;        // sntc_conv_plan_set_schedule's stage-path bit doubles as the unit-order A/B switch here
-    // patch staging: the taps of a slab sample the input at unit stride on a macro grid that IS the input grid, and every
-    // group's patch (tile rows + the tap window's reach in flattened pixels + a zero row) fits the patch buffers; <= 32 taps (the
-    // kernel keeps one validity bit per tap and row)
-    bool halo = !p->no_halo && g.sA == 1 && g.Qh == h && g.Qw == w;
+    // patch staging: the taps of a slab sample the input at unit stride, and every group's patch (tile rows + the tap window's
+    // reach in flattened macro pixels + a zero row) fits the patch buffers; <= 32 taps (the kernel keeps one validity bit per tap
+    // and row)
+    bool halo = !p->no_halo && g.sA == 1;
     for (int gi = 0; halo && gi < p->ngroups; ++gi) {
       const int th = p->g[gi].T / p->g[gi].tw;
-      halo = p->g[gi].T <= 32 && bm + (th - 1) * w + p->g[gi].tw - 1 + (p->g[gi].T > 1 ? 1 : 0) <= bf3p_patch_rows_max();
+      halo = p->g[gi].T <= 32 && bm + (th - 1) * g.Qw + p->g[gi].tw - 1 + (p->g[gi].T > 1 ? 1 : 0) <= bf3p_patch_rows_max();
     }
     a.halo = halo ? 1 : 0;
     return bf3p_launch(v, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
