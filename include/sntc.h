@@ -183,6 +183,17 @@ int sntc_conv_set_stream_k(int enabled);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);
+/* Measured schedule.  Every (tile variant, stream-K / one-workgroup-per-tile) candidate of a plan computes the same k-ordered
+ * chains, so the choice is a question of speed only; sntc_conv_plan_tune times them on the caller's buffers for one (n, h, w)
+ * (`reps` launches each, HIP events on `stream`, synchronises it) and records the winner in the plan: later calls of that shape
+ * run it instead of the cost model's pick (a forced tile / schedule still wins).  `workspace` >= sntc_conv_tune_workspace_bytes().
+ * y holds the layer's output afterwards.  The reference has no counterpart of its own: TensorFlow's convolutions pick their
+ * algorithm by cuDNN autotune the same way (tf.nn.conv2d behind common/transforms.py:81-90). */
+int64_t sntc_conv_tune_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int w);
+int sntc_conv_plan_tune(sntc_conv_plan* plan, const float* x, int n, int h, int w, float* y, const float* res,
+                        const float* aux, void* workspace, size_t workspace_bytes, int reps, int* variant, int* stream_k,
+                        void* stream);
+int sntc_conv_plan_clear_tuning(sntc_conv_plan* plan);
 
 /* ------------------------------------------------------------------------------------------
  * Small-channel GDN1 / IGDN1 (C <= 64): wave-shuffle contraction, no MFMA.

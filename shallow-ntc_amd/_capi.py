@@ -63,6 +63,10 @@ SIGNATURES = {
     "sntc_conv_status": (C.c_int, [C.POINTER(C.c_int), _P]),
     "sntc_conv_set_stream_k": (C.c_int, [C.c_int]),
     "sntc_conv_launch_info": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sntc_conv_tune_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
+    "sntc_conv_plan_tune": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), _P]),
+    "sntc_conv_plan_clear_tuning": (C.c_int, [_P]),
     "sntc_gdn_small": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_two_layer_tail": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,
                                       C.c_int, C.c_int, C.c_int, _P, _P]),

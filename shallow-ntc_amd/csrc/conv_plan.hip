@@ -7,7 +7,12 @@
 // <= 4 groups that share a tap pattern; each group is one GEMM whose columns are
 // (phase, channel) pairs: N = phases*Cout, K = taps*Cin -- no zero stuffing, no col2im.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <array>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <cstdlib>
 #include <vector>
 #include "sntc_internal.h"
@@ -150,7 +155,13 @@ struct sntc_conv_plan {
   bool force_stream_k = false;  // ignore the short-tile rule: stream-K wherever the launch is large enough (tests)
   bool no_halo = false;     // pre-split plans: stage every tap's activation rows separately even where one patch per slab would do (A/B)
   float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (fusable_second plans only)
+  // sntc_conv_plan_tune: (n, h, w) -> measured best (tile variant, schedule).  Every candidate computes the same k-ordered chains,
+  // so a tuned entry changes the launch's speed and never its bits.  Guarded: plans are shared by concurrent streams / threads.
+  struct Choice { int variant = 0; int sk = 0; };
+  mutable std::mutex tune_mu;
+  std::map<std::array<int, 3>, Choice> tuned;
 };
+typedef sntc_conv_plan::Choice TuneChoice;
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_tile: null plan");
@@ -524,6 +535,7 @@ struct Sched {
   int64_t units = 0;      // sum over groups of tiles * stages
   int64_t blocks = 0;     // workgroups launched
   bool deep = false;      // the deep-ring direct-to-LDS instance (small launches)
+  bool valid = false;     // some candidate passed the filters (always true without a forced choice)
 };
 
 static int max_steps(const sntc_conv_plan* p) {
@@ -577,7 +589,7 @@ static std::atomic<int> g_stream_k_enabled{1};
 
 // Pre-split bf16 x 3 plans: 256 x 256 or 256 x 128 tiles on one 512-thread workgroup per CU; stream-K whenever every CU gets
 // at least a longest tile's worth of stages, else one workgroup per tile.  No split-K (layers that small stay on the fp32 path).
-static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
+static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n, const TuneChoice* force) {
   Sched best;
   const int64_t M = n * g.Qh * g.Qw;
   const int msteps = max_steps(p);
@@ -585,6 +597,7 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   double best_cost = 1e300;
   for (int v : {11, 12}) {
     if (p->tile >= 11 && v != p->tile) continue;
+    if (force && v != force->variant) continue;
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
@@ -596,8 +609,9 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
     const int workers = (int)(std::min<int64_t>(cus, fit) & ~7LL);
     // many short tiles (the 13x13 / 8 synthesis: 1482 tiles of 20 ... 80 stages on 256 CUs) balance by themselves and run
     // faster one workgroup per tile (160 vs 145 TFLOP/s-equivalent); few long ones need the stream-K cut (191 vs 155)
-    s.sk = !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 &&
-           2 * workers >= cus && (units >= 64 * tiles || p->force_stream_k);
+    const bool can_sk = g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 && 2 * workers >= cus;
+    s.sk = force ? (force->sk != 0 && can_sk) : (can_sk && !p->no_stream_k && (units >= 64 * tiles || p->force_stream_k));
+    s.valid = true;
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles;
     double cost = macs;
@@ -615,8 +629,8 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n) {
   return best;
 }
 
-static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fused = false) {
-  if (p->s3) return schedule_s3(p, g, n);
+static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fused = false, const TuneChoice* force = nullptr) {
+  if (p->s3) return schedule_s3(p, g, n, force);
   Sched best;
   const int64_t M = n * g.Qh * g.Qw;
   const int ksplit = fused ? 1 : pick_ksplit(p, g);
@@ -630,6 +644,7 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // CU and 61 KB of LDS it shuts out the other stream's kernels: bench.py's two-stream encode went from 48.5 to 49.2 ms.)
     if (p->tile == 0 && (v == 6 || v == 7 || v == 10)) continue;
     if (p->bf3 && v != 2 && v != 4) continue;                       // the bf16 x 3 experiment is instantiated for two tile shapes
+    if (force && v != force->variant) continue;
     int64_t tiles, units;
     double macs;
     count_work(p, v, M, &tiles, &units, &macs);
@@ -650,8 +665,10 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // workgroup per tile measured +6 % on the 3x3 96 -> 96 layers, +4 ... 6 % on the 1x1 layers, +57 % on 320 -> 160 at 1/16
     // resolution, +4 % on the synthesis; long tiles (5x5 / 2: 300 stages, hyper-synthesis: 80 ... 270) keep stream-K (+6 ... 25 %)
     const bool short_tiles = units < 64 * tiles && !p->force_stream_k;
-    s.sk = ksplit == 1 && !p->no_stream_k && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) &&
-           workers >= 8 && 2 * workers >= resident && !short_tiles;
+    const bool can_sk = ksplit == 1 && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 &&
+                        2 * workers >= resident;
+    s.sk = force ? (force->sk != 0 && can_sk) : (can_sk && !p->no_stream_k && !short_tiles);
+    s.valid = true;
     s.workers = s.sk ? workers : 0;
     s.blocks = s.sk ? workers : tiles * ksplit;
     double cost = macs;
@@ -676,9 +693,33 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // where the old 0.97 let the stream-K worker count tip the choice the other way)
     static const double kRate[kNumVariants + 1] = {0, 0.86, 0.93, 1.00, 1.00, 0.97, 0.90, 0.85, 0.90, 1.02, 0.40};
     cost /= kRate[v];
+#ifdef SNTC_DIAG
+    if (getenv("SNTC_SCHED_DBG"))
+      fprintf(stderr, "[sched] M=%lld v=%d sk=%d workers=%d blocks=%lld tiles=%lld units=%lld resident=%d deep=%d cost=%.4g (macs %.4g)\n", (long long)M, v,
+              (int)s.sk, s.workers, (long long)s.blocks, (long long)tiles, (long long)units, resident, (int)s.deep, cost, macs);
+#endif
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
+}
+
+// The schedule of a call: the measured choice for this (n, h, w) if sntc_conv_plan_tune recorded one -- unless the plan's tile or
+// schedule is forced (tests, profiling) -- else the cost model's.
+static Sched plan_schedule(const sntc_conv_plan* p, const Geo& g, int n, int h, int w, bool fused = false) {
+  if (!fused && p->tile == 0 && !p->no_stream_k && !p->force_stream_k) {
+    TuneChoice c;
+    bool have = false;
+    {
+      std::lock_guard<std::mutex> lk(p->tune_mu);
+      auto it = p->tuned.find({n, h, w});
+      if (it != p->tuned.end()) { c = it->second; have = true; }
+    }
+    if (have) {
+      const Sched s = schedule(p, g, n, false, &c);
+      if (s.valid) return s;
+    }
+  }
+  return schedule(p, g, n, fused);
 }
 
 static int64_t workspace_floats(const sntc_conv_plan* p, int64_t M, const Sched& s) {
@@ -694,7 +735,7 @@ extern "C" int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* p, int n, int
   if (!p) return 0;
   Geo g;
   if (geometry(p, h, w, &g)) return 0;
-  return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, schedule(p, g, n));
+  return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, plan_schedule(p, g, n, h, w));
 }
 
 extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int w, int* variant, int* nblocks) {
@@ -702,7 +743,7 @@ extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int 
   Geo g;
   int rc = geometry(p, h, w, &g);
   if (rc) return rc;
-  const Sched s = schedule(p, g, n);
+  const Sched s = plan_schedule(p, g, n, h, w);
   *variant = s.variant;
   *nblocks = (int)s.blocks;
   return SNTC_OK;
@@ -710,7 +751,8 @@ extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int 
 
 // One launch of plan p; with p2 (validated by sntc_conv_forward_fused) the 1x1 plan p2 runs behind p inside the same launch.
 static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, const float* x, int n, int h, int w, float* y,
-                             const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream) {
+                             const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream,
+                             const TuneChoice* force = nullptr) {
   if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: null argument");
   if (n < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: empty batch");
   const sntc_conv_desc& d = p->d;
@@ -725,7 +767,8 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   if (M > 0x7fffffffLL || x_bytes >= (1LL << 31))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: input tensor must be < 2 GiB (32-bit buffer offsets); split the batch");
   if (p2 && M * p2->d.cout >= (1LL << 32)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward_fused: output too large; split the batch");
-  const Sched sc = schedule(p, g, n, p2 != nullptr);
+  const Sched sc = force ? schedule(p, g, n, false, force) : plan_schedule(p, g, n, h, w, p2 != nullptr);
+  if (!sc.valid) return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_forward: no tile variant for this plan");
   const int64_t ws_floats = workspace_floats(p, M, sc);
   if (ws_floats > 0 && (!workspace || workspace_bytes < (size_t)ws_floats * 4))
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_forward: this call needs sntc_conv_workspace_bytes() of workspace "
@@ -801,6 +844,85 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
                                  const float* res, const float* aux, void* workspace, size_t workspace_bytes,
                                  void* stream) {
   return conv_forward_impl(p, nullptr, x, n, h, w, y, res, aux, workspace, workspace_bytes, stream);
+}
+
+// ---- measured schedule (reference: none -- TensorFlow picks its convolution algorithm by cuDNN autotune the same way).
+// Every (tile variant, schedule) candidate of a plan computes the same k-ordered fma chains (tests/test_hip_fullsize.py), so which
+// one runs is a question of speed only.  The cost model of schedule() ranks them from tile counts; this measures them on the
+// caller's buffers, for one (n, h, w), and records the winner in the plan.  Split-K factors are not candidates (they are a
+// function of the layer and the per-image geometry only, by contract).
+static void tune_candidates(const sntc_conv_plan* p, const Geo& g, int n, std::vector<std::pair<TuneChoice, Sched>>* out) {
+  const int v0 = p->s3 ? 11 : 1, v1 = p->s3 ? 12 : kNumVariants;
+  for (int v = v0; v <= v1; ++v)
+    for (int sk = 1; sk >= 0; --sk) {
+      TuneChoice c;
+      c.variant = v;
+      c.sk = sk;
+      const Sched s = schedule(p, g, n, false, &c);
+      if (!s.valid || s.variant != v || (sk && !s.sk)) continue;
+      out->push_back({c, s});
+    }
+}
+
+extern "C" int64_t sntc_conv_tune_workspace_bytes(const sntc_conv_plan* p, int n, int h, int w) {
+  if (!p) return 0;
+  Geo g;
+  if (geometry(p, h, w, &g)) return 0;
+  std::vector<std::pair<TuneChoice, Sched>> cand;
+  tune_candidates(p, g, n, &cand);
+  int64_t m = 0;
+  for (auto& c : cand) m = std::max(m, workspace_floats(p, (int64_t)n * g.Qh * g.Qw, c.second));
+  return 4 * m;
+}
+
+extern "C" int sntc_conv_plan_tune(sntc_conv_plan* p, const float* x, int n, int h, int w, float* y, const float* res,
+                                   const float* aux, void* workspace, size_t workspace_bytes, int reps, int* variant,
+                                   int* stream_k, void* stream) {
+  if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_tune: null argument");
+  Geo g;
+  int rc = geometry(p, h, w, &g);
+  if (rc) return rc;
+  reps = std::max(1, std::min(reps, 100));
+  std::vector<std::pair<TuneChoice, Sched>> cand;
+  tune_candidates(p, g, n, &cand);
+  if (cand.empty()) return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_tune: no candidate");
+  hipEvent_t e0, e1;
+  SNTC_HIP(hipEventCreate(&e0));
+  SNTC_HIP(hipEventCreate(&e1));
+  float best_ms = 1e30f;
+  TuneChoice best;
+  for (auto& c : cand) {
+    if ((size_t)(4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, c.second)) > workspace_bytes) continue;
+    rc = conv_forward_impl(p, nullptr, x, n, h, w, y, res, aux, workspace, workspace_bytes, stream, &c.first);      // warm
+    if (rc) break;
+    (void)hipEventRecord(e0, (hipStream_t)stream);
+    for (int r = 0; r < reps && !rc; ++r)
+      rc = conv_forward_impl(p, nullptr, x, n, h, w, y, res, aux, workspace, workspace_bytes, stream, &c.first);
+    (void)hipEventRecord(e1, (hipStream_t)stream);
+    if (rc) break;
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = fail(SNTC_ERR_HIP, "sntc_conv_plan_tune: timing failed"); break; }
+    if (ms < best_ms) { best_ms = ms; best = c.first; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  if (best.variant == 0) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_tune: workspace smaller than sntc_conv_tune_workspace_bytes()");
+  {
+    std::lock_guard<std::mutex> lk(p->tune_mu);
+    p->tuned[{n, h, w}] = best;
+  }
+  if (variant) *variant = best.variant;
+  if (stream_k) *stream_k = best.sk;
+  // leave y as a plain forward call would: the last candidate's output is the same bits, nothing to redo
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_plan_clear_tuning(sntc_conv_plan* p) {
+  if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_clear_tuning: null plan");
+  std::lock_guard<std::mutex> lk(p->tune_mu);
+  p->tuned.clear();
+  return SNTC_OK;
 }
 
 // ResidualBlock tail (reference common/elic.py:41-68): y = epilogue2(conv1x1_p2(act1(conv3x3_p1(x) + b1)) + b2, res) in ONE

@@ -140,6 +140,7 @@ class ConvPlan:
         self._h = C.c_void_p()
         capi.call("sntc_conv_plan_create", C.byref(desc), _ptr(w), _ptr(b), _stream(), C.byref(self._h))
         torch.cuda.current_stream().synchronize()   # packing reads w/b; they may be freed after this
+        self._tuned = {}
         if FORCE_TILE:
             self.set_tile(FORCE_TILE)
 
@@ -215,6 +216,24 @@ class ConvPlan:
         capi.call("sntc_conv_launch_info", self._h, n, h, w, C.byref(v), C.byref(nb))
         return v.value, nb.value
 
+    def tune(self, x, res=None, aux=None, reps=3):
+        """Time this plan's (tile, schedule) candidates on ``x`` and keep the fastest for calls of this shape
+        (sntc_conv_plan_tune; identical bits whichever runs).  Returns (variant, stream_k)."""
+        n, h, w = (int(v) for v in x.shape[:3])
+        ho, wo = self.out_hw(h, w)
+        y = torch.empty((n, ho, wo, self.cout), dtype=torch.float32, device=x.device)
+        ws_bytes = int(capi.load().sntc_conv_tune_workspace_bytes(self._h, n, h, w))
+        ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=x.device) if ws_bytes else None
+        v, sk = C.c_int(), C.c_int()
+        capi.call("sntc_conv_plan_tune", self._h, _ptr(x), n, h, w, _ptr(y), _ptr(res), _ptr(aux), _ptr(ws), ws_bytes, int(reps),
+                  C.byref(v), C.byref(sk), _stream())
+        self._tuned[(n, h, w)] = (v.value, sk.value)
+        return v.value, sk.value
+
+    def clear_tuning(self):
+        capi.call("sntc_conv_plan_clear_tuning", self._h)
+        self._tuned = {}
+
     def __call__(self, x, res=None, aux=None, out=None):
         if self.s3:
             _check_s3(x, self.cin)
@@ -236,6 +255,8 @@ class ConvPlan:
             self.__call__(x[:half], r0, a0, out=y[:half])
             self.__call__(x[half:], r1, a1, out=y[half:])
             return y
+        if AUTOTUNE and (n, h, w) not in self._tuned:
+            self.tune(x, res, aux, reps=AUTOTUNE)
         prof = PROFILE
         if prof is not None:     # bench.py: HIP events on the launch stream around this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -261,6 +282,30 @@ def check_conv_status():
         capi.call("sntc_conv_set_stream_k", 0)
         raise capi.SntcError(capi.ERR_HIP, "a stream-K hand-off timed out (the device is shared with other streams / processes): "
                                            "the results since the last check are invalid; stream-K is now off, run the step again")
+
+
+AUTOTUNE = False       # inside ``with ops.autotune():`` every ConvPlan measures its launch schedule the first time it sees a shape
+
+
+class autotune:
+    """``with ops.autotune(): model.decode(...)`` -- every convolution plan that runs inside the block times its candidate
+    (tile, schedule) pairs on the tensors it is called with, once per (n, h, w), and keeps the fastest for later calls of that
+    shape (sntc_conv_plan_tune).  All candidates give identical bits; run the block on ONE stream with the device otherwise
+    idle, so that the timings mean something."""
+
+    def __init__(self, reps=3):
+        self.reps = int(reps)
+
+    def __enter__(self):
+        global AUTOTUNE
+        self._old = AUTOTUNE
+        AUTOTUNE = self.reps
+        return self
+
+    def __exit__(self, *exc):
+        global AUTOTUNE
+        AUTOTUNE = self._old
+        return False
 
 
 def set_stream_k(enabled):

@@ -355,3 +355,48 @@ def test_concurrent_stream_k_launches_and_the_status_word(dev):
         assert changed >= 2
     finally:
         ops.set_stream_k(True)
+
+
+@pytest.mark.gpu
+def test_tuned_schedule_is_a_speed_choice_only(dev):
+    """sntc_conv_plan_tune measures the (tile, schedule) candidates of a plan for one call shape and records the fastest; the
+    bits do not change (every candidate is the same k-ordered chain), other shapes and forced tiles are unaffected, and the
+    entry can be cleared."""
+    from shallow_ntc_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    for kind, k, s, cin, cout, shape in (("convT", 5, 2, 320, 480, (6, 24, 16)), ("conv", 3, 1, 96, 96, (2, 64, 96)),
+                                         ("conv", 1, 1, 192, 96, (3, 64, 64))):
+        wshape = (k, k, cout, cin) if kind == "convT" else (k, k, cin, cout)
+        wk = torch.randn(wshape, device=dev, generator=g) * 0.05
+        b = torch.randn((cout,), device=dev, generator=g)
+        x = torch.randn(shape + (cin,), device=dev, generator=g)
+        p = ops.ConvPlan(kind, wk, b, s, "relu")
+        before = p(x).clone()
+        info0 = p.launch_info(*shape)
+        other = x[:1].contiguous()
+        other_info = p.launch_info(1, shape[1], shape[2])
+        v, sk = p.tune(x)
+        assert 1 <= v <= 10 and sk in (0, 1)
+        assert p.launch_info(*shape)[0] == v
+        assert p.launch_info(1, shape[1], shape[2]) == other_info          # another batch size: untouched
+        assert torch.equal(p(x), before)
+        assert torch.equal(p(other), before[:1])
+        p.set_tile(2)                                                        # a forced tile wins over the tuned entry
+        assert p.launch_info(*shape)[0] == 2 and torch.equal(p(x), before)
+        p.set_tile(0)
+        with ops.autotune(reps=2):                                           # the context manager tunes unseen shapes on the fly
+            assert torch.equal(p(other), before[:1])
+        assert (1, shape[1], shape[2]) in p._tuned
+        p.clear_tuning()
+        assert p.launch_info(*shape) == info0
+    # a pre-split bf16 x 3 plan tunes over its own two tiles
+    wk = torch.randn((3, 3, 64, 64), device=dev, generator=g) * 0.05
+    x = torch.randn((4, 32, 48, 64), device=dev, generator=g)
+    ps = ops.ConvPlan("convT", wk, None, 1, bf16x3="presplit")
+    xs = ops.split3(x)
+    before = ps(xs).clone()
+    v, sk = ps.tune(xs)
+    assert v in (11, 12) and torch.equal(ps(xs), before)
+    torch.cuda.synchronize()
+    ops.check_conv_status()

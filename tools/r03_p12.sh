@@ -1,6 +1,11 @@
-R=${GRAFT_REPO_ROOT:-.}; O=$R/gpurun_out/r03_p12; mkdir -p $O
-cd $R
-SNTC_FUSE2_T=8 python -m pytest tests/test_hip_ops.py -m gpu -x -q -k "fused_residual" 2>&1 | grep -E "passed|failed"
-for t in 0 4 8 12 16 0 8; do
-echo "naps $t"; SNTC_FUSE2_T=$t python3 tools/profile_layers.py --reps 5 2>&1 | grep "== encode\|  6 conv+1x1 k3 s1   96-> 192 in 18x256x384\| 19 conv+1x1\|conv total" | tail -4
-done
+#!/bin/bash
+mkdir -p gpurun_out/r03_p12
+python bench.py > gpurun_out/r03_p12/bench.json 2> gpurun_out/r03_p12/bench.err; tail -3 gpurun_out/r03_p12/bench.err
+python - <<'PY'
+import json
+for f in ("bench",):
+    d=json.load(open(f"gpurun_out/r03_p12/{f}.json"))
+    print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["config"].get("launch_schedule"))
+    for k,v in d.get("regions",{}).items():
+        print("  ", k, v.get("ms_per_step"), v.get("roofline",{}).get("frac_of_fp32_mfma_peak"), v.get("speedup_over_fp32"))
+PY
