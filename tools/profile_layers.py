@@ -24,6 +24,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--config", default="two_layer_syn")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--decode-only", action="store_true")
+ap.add_argument("--autotune", action="store_true", help="measure every plan's (tile, schedule) candidates first (ops.autotune), as bench.py does for its encoder-side regions")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 ops.FORCE_TILE = args.variant
@@ -33,6 +34,9 @@ x = (torch.rand((n, h, w, 3), device=dev) - 0.5).contiguous()
 
 
 def run(fn, label):
+    if args.autotune:
+        with ops.autotune():
+            fn()
     fn()
     torch.cuda.synchronize()
     acc = {}

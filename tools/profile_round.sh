@@ -16,7 +16,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/enc_pmc_write -- python3 $R
 # ---- un-profiled: layer tables, microbench, default bench
 cd $R
 python3 tools/profile_layers.py --reps 5 > $O/layer_table_unprofiled.txt 2>&1
-python3 tools/profile_layers.py --reps 5 --batch 64 --hw 256 256 > $O/layer_table_w1.txt 2>&1
-tools/microbench/gemm_ceiling > $O/gemm_ceiling.txt 2>&1
+python3 tools/profile_layers.py --reps 5 --autotune > $O/layer_table_tuned.txt 2>&1
+python3 tools/profile_layers.py --reps 5 --batch 64 --hw 256 256 --autotune > $O/layer_table_w1.txt 2>&1
+( cd tools/microbench && echo "# tools/microbench/gemm_ceiling (raw float bits as operands)" && ./gemm_ceiling && echo && echo "# GEMM_CEILING_S3=1: genuine S3 operands (hi / mid / lo terms of N(0,1) values) for the bf16x3 loops" && GEMM_CEILING_S3=1 ./gemm_ceiling | grep -i bf16x3 ) > $O/gemm_ceiling.txt 2>&1
+python3 tools/one_layer.py --kind convT --k 3 --s 1 --cin 480 --cout 640 --n 18 --hw 32 48 --bf16x3 --reps 12 > $O/bf16x3_hs3.txt 2>&1
+python3 tools/one_layer.py --kind convT --k 5 --s 2 --cin 320 --cout 480 --n 18 --hw 16 24 --bf16x3 --reps 12 > $O/bf16x3_hs2.txt 2>&1
+python3 tools/one_layer.py --kind convT --k 13 --s 8 --cin 320 --cout 24 --n 18 --hw 32 48 --bf16x3 --reps 12 > $O/bf16x3_syn.txt 2>&1
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 find $O -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head; ls $O
