@@ -664,7 +664,10 @@ static Sched schedule(const sntc_conv_plan* p, const Geo& g, int64_t n, bool fus
     // 6 ... 20, the 13x13 / 8 synthesis: 52) the pieces' own bookkeeping outweighs the tile quantisation it removes -- one
     // workgroup per tile measured +6 % on the 3x3 96 -> 96 layers, +4 ... 6 % on the 1x1 layers, +57 % on 320 -> 160 at 1/16
     // resolution, +4 % on the synthesis; long tiles (5x5 / 2: 300 stages, hyper-synthesis: 80 ... 270) keep stream-K (+6 ... 25 %)
-    const bool short_tiles = units < 64 * tiles && !p->force_stream_k;
+    // ... and only where tiles are FEW: with four or more rounds of resident workgroups the hardware's own dispatch balances the
+    // launch, and the hand-offs only cost (5x5/2 192 -> 192 at 256 x 384: 6912 tiles of 300 stages on 768 slots, 131.9 TFLOP/s one
+    // workgroup per tile against 118.2 stream-K; at two rounds -- the decode layers -- stream-K wins by up to 25 %)
+    const bool short_tiles = (units < 64 * tiles || tiles * ksplit >= 4 * (int64_t)resident) && !p->force_stream_k;
     const bool can_sk = ksplit == 1 && g_stream_k_enabled.load(std::memory_order_relaxed) && units < (1LL << 31) && workers >= 8 &&
                         2 * workers >= resident;
     s.sk = force ? (force->sk != 0 && can_sk) : (can_sk && !p->no_stream_k && !short_tiles);

@@ -116,13 +116,7 @@ GDN_CONFIGS = [("bls2017", True, "analysis/layer_2", 0.8), ("mbt2018", False, "a
                ("two_layer_syn2", False, "analysis/layer_3", 0.4)]
 
 
-@pytest.mark.parametrize("name,factorized,last,y_std", GDN_CONFIGS, ids=[c[0] for c in GDN_CONFIGS])
-def test_gdn_signal_conv_configs_image_to_bpp_psnr_at_full_width(name, factorized, last, y_std, dev):
-    """BASELINE.json configs[0] (factorized/configs/bls2017.py: 256 filters, 9x9 / 4 SignalConv2D, GDN), configs[1]
-    (mshyper/configs/mbt2018.py: 192 / 320, 5x5 / 2 SignalConv2D, GDN / IGDN) and the model of configs[4]
-    (mshyper/configs/two_layer_syn2.py: CNNAnalysis 256 -> 320 with leaky_relu, TwoLayerSynthesis) at their real widths, 256 x 256: image -> (bpp, PSNR) of the HIP path against the float64 oracle end to end from pixels, BASELINE tolerance
-    asserted unconditionally.  Random-init weights with the last analysis layer rescaled (and, with a hyperprior, the
-    predicted scales lifted) so that the codec works at a published rate instead of at sigma_min."""
+def _gdn_model(name, factorized, last, y_std, dev, precision="fp32"):
     from shallow_ntc_amd.common import data_lib
     from shallow_ntc_amd.factorized.models import Model as FModel
     from shallow_ntc_amd.mshyper import configs
@@ -144,6 +138,22 @@ def test_gdn_signal_conv_configs_image_to_bpp_psnr_at_full_width(name, factorize
     if last + "/bias" in w:
         w[last + "/bias"] = (w[last + "/bias"] * gain).astype(np.float32)
     model.set_weights(w)
+    if precision != "fp32":
+        model = (FModel if factorized else Model)(device=dev, precision=precision, **cfg)
+        model._step = 10 ** 9
+        model.set_weights(w)
+    return model, w, cfg
+
+
+@pytest.mark.parametrize("name,factorized,last,y_std", GDN_CONFIGS, ids=[c[0] for c in GDN_CONFIGS])
+def test_gdn_signal_conv_configs_image_to_bpp_psnr_at_full_width(name, factorized, last, y_std, dev):
+    """BASELINE.json configs[0] (factorized/configs/bls2017.py: 256 filters, 9x9 / 4 SignalConv2D, GDN), configs[1]
+    (mshyper/configs/mbt2018.py: 192 / 320, 5x5 / 2 SignalConv2D, GDN / IGDN) and the model of configs[4]
+    (mshyper/configs/two_layer_syn2.py: CNNAnalysis 256 -> 320 with leaky_relu, TwoLayerSynthesis) at their real widths, 256 x 256: image -> (bpp, PSNR) of the HIP path against the float64 oracle end to end from pixels, BASELINE tolerance
+    asserted unconditionally.  Random-init weights with the last analysis layer rescaled (and, with a hyperprior, the
+    predicted scales lifted) so that the codec works at a published rate instead of at sigma_min."""
+    from shallow_ntc_amd.common import data_lib
+    model, w, cfg = _gdn_model(name, factorized, last, y_std, dev)
     x = data_lib.normalize_image(data_lib.synthetic_images(1, 256, 256, seed=6))
     lat = model.infer_latent_rvs(x)
     r = model._rate_and_reconstruction(lat, want_symbols=True)
@@ -252,3 +262,59 @@ def test_published_operating_range(name, hw, target, dev):
     assert flips <= max(2, sym.size * 1e-5), rep
     if hw[0] % 64:                                                       # the Tecnick path: the latents live on the padded grid
         assert rep["padded"] == [-(-hw[0] // 64) * 4, -(-hw[1] // 64) * 4], rep
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Split precision (Model(precision="bf16x3")) through the same end-to-end check, all five BASELINE configs at
+# their real widths: not bit-identical to fp32, held to the same bars against the float64 oracle.
+# ---------------------------------------------------------------------------------------------------------------------------
+BF3_CASES = [("two_layer_syn", (512, 768)), ("jpegl", (256, 256)), ("bls2017", (256, 256)), ("mbt2018", (256, 256)),
+             ("two_layer_syn2", (256, 256))]
+
+
+@pytest.mark.parametrize("name,hw", BF3_CASES, ids=[c[0] for c in BF3_CASES])
+def test_bf16x3_image_to_bpp_psnr_at_full_width(name, hw, dev):
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    gdn = {c[0]: c for c in GDN_CONFIGS}
+    factorized = False
+    if name in gdn:
+        _, factorized, last, y_std = gdn[name]
+        model, w, cfg = _gdn_model(name, factorized, last, y_std, dev, precision="bf16x3")
+    else:
+        _, w = _model(name, dev, **OPERATING_POINTS["low_rate"])
+        cfg = configs.CONFIGS[name](rd_lambda=0.02)
+        model = Model(device=dev, precision="bf16x3", **cfg)
+        model._step = 10 ** 9
+        model.set_weights(w)
+    x = data_lib.normalize_image(data_lib.synthetic_images(1, hw[0], hw[1], seed=5 + hw[0]))
+    lat = model.infer_latent_rvs(x)
+    r = model._rate_and_reconstruction(lat, want_symbols=True)
+    _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
+    m = metrics.scalars_float
+    ref_model = model_np.Model(cfg["transform_config"], rd_lambda=0.02, factorized=factorized)
+    ref = ref_model.end_to_end(w, x, be=train_ref)
+    if factorized:
+        sym = r["y_hat"].cpu().numpy()
+        flips = int((np.abs(sym - ref["y_hat"]) > 0.25).sum())
+    else:
+        sym = r["symbols"].cpu().numpy()
+        flips = int((sym != ref["symbols_y"]).sum())
+    rep = dict(precision="bf16x3", symbols=int(sym.size), symbol_flips=flips, bpp_hip=m["bpp"], bpp_f64=float(ref["bpp"]),
+               d_bpp=m["bpp"] - float(ref["bpp"]), psnr_hip=m["psnr"], psnr_f64=float(ref["psnr"]), d_psnr=m["psnr"] - float(ref["psnr"]))
+    if not factorized:                   # the bitstream round trip in this arithmetic: the decoder rebuilds mu / sigma bit for bit
+        xd = torch.from_numpy(x).to(dev)
+        z_hat, symbols = model.encode(xd)[:2]
+        px = model.decode(z_hat, symbols, hw).cpu().numpy()
+        rep["pixel_code_diffs"] = int((px != ref["recon_pixels"].astype(np.uint8)).sum())
+        rep["pixel_values"] = int(px.size)
+    REPORT[f"bf16x3/{name}/{hw[0]}x{hw[1]}"] = rep
+    print(json.dumps({f"bf16x3/{name}": rep}))
+    out = ROOT / "gpurun_out"
+    if out.is_dir():
+        (out / "e2e_parity.json").write_text(json.dumps(REPORT, indent=1))
+    assert 0.05 <= rep["bpp_f64"] <= 8.0, rep
+    assert abs(rep["d_bpp"]) <= 1e-4, rep            # BASELINE.json north_star tolerance
+    assert abs(rep["d_psnr"]) <= 1e-3, rep
+    assert flips <= sym.size * 2e-4, rep

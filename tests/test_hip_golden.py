@@ -49,12 +49,15 @@ def test_ops_fixture(dev):
     np.testing.assert_array_equal(ops.pad_reflect(t(g["pix/x"], dev), 16, 8).cpu().numpy(), g["pix/padded8"])
 
 
-def test_model_fixture(dev):
-    """Reduced-width two_layer_syn (16-channel ELIC blocks also exercise the scalar-gather path)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_model_fixture(precision, dev):
+    """Reduced-width two_layer_syn (16-channel ELIC blocks also exercise the scalar-gather path).  Also in the split-precision
+    mode: at this image size only the layers with at least one 256-row strip per image take it (common/_graph.py::DualPlan),
+    the bars are the same; the full-width counterpart is tests/test_hip_e2e_parity.py::test_bf16x3_image_to_bpp_psnr_at_full_width."""
     from shallow_ntc_amd.mshyper.models import Model
     g = np.load(GOLD / "model_two_layer_small.npz")
     tc = json.loads(str(g["config"]))
-    model = Model(rd_lambda=float(g["rd_lambda"]), transform_config=tc, device=dev)
+    model = Model(rd_lambda=float(g["rd_lambda"]), transform_config=tc, device=dev, precision=precision)
     model._step = 10**9                      # past the lambda warm-up
     w = {k[2:]: g[k] for k in g.files if k.startswith("w/")}
     assert set(w) == set(model.get_weights())
