@@ -233,6 +233,10 @@ int sntc_pad_reflect(const float* x, int n, int h, int w, int c, int hp, int wp,
 int sntc_pad_zero(const float* x, int n, int h, int w, int c, int top, int left, int hp, int wp, float* y, void* stream);
 /* Crop top-left: y[n,h,w,c] from x[n,hp,wp,c]. */
 int sntc_crop(const float* x, int n, int hp, int wp, int c, int h, int w, float* y, void* stream);
+/* tf.nn.depth_to_space(x, block), NHWC: y[n, h*block, w*block, c/block^2] with input channel (dy*block + dx)*(c/block^2) + k
+ * going to output pixel (iy*block + dy, ix*block + dx), channel k -- the upsampling steps of
+ * TwoLayerResSynthesis(res_type="d2s"), common/transforms.py:341-348. */
+int sntc_depth_to_space(const float* x, int n, int h, int w, int c, int block, float* y, void* stream);
 /* Quantise both images to uint8 the reference's way ((v+.5)*255, round-half-even, saturate) and
  * accumulate the per-image integer sum of squared differences.  x_hat may be strided (crop fused):
  * element (b,i,j,k) at x_hat[((b*hs + i)*ws + j)*c + k].  pixels_out (uint8 [n,h,w,c]) may be NULL.

@@ -47,6 +47,15 @@ def append_ones(x):
     return np.concatenate([x, np.ones(x.shape[:3] + (1,), F64)], axis=-1)
 
 
+def depth_to_space(x, block=2):
+    """tf.nn.depth_to_space, NHWC (the upsampling steps of TwoLayerResSynthesis(res_type="d2s"), common/transforms.py:341-348):
+    input channel (dy * block + dx) * C + c -> output pixel (iy * block + dy, ix * block + dx), channel c."""
+    n, h, w, c = x.shape
+    co = c // (block * block)
+    y = x.reshape(n, h, w, block, block, co).transpose(0, 1, 3, 2, 4, 5)
+    return y.reshape(n, h * block, w * block, co)
+
+
 ACTIVATIONS = {None: lambda x: x, "none": lambda x: x, "relu": relu,
                "leaky_relu": leaky_relu, "lrelu": leaky_relu, "sigmoid": sigmoid}
 

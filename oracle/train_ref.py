@@ -51,6 +51,14 @@ def append_ones(x):
     return torch.cat([x, torch.ones_like(x[:, :1])], dim=1)
 
 
+def depth_to_space(x, block=2):
+    """tf.nn.depth_to_space on this backend's NCHW tensors (channel = (dy * block + dx) * C + c, TensorFlow's DCR order)."""
+    n, c, h, w = x.shape
+    co = c // (block * block)
+    y = x.reshape(n, block, block, co, h, w).permute(0, 3, 4, 1, 5, 2)
+    return y.reshape(n, co, h * block, w * block)
+
+
 ACTIVATIONS = {None: lambda x: x, "none": lambda x: x, "relu": F.relu,
                "leaky_relu": lambda x: F.leaky_relu(x, 0.2), "lrelu": lambda x: F.leaky_relu(x, 0.2),
                "sigmoid": torch.sigmoid}

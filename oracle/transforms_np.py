@@ -90,6 +90,23 @@ class GDN(_Layer):
         return 2 * h * w * cin * cin, cin, h, w
 
 
+class DepthToSpace(_Layer):
+    """tf.nn.depth_to_space(x, 2) as a layer (common/transforms.py:342-347)."""
+
+    def __init__(self, block=2):
+        self.block = block
+
+    def shapes(self, cin):
+        assert cin % (self.block * self.block) == 0, cin
+        return OrderedDict(), cin // (self.block * self.block)
+
+    def __call__(self, p, x, be=ops):
+        return be.depth_to_space(x, self.block)
+
+    def flops(self, cin, h, w):
+        return 0, cin // (self.block * self.block), h * self.block, w * self.block
+
+
 class Seq(_Layer):
     def __init__(self, layers):
         self.layers = layers
@@ -398,18 +415,24 @@ class TwoLayerSynthesis(Transform):
 
 
 class TwoLayerResSynthesis(Transform):
-    """common/transforms.py:320-361, res_type='conv':  out_conv(act(base_conv(z)) + res(z))."""
+    """common/transforms.py:320-361:  out_conv(act(base_conv(z)) + res(z)); res is a second stride-8 transposed convolution
+    (res_type='conv') or three depth_to_space steps with two 1x1 leaky-relu convolutions between them (res_type='d2s', :339-348;
+    its variables are named res/conv0, res/conv1 here -- Keras would call them conv2d_<n>)."""
 
     def __init__(self, channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn",
                  res_type="conv", cin=None):
-        if res_type != "conv":
-            raise NotImplementedError(res_type)
         act, extra = _act_layers(activation_type, "act")
         base = [Conv("base_conv", "convT", channels[0], kernel_sizes[0], strides[0], act)]
         if extra is not None:
             base.append(extra)
         self.base = Seq(base)
-        self.res = Conv("res", "convT", channels[0], kernel_sizes[0], strides[0], None)
+        if res_type == "conv":
+            self.res = Conv("res", "convT", channels[0], kernel_sizes[0], strides[0], None)
+        elif res_type == "d2s":
+            self.res = Seq([DepthToSpace(), Conv("res/conv0", "conv", 192, 1, 1, "leaky_relu"), DepthToSpace(),
+                            Conv("res/conv1", "conv", channels[0] * 4, 1, 1, "leaky_relu"), DepthToSpace()])
+        else:
+            raise NotImplementedError(res_type)
         self.out_conv = Conv("out_conv", "convT", channels[1], kernel_sizes[1], strides[1], None)
         self.cin = cin
 

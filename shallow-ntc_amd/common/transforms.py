@@ -26,7 +26,9 @@ def get_activation_op(activation, name="act"):
     if activation is None:
         return None, None
     if activation == "prelu":
-        raise NotImplementedError("prelu is not used by any reference config")
+        # tf.keras.layers.PReLU() with default shared_axes=None owns one alpha per (H, W, C) POSITION of its first input: such a
+        # model only runs at the one resolution it was built at; no reference config uses it (transforms.py:69-70)
+        raise NotImplementedError("prelu: Keras' PReLU has one alpha per spatial position (a fixed-resolution model); not supported")
     a = activation.lower()
     if a in ("gdn", "gdn1"):
         return None, GDN(name, inverse=False)
@@ -268,14 +270,43 @@ class HyperSynthesisSmall(Transform):
 
 class JPEGLikeSynthesis(Transform):
     """reference transforms.py:265-295: one Conv2DTranspose(k, s) mapping each latent vector to an
-    overlapping k x k x 3 patch."""
+    overlapping k x k x 3 patch.  ``use_offset`` (:291-293) appends a channel of ones to the input: the kernel variable then
+    has Cin + 1 input channels; the device plan carries it padded to Cin + 16 (zero weights) so that the layer stays on the
+    16-channel vector loader, and the input gets the ones channel and fifteen zero channels appended per call."""
 
     def __init__(self, output_channels=3, kernel_size=16, strides=16, padding="SAME", use_bias=True, use_offset=False):
         if padding != "SAME":
             raise NotImplementedError("only padding='SAME' is used by the reference configs")
-        if use_offset:
-            raise NotImplementedError("use_offset=True (a constant extra input channel) is not used by any reference config")
+        self._use_offset = bool(use_offset)
         super().__init__(Seq([Conv("conv", "convT", output_channels, kernel_size, strides, None, use_bias)]))
+
+    def param_shapes(self, input_channels=None):
+        cin = input_channels or self._cin
+        if cin is None:
+            raise ValueError("input channels unknown: pass input_channels or call the transform once")
+        return self._graph.shapes(cin + 1 if self._use_offset else cin)[0]
+
+    def _graph_cin(self):
+        return self._cin + 16 if self._use_offset else self._cin
+
+    def _prepare_weights(self, w):
+        if not self._use_offset:
+            return w
+        w = OrderedDict(w)
+        k = w["conv/kernel"]                                  # Keras transposed layout [kh, kw, Cout, Cin + 1]
+        w["conv/kernel"] = np.concatenate([k, np.zeros(k.shape[:3] + (15,), np.float32)], axis=3)
+        return w
+
+    def takes_s3(self, h, w):
+        return not self._use_offset and super().takes_s3(h, w)
+
+    def _forward(self, x):
+        if self._use_offset:
+            n, h, w_, _ = x.shape
+            extra = torch.zeros((n, h, w_, 16), dtype=torch.float32, device=x.device)
+            extra[..., 0] = 1.0
+            x = torch.cat([x, extra], dim=-1)
+        return self._graph(x)
 
 
 class JPEGLikeHyperSynthesis(Transform):
@@ -286,21 +317,29 @@ class JPEGLikeHyperSynthesis(Transform):
 
 
 class _TwoLayerBase(Transform):
-    """Shared driver of the two-layer syntheses: ONE stride-8 transposed conv producing [base | res]
-    (the two 13x13 kernels are concatenated along Cout, since they read the same input), then the
-    fused tail kernel (activation + residual add + 5x5/2 output layer)."""
+    """Shared driver of the two-layer syntheses.  The shapes the reference's configs use (hidden width 12 / 24 / 48, a 5x5
+    stride-2 output layer with 3 channels, a convolutional residual) run as ONE stride-8 transposed conv producing
+    [base | res] (the two 13x13 kernels are concatenated along Cout, since they read the same input) followed by the fused
+    tail kernel (activation + residual add + output layer [+ crop + uint8 + SSE]).  Every other registered shape -- another
+    hidden width or output layer, res_type="d2s" (reference transforms.py:339-348) -- runs layer by layer on the generic
+    plans: base conv (+ relu / leaky-relu in its epilogue), GDN / IGDN, residual branch, add, output conv."""
 
-    def __init__(self, channels, strides, kernel_sizes, activation_type, has_res):
+    def __init__(self, channels, strides, kernel_sizes, activation_type, has_res, res_type="conv"):
         self._ch, self._out_ch = int(channels[0]), int(channels[1])
         self._s, self._k = tuple(strides), tuple(kernel_sizes)
         self._has_res = has_res
+        if res_type not in ("conv", "d2s"):
+            raise NotImplementedError(f"res_type {res_type!r}")           # as the reference (transforms.py:349-350)
+        self._res_type = res_type if has_res else None
         a = None if activation_type is None else activation_type.lower()
         if a not in ops.TAIL_ACTS:
             raise NotImplementedError(f"activation {activation_type!r} in the two-layer synthesis")
+        self._act_name = {"lrelu": "leaky_relu", "none": None}.get(a, a)
         self._act_kind = ops.TAIL_ACTS[a]
-        if self._ch not in ops.TAIL_CHANNELS or self._k[1] != 5 or self._s[1] != 2 or self._out_ch != 3:
-            raise NotImplementedError("two-layer synthesis tail is fused for hidden channels 12/24/48, "
-                                      "5x5 stride-2 output layer, 3 output channels (the reference configs)")
+        self._fused = (self._ch in ops.TAIL_CHANNELS and self._k[1] == 5 and self._s[1] == 2 and self._out_ch == 3)
+        self._merged = self._fused and self._res_type != "d2s"     # [base | res] from one launch, then the fused tail
+        if self._res_type == "d2s" and self._s[0] != 8:
+            raise ValueError("res_type='d2s' upsamples by 2 x 2 x 2: the first layer's stride must be 8")
         super().__init__(None)
         self._names = ("base_conv", "res", "out_conv") if has_res else ("conv1", None, "conv2")
 
@@ -315,9 +354,16 @@ class _TwoLayerBase(Transform):
         if self._act_kind in (1, 2):
             d["act/beta"] = (self._ch,)
             d["act/gamma"] = (self._ch, self._ch)
-        if nr:
+        if self._res_type == "conv":
             d[f"{nr}/kernel"] = (self._k[0], self._k[0], self._ch, cin)
             d[f"{nr}/bias"] = (self._ch,)
+        elif self._res_type == "d2s":
+            if cin % 4 or (192 % 4) or (self._ch * 4) % 4:
+                raise ValueError(f"res_type='d2s' needs input channels divisible by 4, got {cin}")
+            d[f"{nr}/conv0/kernel"] = (1, 1, cin // 4, 192)               # Keras names them conv2d_<n>; ours: res/conv0, res/conv1
+            d[f"{nr}/conv0/bias"] = (192,)
+            d[f"{nr}/conv1/kernel"] = (1, 1, 48, self._ch * 4)
+            d[f"{nr}/conv1/bias"] = (self._ch * 4,)
         d[f"{n2}/kernel"] = (self._k[1], self._k[1], self._out_ch, self._ch)
         d[f"{n2}/bias"] = (self._out_ch,)
         return d
@@ -336,36 +382,83 @@ class _TwoLayerBase(Transform):
             return self
         w = self.get_weights()
         n1, nr, n2 = self._names
+        dv = lambda a: ops.to_device(a, device)
         k1, b1 = w[f"{n1}/kernel"], w[f"{n1}/bias"]
-        if nr:
+        merged = self._merged
+        if merged and nr:
             k1 = np.concatenate([k1, w[f"{nr}/kernel"]], axis=2)
             b1 = np.concatenate([b1, w[f"{nr}/bias"]])
         with torch.cuda.device(device):
-            self._up = DualPlan("convT", ops.to_device(k1, device), ops.to_device(b1, device), self._s[0], precision=self._precision)
-        self._beta = ops.to_device(w["act/beta"], device) if "act/beta" in w else None
-        self._gamma = ops.to_device(w["act/gamma"], device) if "act/gamma" in w else None
-        self._w2 = ops.to_device(w[f"{n2}/kernel"], device)
-        self._b2 = ops.to_device(w[f"{n2}/bias"], device)
+            epi_act = self._act_name if (not self._fused and self._act_kind in (3, 4)) else None     # else the tail / GDN node applies it
+            self._up = DualPlan("convT", dv(k1), dv(b1), self._s[0], epi_act, precision=self._precision)
+            self._res_plan = self._d2s = self._out_plan = None
+            if self._res_type == "conv" and not merged:
+                self._res_plan = ops.ConvPlan("convT", dv(w[f"{nr}/kernel"]), dv(w[f"{nr}/bias"]), self._s[0])
+            if self._res_type == "d2s":
+                self._d2s = (ops.ConvPlan("conv", dv(w[f"{nr}/conv0/kernel"]), dv(w[f"{nr}/conv0/bias"]), 1, "leaky_relu"),
+                             ops.ConvPlan("conv", dv(w[f"{nr}/conv1/kernel"]), dv(w[f"{nr}/conv1/bias"]), 1, "leaky_relu"))
+            if not self._fused:
+                self._out_plan = ops.ConvPlan("convT", dv(w[f"{n2}/kernel"]), dv(w[f"{n2}/bias"]), self._s[1])
+            self._gdn_plan = None
+            if self._act_kind in (1, 2) and not self._fused and self._ch not in ops.GDN_SMALL_CHANNELS:
+                from .. import _capi as capi
+                epi = capi.EPI_RES_MUL if self._act_kind == 1 else capi.EPI_RES_DIV
+                self._gdn_plan = ops.ConvPlan("conv", dv(w["act/gamma"].reshape(1, 1, self._ch, self._ch)), dv(w["act/beta"]), 1, None,
+                                              capi.PRO_ABS, epi)
+        self._beta = dv(w["act/beta"]) if "act/beta" in w else None
+        self._gamma = dv(w["act/gamma"]) if "act/gamma" in w else None
+        self._w2 = dv(w[f"{n2}/kernel"])
+        self._b2 = dv(w[f"{n2}/bias"])
         self.output_channels = self._out_ch
         self._built_on = device
         return self
 
     def takes_s3(self, h, w):
-        return self._built_on is not None and self._up.takes_s3(h, w)
+        return self._built_on is not None and self._merged and self._up.takes_s3(h, w)
+
+    def _res_d2s(self, x):
+        c0, c1 = self._d2s
+        return ops.depth_to_space(c1(ops.depth_to_space(c0(ops.depth_to_space(x)))))
+
+    def _hidden(self, x):
+        """Layer by layer: act(base_conv(x)) + res(x), fp32 [n, 8h, 8w, ch]."""
+        base = self._up(x)                                        # relu / leaky-relu already applied in its epilogue
+        if self._act_kind in (1, 2):
+            if self._gdn_plan is not None:
+                base = self._gdn_plan(base, res=base)
+            else:
+                base = ops.gdn_small(base, self._beta, self._gamma, inverse=self._act_kind == 1)
+        if self._res_type == "conv":
+            base = ops.axpy(base, self._res_plan(x))
+        elif self._res_type == "d2s":
+            base = ops.axpy(base, self._res_d2s(x))
+        return base
+
+    def _tail_input(self, x):
+        """[base | res] for the fused tail: one launch, or (d2s) the two branches concatenated."""
+        if self._merged:
+            return self._up(x)
+        return torch.cat([self._up(x), self._res_d2s(x)], dim=-1)
 
     def _forward(self, x):
-        t = self._up(x)
-        return ops.two_layer_tail(t, self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
-                                  self._w2, self._b2, self._k[1], self._s[1])
+        if self._fused:
+            return ops.two_layer_tail(self._tail_input(x), self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
+                                      self._w2, self._b2, self._k[1], self._s[1])
+        return self._out_plan(self._hidden(x))
 
     def forward_pixels(self, x, h, w, reference=None):
-        """Decoder form: the synthesis ends in uint8 pixels cropped to h x w (and the integer SSE against ``reference``)
-        in the same launch as the activation and the output layer -- no float image round trip."""
+        """Decoder form: the synthesis ends in uint8 pixels cropped to h x w (and the integer SSE against ``reference``);
+        for the fused shapes in the same launch as the activation and the output layer -- no float image round trip."""
         if self._built_on != x.device:
             self.build(x.shape[-1] if x.dim() == 4 else x.shape[3] * 16, x.device)
-        t = self._up(x)
-        return ops.two_layer_tail_pixels(t, self._ch, self._has_res, self._act_kind, self._beta, self._gamma, self._w2, self._b2,
-                                         h, w, reference, self._k[1], self._s[1])
+        if self._fused:
+            return ops.two_layer_tail_pixels(self._tail_input(x), self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
+                                             self._w2, self._b2, h, w, reference, self._k[1], self._s[1])
+        recon = self._out_plan(self._hidden(x))
+        if reference is None:
+            return ops.to_pixels(recon, h, w), None
+        sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
+        return px, sse
 
 
 class TwoLayerSynthesis(_TwoLayerBase):
@@ -376,12 +469,10 @@ class TwoLayerSynthesis(_TwoLayerBase):
 
 
 class TwoLayerResSynthesis(_TwoLayerBase):
-    """reference transforms.py:320-361 (res_type='conv')."""
+    """reference transforms.py:320-361."""
 
     def __init__(self, channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn", res_type="conv"):
-        if res_type != "conv":
-            raise NotImplementedError("res_type='d2s' is not used by any reference config")
-        super().__init__(channels, strides, kernel_sizes, activation_type, has_res=True)
+        super().__init__(channels, strides, kernel_sizes, activation_type, has_res=True, res_type=res_type)
 
 
 class ElicAnalysis(Transform):

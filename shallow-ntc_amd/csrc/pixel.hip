@@ -328,6 +328,33 @@ extern "C" int sntc_crop(const float* x, int n, int hp, int wp, int c, int h, in
   return SNTC_OK;
 }
 
+// tf.nn.depth_to_space(x, block) in NHWC (DCR order: input channel = (dy * block + dx) * C_out + c): the upsampling step of
+// TwoLayerResSynthesis(res_type="d2s"), reference common/transforms.py:341-348.  One thread per output element.
+__global__ void __launch_bounds__(256) depth_to_space_kernel(const float* __restrict__ x, int h, int w, int c, int bs,
+                                                             float* __restrict__ y, int64_t total) {
+  const int co = c / (bs * bs);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % co);
+    int64_t r = i / co;
+    const int ox = (int)(r % ((int64_t)w * bs));
+    r /= (int64_t)w * bs;
+    const int oy = (int)(r % ((int64_t)h * bs));
+    const int64_t n = r / ((int64_t)h * bs);
+    const int iy = oy / bs, dy = oy - iy * bs, ix = ox / bs, dx = ox - ix * bs;
+    y[i] = x[((n * h + iy) * w + ix) * c + (dy * bs + dx) * co + ch];
+  }
+}
+
+extern "C" int sntc_depth_to_space(const float* x, int n, int h, int w, int c, int block, float* y, void* stream) {
+  if (!x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_depth_to_space: null argument");
+  if (n < 1 || h < 1 || w < 1 || block < 1 || c < 1 || c % (block * block))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_depth_to_space: channels must be a multiple of block^2");
+  const int64_t total = (int64_t)n * h * w * c;
+  hipLaunchKernelGGL(depth_to_space_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, h, w, c, block, y, total);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
 extern "C" int sntc_pixels_sse(const float* x, const float* x_hat, int n, int h, int w, int c, int hs, int ws,
                                uint8_t* pixels_out, unsigned long long* sse_out, void* stream) {
   if (!x_hat || (x && !sse_out) || (!x && !pixels_out)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_pixels_sse: null argument");

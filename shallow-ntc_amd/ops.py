@@ -403,6 +403,17 @@ def pad_reflect(x, hp, wp):
     return y
 
 
+def depth_to_space(x, block=2):
+    """tf.nn.depth_to_space in NHWC (sntc_depth_to_space)."""
+    _check_nhwc(x)
+    n, h, w, c = x.shape
+    if c % (block * block):
+        raise ValueError(f"depth_to_space: {c} channels are not a multiple of {block * block}")
+    y = torch.empty((n, h * block, w * block, c // (block * block)), dtype=torch.float32, device=x.device)
+    capi.call("sntc_depth_to_space", _ptr(x), n, h, w, c, int(block), _ptr(y), _stream())
+    return y
+
+
 def crop(x, h, w):
     _check_nhwc(x)
     n, hp, wp, c = x.shape

@@ -90,6 +90,9 @@ class TwoLayerBackward:
     """Forward-with-cache and input-gradient of TwoLayer[Res]Synthesis."""
 
     def __init__(self, t: _TwoLayerBase):
+        if not t._merged:
+            raise NotImplementedError("gradients through the two-layer synthesis exist for the shapes the reference's configs use "
+                                      "(hidden width 12 / 24 / 48, 5x5 / 2 output layer, convolutional residual); this one runs forward only")
         self.t = t
         dev = t._w2.device
         w = t.get_weights()

@@ -324,6 +324,9 @@ class TTwoLayer:
     [base | res], the hidden layer (IGDN1 + add), the 5x5/2 output layer."""
 
     def __init__(self, store, pre, t: _TwoLayerBase, cin):
+        if not t._merged:
+            raise NotImplementedError("gradients through the two-layer synthesis exist for the shapes the reference's configs use "
+                                      "(hidden width 12 / 24 / 48, 5x5 / 2 output layer, convolutional residual); this one runs forward only")
         self.t, self.pre = t, pre
         c2 = t._ch * (2 if t._has_res else 1)
         self.up = TConv(store, f"{pre}/up", "convT", t._k[0], t._s[0], cin, c2, None, True)

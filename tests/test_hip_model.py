@@ -54,6 +54,13 @@ TRANSFORMS = [  # cls, kwargs, input shape (n,h,w,c)
     ("TwoLayerSynthesis", dict(channels=(24, 3)), (1, 3, 4, 64)),
     ("TwoLayerSynthesis", dict(channels=(48, 3)), (1, 2, 3, 64)),
     ("TwoLayerResSynthesis", dict(channels=(12, 3)), (2, 4, 3, 64)),
+    # registered shapes no reference config uses (common/transforms.py:291-293, 339-348; other hidden widths / output layers)
+    ("JPEGLikeSynthesis", dict(kernel_size=18, strides=16, use_offset=True), (2, 3, 4, 64)),
+    ("TwoLayerResSynthesis", dict(channels=(12, 3), res_type="d2s"), (2, 4, 3, 64)),
+    ("TwoLayerResSynthesis", dict(channels=(8, 3), res_type="d2s", activation_type=None), (1, 2, 2, 64)),
+    ("TwoLayerSynthesis", dict(channels=(16, 3), activation_type="relu"), (1, 3, 4, 64)),
+    ("TwoLayerResSynthesis", dict(channels=(20, 3)), (1, 2, 3, 64)),
+    ("TwoLayerSynthesis", dict(channels=(24, 3), kernel_sizes=(13, 3), activation_type="leaky_relu"), (1, 2, 2, 64)),
 ]
 
 
@@ -77,6 +84,16 @@ def test_transform_parity(cls, kwargs, shape, dev):
     ref = ref_t(w, x)
     assert got.shape == ref.shape
     assert rel_err(got, ref) < 5e-5
+    if hasattr(t, "forward_pixels"):                     # the decoder form of the two-layer syntheses: same image, as uint8, cropped
+        from shallow_ntc_amd import ops
+        xd = torch.from_numpy(x).to(dev)
+        hh, ww = got.shape[1] - 3, got.shape[2] - 5
+        px, sse = t.forward_pixels(xd, hh, ww)
+        assert sse is None and torch.equal(px, ops.to_pixels(t(xd), hh, ww))
+        refimg = torch.rand((got.shape[0], hh, ww, got.shape[3]), device=dev) - 0.5
+        px2, sse2 = t.forward_pixels(xd, hh, ww, reference=refimg)
+        want_sse, want_px = ops.pixels_sse(refimg, t(xd), want_pixels=True)
+        assert torch.equal(px2, want_px) and torch.equal(sse2.to(torch.int64), want_sse.to(torch.int64))
 
 
 def _small_cfg(synth):
@@ -87,7 +104,10 @@ def _small_cfg(synth):
     dict(cls="TwoLayerResSynthesis", channels=(12, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn", res_type="conv"),
     dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16),
     dict(cls="TwoLayerSynthesis", channels=(24, 3), strides=(8, 2), kernel_sizes=(13, 5), activation_type="igdn"),
-], ids=["two_layer_res", "jpeg_like", "two_layer"])
+    dict(cls="TwoLayerResSynthesis", channels=(12, 3), res_type="d2s"),                       # reference transforms.py:339-348
+    dict(cls="JPEGLikeSynthesis", kernel_size=18, strides=16, use_offset=True),               # :291-293
+    dict(cls="TwoLayerSynthesis", channels=(16, 3), activation_type="relu"),                  # a hidden width off the fused tail
+], ids=["two_layer_res", "jpeg_like", "two_layer", "two_layer_res_d2s", "jpeg_like_offset", "two_layer_16"])
 def test_mshyper_model_parity(synth, dev):
     """bpp / PSNR of the HIP path vs the oracle on the same image + weights.  The latents are compared
     first; rate and distortion are then checked with the oracle evaluated on the HIP latents so that a

@@ -72,7 +72,22 @@ TRANSFORMS = [
     ("MBT2018Synthesis", dict(channels_base=16, cin=24), (1, 2, 2, 24)),
     ("CNNAnalysis", dict(channels_base=16, output_channels=24, activation_type="gdn"), (1, 32, 32, 3)),
     ("JPEGLikeHyperSynthesis", dict(bottleneck_size=16), (1, 2, 2, 16)),
+    ("TwoLayerResSynthesis", dict(cin=32, res_type="d2s"), (1, 3, 2, 32)),                  # transforms.py:339-348
+    ("JPEGLikeSynthesis", dict(kernel_size=18, strides=16, use_offset=True, cin=32), (1, 2, 3, 32)),      # :291-293
+    ("TwoLayerSynthesis", dict(cin=32, channels=(16, 3), activation_type="relu"), (1, 2, 2, 32)),
 ]
+
+
+def test_depth_to_space_is_tensorflows_dcr_order():
+    """tf.nn.depth_to_space(x, 2), NHWC: out[n, 2i + dy, 2j + dx, c] = x[n, i, j, (2 dy + dx) C + c]; both backends."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 2, 12)).astype(np.float32)
+    y = O.depth_to_space(x, 2)
+    assert y.shape == (2, 6, 4, 3)
+    for dy in range(2):
+        for dx in range(2):
+            np.testing.assert_array_equal(y[:, dy::2, dx::2, :], x[..., (2 * dy + dx) * 3:(2 * dy + dx + 1) * 3])
+    np.testing.assert_array_equal(R.to_nhwc(R.depth_to_space(R.as_input(x), 2)), y)
 
 
 @pytest.mark.parametrize("cls,kw,shape", TRANSFORMS, ids=[t[0] + str(i) for i, t in enumerate(TRANSFORMS)])
