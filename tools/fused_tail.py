@@ -30,13 +30,18 @@ second = ops.ConvPlan("conv", torch.randn((1, 1, 96, 192), device=dev, generator
                       capi.PRO_NONE, capi.EPI_ADD)
 
 
-def timed(fn):
+def timed(fn, burst=6):
+    """Median over bursts of back-to-back launches (a lone launch from an idle stream carries ~0.1 ms of host latency)."""
     ts = []
     for rep in range(args.reps + 3):
+        fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(burst):
+            fn()
+        e1.record(); torch.cuda.synchronize()
         if rep >= 3:
-            ts.append(e0.elapsed_time(e1))
+            ts.append(e0.elapsed_time(e1) / burst)
     return float(np.median(ts))
 
 
