@@ -193,6 +193,12 @@ int64_t sntc_conv_tune_workspace_bytes(const sntc_conv_plan* plan, int n, int h,
 int sntc_conv_plan_tune(sntc_conv_plan* plan, const float* x, int n, int h, int w, float* y, const float* res,
                         const float* aux, void* workspace, size_t workspace_bytes, int reps, int* variant, int* stream_k,
                         void* stream);
+/* The candidates sntc_conv_plan_tune would time for this call shape (returns how many were written, < 0 on a bad shape), and a
+ * way to record a choice made elsewhere -- e.g. by timing a whole step with several streams in flight, where a schedule
+ * measured with the device to itself is not the best one (bench.py does this for its two-stream decode).  Same remark as above:
+ * cuDNN's algorithm selection behind tf.nn.conv2d (common/transforms.py:81-90) is the reference-side counterpart. */
+int sntc_conv_plan_candidates(const sntc_conv_plan* plan, int n, int h, int w, int* variants, int* stream_k, int capacity);
+int sntc_conv_plan_set_choice(sntc_conv_plan* plan, int n, int h, int w, int variant, int stream_k);
 int sntc_conv_plan_clear_tuning(sntc_conv_plan* plan);
 
 /* ------------------------------------------------------------------------------------------

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sntc_conv_plan_tune": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), _P]),
     "sntc_conv_plan_clear_tuning": (C.c_int, [_P]),
+    "sntc_conv_plan_candidates": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "sntc_conv_plan_set_choice": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sntc_gdn_small": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_two_layer_tail": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,
                                       C.c_int, C.c_int, C.c_int, _P, _P]),

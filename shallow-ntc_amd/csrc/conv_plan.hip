@@ -921,6 +921,34 @@ extern "C" int sntc_conv_plan_tune(sntc_conv_plan* p, const float* x, int n, int
   return SNTC_OK;
 }
 
+extern "C" int sntc_conv_plan_set_choice(sntc_conv_plan* p, int n, int h, int w, int variant, int stream_k) {
+  if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_choice: null plan");
+  Geo g;
+  int rc = geometry(p, h, w, &g);
+  if (rc) return rc;
+  TuneChoice c;
+  c.variant = variant;
+  c.sk = stream_k ? 1 : 0;
+  const Sched s = schedule(p, g, n, false, &c);
+  if (!s.valid || s.variant != variant || (stream_k && !s.sk))
+    return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_choice: not a candidate of this plan for this call shape");
+  std::lock_guard<std::mutex> lk(p->tune_mu);
+  p->tuned[{n, h, w}] = c;
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_plan_candidates(const sntc_conv_plan* p, int n, int h, int w, int* variants, int* stream_k, int capacity) {
+  if (!p || !variants || !stream_k || capacity < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_candidates: bad argument");
+  Geo g;
+  if (geometry(p, h, w, &g)) return -1;
+  std::vector<std::pair<TuneChoice, Sched>> cand;
+  tune_candidates(p, g, n, &cand);
+  int k = 0;
+  for (auto& c : cand)
+    if (k < capacity) { variants[k] = c.first.variant; stream_k[k] = c.first.sk; ++k; }
+  return k;
+}
+
 extern "C" int sntc_conv_plan_clear_tuning(sntc_conv_plan* p) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_clear_tuning: null plan");
   std::lock_guard<std::mutex> lk(p->tune_mu);

@@ -234,6 +234,19 @@ class ConvPlan:
         capi.call("sntc_conv_plan_clear_tuning", self._h)
         self._tuned = {}
 
+    def candidates(self, n, h, w):
+        """[(variant, stream_k)] this plan could run a call of this shape with (all give identical bits)."""
+        v, s = (C.c_int * 32)(), (C.c_int * 32)()
+        k = int(capi.load().sntc_conv_plan_candidates(self._h, int(n), int(h), int(w), v, s, 32))
+        if k < 0:
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, capi.last_error())
+        return [(v[i], s[i]) for i in range(k)]
+
+    def set_choice(self, n, h, w, variant, stream_k):
+        """Record (variant, stream_k) as the schedule of calls of this shape (sntc_conv_plan_set_choice)."""
+        capi.call("sntc_conv_plan_set_choice", self._h, int(n), int(h), int(w), int(variant), int(bool(stream_k)))
+        self._tuned[(int(n), int(h), int(w))] = (int(variant), int(bool(stream_k)))
+
     def __call__(self, x, res=None, aux=None, out=None):
         if self.s3:
             _check_s3(x, self.cin)
@@ -257,6 +270,8 @@ class ConvPlan:
             return y
         if AUTOTUNE and (n, h, w) not in self._tuned:
             self.tune(x, res, aux, reps=AUTOTUNE)
+        if LAUNCH_LOG is not None:
+            LAUNCH_LOG.append((self, int(n), int(h), int(w)))
         prof = PROFILE
         if prof is not None:     # bench.py: HIP events on the launch stream around this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -284,6 +299,7 @@ def check_conv_status():
                                            "the results since the last check are invalid; stream-K is now off, run the step again")
 
 
+LAUNCH_LOG = None       # a list: every ConvPlan call appends (plan, n, h, w) -- tune_step() uses it to find a step's launches
 AUTOTUNE = False       # inside ``with ops.autotune():`` every ConvPlan measures its launch schedule the first time it sees a shape
 
 
@@ -306,6 +322,60 @@ class autotune:
         global AUTOTUNE
         AUTOTUNE = self._old
         return False
+
+
+def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None):
+    """Choose the schedules of a whole step by the step's own clock: ``step_fn`` (which may use several streams and must join
+    them back into the current stream) is run once to find its convolution launches; then, launch by launch (longest
+    contraction first), every (tile, schedule) candidate is tried and kept if the median time of ``reps`` steps improves by
+    more than ``min_gain``.  For steps whose launches overlap on the device -- where a schedule measured with the device to
+    itself (``autotune``) can be the wrong one.  All candidates give identical bits.  Returns (ms before, ms after)."""
+    global LAUNCH_LOG
+
+    def clock():
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step_fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    LAUNCH_LOG = []
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+        launches = list(dict.fromkeys(LAUNCH_LOG))               # unique (plan, n, h, w), first-seen order
+    finally:
+        LAUNCH_LOG = None
+    launches.sort(key=lambda e: -e[0].flops(e[1], e[2], e[3]))
+    for _ in range(3):
+        step_fn()
+    base = best = clock()
+    for plan, n, h, w in launches[:max_launches]:
+        if plan.rowpack:
+            continue
+        start = plan.launch_info(n, h, w)
+        chosen = None
+        for v, sk in plan.candidates(n, h, w):
+            plan.set_choice(n, h, w, v, sk)
+            t = clock()
+            if t < best * (1.0 - min_gain):
+                best, chosen = t, (v, sk)
+        if chosen is None:
+            plan._tuned.pop((n, h, w), None)
+            capi.call("sntc_conv_plan_clear_tuning", plan._h)    # back to the cost model for every shape of this plan ...
+            for (nn, hh, ww), (vv, ss) in list(plan._tuned.items()):
+                capi.call("sntc_conv_plan_set_choice", plan._h, nn, hh, ww, vv, ss)      # ... but the ones already chosen
+        else:
+            plan.set_choice(n, h, w, *chosen)
+        if log is not None:
+            log.append(dict(layer=f"{plan.kind} k{plan.k[0]} s{plan.stride} {plan.cin}->{plan.cout}", shape=[n, h, w], model=list(start),
+                            chosen=None if chosen is None else list(chosen), step_ms=round(best, 4)))
+    return base, best
 
 
 def set_stream_k(enabled):

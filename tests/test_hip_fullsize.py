@@ -362,6 +362,7 @@ def test_tuned_schedule_is_a_speed_choice_only(dev):
     """sntc_conv_plan_tune measures the (tile, schedule) candidates of a plan for one call shape and records the fastest; the
     bits do not change (every candidate is the same k-ordered chain), other shapes and forced tiles are unaffected, and the
     entry can be cleared."""
+    from shallow_ntc_amd import _capi as capi
     from shallow_ntc_amd import ops
     g = torch.Generator(device=dev)
     g.manual_seed(11)
@@ -390,6 +391,38 @@ def test_tuned_schedule_is_a_speed_choice_only(dev):
         assert (1, shape[1], shape[2]) in p._tuned
         p.clear_tuning()
         assert p.launch_info(*shape) == info0
+        # the candidate list, and a choice recorded from outside (ops.tune_step does this from a whole step's clock)
+        cands = p.candidates(*shape)
+        assert (v, sk) in cands and len(cands) >= 2
+        ov, osk = next(c for c in cands if c != (v, sk))
+        p.set_choice(*shape, ov, osk)
+        assert p.launch_info(*shape)[0] == ov and torch.equal(p(x), before)
+        with pytest.raises(capi.SntcError):
+            p.set_choice(*shape, 10, 0)                                      # 256 x 128 is never a candidate
+        p.clear_tuning()
+    # a whole step on two streams chosen by its own clock: same bits whatever it settles on
+    pa = ops.ConvPlan("convT", torch.randn((3, 3, 64, 64), device=dev, generator=g) * 0.05, None, 1, "relu")
+    pb = ops.ConvPlan("conv", torch.randn((3, 3, 64, 64), device=dev, generator=g) * 0.05, None, 1)
+    xa = torch.randn((6, 32, 48, 64), device=dev, generator=g)
+    xb = torch.randn((2, 48, 32, 64), device=dev, generator=g)
+    want = (pa(xa).clone(), pb(xb).clone())
+    side = torch.cuda.Stream(device=dev)
+    outs = {}
+
+    def step():
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            outs["b"] = pb(xb)
+        outs["a"] = pa(xa)
+        cur.wait_stream(side)
+
+    log = []
+    t0, t1 = ops.tune_step(step, reps=4, log=log)
+    assert t1 <= t0 and len(log) == 2
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(outs["a"], want[0]) and torch.equal(outs["b"], want[1])
     # a pre-split bf16 x 3 plan tunes over its own two tiles
     wk = torch.randn((3, 3, 64, 64), device=dev, generator=g) * 0.05
     x = torch.randn((4, 32, 48, 64), device=dev, generator=g)
