@@ -243,6 +243,9 @@ int sntc_crop(const float* x, int n, int hp, int wp, int c, int h, int w, float*
  * going to output pixel (iy*block + dy, ix*block + dx), channel k -- the upsampling steps of
  * TwoLayerResSynthesis(res_type="d2s"), common/transforms.py:341-348. */
 int sntc_depth_to_space(const float* x, int n, int h, int w, int c, int block, float* y, void* stream);
+/* y[npix, ca + cb] = [a | b] along the channel axis (tf.concat(..., axis=-1)); b == NULL appends a channel of ones and cb - 1 zero
+ * channels instead: the constant input of JPEGLikeSynthesis(use_offset=True), common/transforms.py:291-293, padded to a 16-channel slab. */
+int sntc_concat_channels(const float* a, int ca, const float* b, int cb, int64_t npix, float* y, void* stream);
 /* Quantise both images to uint8 the reference's way ((v+.5)*255, round-half-even, saturate) and
  * accumulate the per-image integer sum of squared differences.  x_hat may be strided (crop fused):
  * element (b,i,j,k) at x_hat[((b*hs + i)*ws + j)*c + k].  pixels_out (uint8 [n,h,w,c]) may be NULL.

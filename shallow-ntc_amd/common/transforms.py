@@ -302,10 +302,7 @@ class JPEGLikeSynthesis(Transform):
 
     def _forward(self, x):
         if self._use_offset:
-            n, h, w_, _ = x.shape
-            extra = torch.zeros((n, h, w_, 16), dtype=torch.float32, device=x.device)
-            extra[..., 0] = 1.0
-            x = torch.cat([x, extra], dim=-1)
+            x = ops.concat_channels(x, None, 16)
         return self._graph(x)
 
 
@@ -438,7 +435,7 @@ class _TwoLayerBase(Transform):
         """[base | res] for the fused tail: one launch, or (d2s) the two branches concatenated."""
         if self._merged:
             return self._up(x)
-        return torch.cat([self._up(x), self._res_d2s(x)], dim=-1)
+        return ops.concat_channels(self._up(x), self._res_d2s(x))
 
     def _forward(self, x):
         if self._fused:

@@ -328,6 +328,27 @@ extern "C" int sntc_crop(const float* x, int n, int hp, int wp, int c, int h, in
   return SNTC_OK;
 }
 
+// y[p, :ca] = a[p, :], y[p, ca:ca+cb] = b[p, :] -- or, with b == NULL, a channel of ones followed by cb - 1 zero channels (the
+// constant input channel of JPEGLikeSynthesis(use_offset=True), reference common/transforms.py:291-293, padded to a 16-channel slab).
+__global__ void __launch_bounds__(256) concat_channels_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb,
+                                                              float* __restrict__ y, int64_t total) {
+  const int c = ca + cb;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c;
+    const int k = (int)(i - p * c);
+    y[i] = k < ca ? a[p * ca + k] : (b ? b[p * cb + (k - ca)] : (k == ca ? 1.0f : 0.0f));
+  }
+}
+
+extern "C" int sntc_concat_channels(const float* a, int ca, const float* b, int cb, int64_t npix, float* y, void* stream) {
+  if (!a || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_concat_channels: null argument");
+  if (npix < 1 || ca < 1 || cb < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_concat_channels: bad sizes");
+  const int64_t total = npix * (ca + cb);
+  hipLaunchKernelGGL(concat_channels_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, a, ca, b, cb, y, total);
+  SNTC_HIP(hipGetLastError());
+  return SNTC_OK;
+}
+
 // tf.nn.depth_to_space(x, block) in NHWC (DCR order: input channel = (dy * block + dx) * C_out + c): the upsampling step of
 // TwoLayerResSynthesis(res_type="d2s"), reference common/transforms.py:341-348.  One thread per output element.
 __global__ void __launch_bounds__(256) depth_to_space_kernel(const float* __restrict__ x, int h, int w, int c, int bs,

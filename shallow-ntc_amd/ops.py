@@ -473,6 +473,20 @@ def pad_reflect(x, hp, wp):
     return y
 
 
+def concat_channels(a, b=None, extra=16):
+    """[a | b] along the channel axis; with ``b`` None: a channel of ones and ``extra`` - 1 zero channels (sntc_concat_channels)."""
+    _check_nhwc(a)
+    n, h, w, ca = a.shape
+    if b is not None:
+        _check_nhwc(b)
+        if tuple(b.shape[:3]) != (n, h, w):
+            raise ValueError(f"concat_channels: {tuple(a.shape)} vs {tuple(b.shape)}")
+    cb = int(b.shape[-1]) if b is not None else int(extra)
+    y = torch.empty((n, h, w, ca + cb), dtype=torch.float32, device=a.device)
+    capi.call("sntc_concat_channels", _ptr(a), ca, _ptr(b), cb, n * h * w, _ptr(y), _stream())
+    return y
+
+
 def depth_to_space(x, block=2):
     """tf.nn.depth_to_space in NHWC (sntc_depth_to_space)."""
     _check_nhwc(x)
