@@ -825,17 +825,6 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   }
   a.tps = tile0;
   a.ups = (int)unit0;
-  a.order = 1;                             // fp32 stream-K: strip-major units ...
-  {
-    // ... unless the launch's packed weights do not fit an XCD's 4 MB L2: then the column tile goes outermost, so that each
-    // XCD's workers keep "their" weight rows resident instead of streaming the whole matrix past once per row strip
-    int64_t wbytes = 0;
-    for (int gi = 0; gi < p->ngroups; ++gi) wbytes += (int64_t)p->g[gi].Ncol * p->g[gi].K * 4;
-    if (sc.sk && wbytes > (4 << 20)) a.order = 0;
-#ifdef SNTC_DIAG
-    if (getenv("SNTC_SK_ORDER")) a.order = atoi(getenv("SNTC_SK_ORDER"));      // tools/ab_order.sh (make DIAG=1)
-#endif
-  }
   if (p->s3) {
     a.order = p->dma == 0 ? 1 : 0;        // sntc_conv_plan_set_schedule's stage-path bit doubles as the unit-order A/B switch here
     // patch staging: the taps of a slab sample the input at unit stride, and every group's patch (tile rows + the tap window's

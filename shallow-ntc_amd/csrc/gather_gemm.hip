@@ -209,34 +209,17 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
     // tile order: row strip major, then group, then column tile -- every worker's share mixes the groups (their tiles
     // differ in length, so a group-major order would hand some workers only short, epilogue-heavy tiles) and one strip's
     // input rows serve all groups while they are hot in L2
-    // a.order == 0: COLUMN tile outermost, row strips inside (u = ntm * unit0(g) + nt * ntm * steps + mt * steps + k): the workers
-    // of one XCD own a contiguous eighth of the range, i.e. a few column tiles, whose weight rows then stay in that XCD's 4 MB
-    // L2 while the strips stream past -- for layers whose packed weights exceed the L2 (hyper-synthesis: 11 - 15 MB), where the
-    // strip-major order streams the whole matrix through every XCD once per strip (HBM-side traffic 12 x the algorithmic bytes)
     auto locate = [&](int u, int* t, int* k, int* steps) {
+      const int mt = u / a.ups;
+      const int r = u - mt * a.ups;
       int gi = 0;
-      if (a.order == 1) {
-        const int mt = u / a.ups;
-        const int r = u - mt * a.ups;
 #pragma unroll
-        for (int i = 1; i < kMaxGroups; ++i)
-          if (i < a.ngroups && r >= (int)a.g[i].unit0) gi = i;
-        const int r2 = r - (int)a.g[gi].unit0;
-        const int nt = r2 / a.g[gi].steps;
-        *t = mt * a.tps + a.g[gi].tile0 + nt;
-        *k = r2 - nt * a.g[gi].steps;
-      } else {
-#pragma unroll
-        for (int i = 1; i < kMaxGroups; ++i)
-          if (i < a.ngroups && u >= (int)a.g[i].unit0 * a.ntm) gi = i;
-        const int r = u - (int)a.g[gi].unit0 * a.ntm;
-        const int per = a.ntm * a.g[gi].steps;
-        const int nt = r / per;
-        const int r2 = r - nt * per;
-        const int mt = r2 / a.g[gi].steps;
-        *t = (a.g[gi].tile0 + nt) * a.ntm + mt;
-        *k = r2 - mt * a.g[gi].steps;
-      }
+      for (int i = 1; i < kMaxGroups; ++i)
+        if (i < a.ngroups && r >= (int)a.g[i].unit0) gi = i;
+      const int r2 = r - (int)a.g[gi].unit0;
+      const int nt = r2 / a.g[gi].steps;
+      *t = mt * a.tps + a.g[gi].tile0 + nt;
+      *k = r2 - nt * a.g[gi].steps;
       *steps = a.g[gi].steps;
     };
     if (u_hi > u_lo) {
@@ -255,8 +238,8 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
 
   auto tile_of = [&](int t, Piece* p) {          // global tile id -> (group, row strip, column tile): column fastest
     KArgs& a = fresh_args();
-    const int mt = a.order == 1 ? t / a.tps : t % a.ntm;
-    const int r = a.order == 1 ? t - mt * a.tps : t / a.ntm;
+    const int mt = t / a.tps;
+    const int r = t - mt * a.tps;
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroups; ++i)
