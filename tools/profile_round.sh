@@ -1,5 +1,7 @@
 # rocprofv3 evidence for profiles/ (round 3): kernel stats + PMC passes of the decode-only bench AND of the encode-side layer
 # table, the layer tables (Kodak batch and W1), the loop-ceiling microbench, the default bench line.  Program directly after `--`.
+# NOTE: gpurun MERGES what this writes into the local gpurun_out/prof_r03 -- delete that directory locally before a re-run, or
+# stale *_kernel_stats.csv / *_counter_collection.csv of the previous run are averaged into tools/summarize_pmc.py's output.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r03; rm -rf $O; mkdir -p $O
 SQ="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"
