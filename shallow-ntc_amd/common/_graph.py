@@ -18,7 +18,10 @@ from .. import _capi as capi
 from .. import ops
 
 
-S3_MIN_ROWS = 256      # a layer runs on the pre-split bf16 x 3 kernel when one IMAGE offers at least one 256-row strip of its GEMM
+S3_MIN_ROWS = 256      # a layer runs on the pre-split bf16 x 3 kernel when one IMAGE offers at least one 256-row strip of its GEMM ...
+S3_MIN_TILES = 12      # ... and at least this many 256 x 128 tiles: the kernel runs one workgroup per CU, and a layer that offers a
+                       # batch only a few dozen tiles leaves most CUs idle (5x5/2 320 -> 320 at 1/32 resolution: 6 tiles per image,
+                       # 0.52 ms against the fp32 kernel's 0.32 ms on 18 images; the hyper-synthesis layers offer 30)
 
 
 def s3_eligible(kind, cin, cout, epilogue):
@@ -49,7 +52,11 @@ class DualPlan:
         self.cin, self.cout = self.fp32.cin, self.fp32.cout
 
     def takes_s3(self, h, w):
-        return self.s3 is not None and s3_rows(self.kind, self.stride, h, w) >= S3_MIN_ROWS
+        if self.s3 is None:
+            return False
+        rows = s3_rows(self.kind, self.stride, h, w)
+        cols = self.cout * (self.stride * self.stride if self.kind in ("convT", "sigup") else 1)
+        return rows >= S3_MIN_ROWS and (-(-rows // 256)) * (-(-cols // 128)) >= S3_MIN_TILES
 
     def __call__(self, x, res=None, aux=None):
         if self.takes_s3(x.shape[1], x.shape[2]):

@@ -24,11 +24,12 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--config", default="two_layer_syn")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--decode-only", action="store_true")
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"])
 ap.add_argument("--autotune", action="store_true", help="measure every plan's (tile, schedule) candidates first (ops.autotune), as bench.py does for its encoder-side regions")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 ops.FORCE_TILE = args.variant
-model = Model(device=dev, **configs.CONFIGS[args.config]())
+model = Model(device=dev, precision=args.precision, **configs.CONFIGS[args.config]())
 n, (h, w) = args.batch, args.hw
 x = (torch.rand((n, h, w, 3), device=dev) - 0.5).contiguous()
 
