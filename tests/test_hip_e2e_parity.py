@@ -227,14 +227,28 @@ def _model_at_bpp(name, dev, x, target):
     return model, w
 
 
-@pytest.mark.parametrize("name,hw,target", PUBLISHED_RANGE, ids=[f"{n}-{h}x{w}-{t}bpp" for n, (h, w), t in PUBLISHED_RANGE])
-def test_published_operating_range(name, hw, target, dev):
+PUBLISHED_RANGE_P = [c + ("fp32",) for c in PUBLISHED_RANGE] + [
+    ("two_layer_syn", (512, 768), 0.12, "bf16x3"), ("two_layer_syn", (512, 768), 0.5, "bf16x3")]
+
+
+@pytest.mark.parametrize("name,hw,target,precision", PUBLISHED_RANGE_P,
+                         ids=[f"{n}-{h}x{w}-{t}bpp" + ("" if p == "fp32" else "-" + p) for n, (h, w), t, p in PUBLISHED_RANGE_P])
+def test_published_operating_range(name, hw, target, precision, dev):
     """The same unconditional bars (|d bpp| <= 1e-4, |d PSNR| <= 1e-3 dB, image -> metrics from pixels, float32 GPU against
     the float64 oracle) at ~0.12 / 0.25 / 0.5 bpp at Kodak size and on the padded Tecnick path."""
     from shallow_ntc_amd.common import data_lib
     from shallow_ntc_amd.mshyper import configs
     x = data_lib.normalize_image(data_lib.synthetic_images(1, hw[0], hw[1], seed=31 + hw[0]))
     model, w = _model_at_bpp(name, dev, x, target)
+    if precision != "fp32":              # the same weights in split precision (DESIGN.md 4.1b): same bars; and its bitstream round trip
+        from shallow_ntc_amd.mshyper.models import Model
+        model = Model(device=dev, quality_metrics=False, precision=precision, **configs.CONFIGS[name](rd_lambda=0.02))
+        model._step = 10 ** 9
+        model.set_weights(w)
+        xd = torch.from_numpy(x).to(dev)
+        blob = model.compress(xd)
+        z_hat, symbols = model.encode(xd)[:2]
+        assert torch.equal(model.decompress(blob), model.decode(z_hat, symbols, hw))
     lat = model.infer_latent_rvs(x)
     r = model._rate_and_reconstruction(lat, want_symbols=True)
     _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
@@ -250,8 +264,9 @@ def test_published_operating_range(name, hw, target, dev):
                d_bpp=m["bpp"] - float(ref["bpp"]), psnr_hip=m["psnr"], psnr_f64=float(ref["psnr"]), d_psnr=m["psnr"] - float(ref["psnr"]),
                symbols_nonzero=float((sym != 0).mean()), symbols_abs_max=int(np.abs(sym).max()),
                scale_index_range=[float(idx.min()), float(idx.max())], padded=[int(v) for v in lat.uq[1].loc.shape[1:3]])
-    REPORT[f"{name}/{hw[0]}x{hw[1]}/{target}bpp"] = rep
-    print(json.dumps({f"{name}/{hw[0]}x{hw[1]}/{target}bpp": rep}))
+    key = f"{name}/{hw[0]}x{hw[1]}/{target}bpp" if precision == "fp32" else f"{precision}/{name}/{hw[0]}x{hw[1]}/{target}bpp"
+    REPORT[key] = rep
+    print(json.dumps({key: rep}))
     out = ROOT / "gpurun_out"
     if out.is_dir():
         (out / "e2e_parity.json").write_text(json.dumps(REPORT, indent=1))
