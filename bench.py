@@ -440,6 +440,8 @@ def main():
             singles = [port.pop(0) if i in (3, 8, 9, 16, 17, 18) else land.pop(0) for i in range(24)]
         b1 = {}
         keep_q = model._quality_metrics
+        model._quality_metrics = False
+        tune(lambda: [list(model.evaluate(singles, lookahead=look)) for look in (1, 4)])      # the one-, two- and four-image launch shapes
         for label, quality, look in (("psnr_only_serial", False, 1), ("psnr_only", False, 4), ("with_msssim_serial", True, 1),
                                      ("with_msssim", True, 4)):
             model._quality_metrics = quality
