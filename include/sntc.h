@@ -187,7 +187,9 @@ int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* 
  * chains, so the choice is a question of speed only; sntc_conv_plan_tune times them on the caller's buffers for one (n, h, w)
  * (`reps` launches each, HIP events on `stream`, synchronises it) and records the winner in the plan: later calls of that shape
  * run it instead of the cost model's pick (a forced tile / schedule still wins).  `workspace` >= sntc_conv_tune_workspace_bytes().
- * y holds the layer's output afterwards.  The reference has no counterpart of its own: TensorFlow's convolutions pick their
+ * y holds the layer's output afterwards.  A recorded choice can change what sntc_conv_workspace_bytes() reports for that shape: tune
+ * (or set a choice) before other threads size their workspaces for it, not while they are between the query and the launch.
+ * The reference has no counterpart of its own: TensorFlow's convolutions pick their
  * algorithm by cuDNN autotune the same way (tf.nn.conv2d behind common/transforms.py:81-90). */
 int64_t sntc_conv_tune_workspace_bytes(const sntc_conv_plan* plan, int n, int h, int w);
 int sntc_conv_plan_tune(sntc_conv_plan* plan, const float* x, int n, int h, int w, float* y, const float* res,
