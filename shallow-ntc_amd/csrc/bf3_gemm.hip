@@ -116,10 +116,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) bf3_kernel(const GGArgs a) {
     const int w = blockIdx.x;
     wl = (w & 7) * (a.nworkers >> 3) + (w >> 3);
     const int u_lo = (int)(a.units * wl / a.nworkers), u_hi = (int)(a.units * (wl + 1) / a.nworkers);
-    // Unit order: COLUMN tile outermost, row strips inside (u = ntm * unit0(g) + nt * ntm * steps + mt * steps + k): the
-    // workers of one XCD own a contiguous eighth of the range, i.e. one or two column tiles, whose weight rows (a 128-column
-    // tile of the 480 -> 640 layer is 3.3 MB in S3) then stay in that XCD's 4 MB L2 while the strips stream past.
-    // a.order == 1: the fp32 kernel's strip-major order (column tile fastest), kept for the A/B.
+    // Unit order (a.order == 1, the default): row strip major, then group, then column tile -- every worker's share mixes the
+    // groups (their tiles differ in length: a group-major order hands some workers only short, epilogue-heavy tiles).
+    // a.order == 0: COLUMN tile outermost, row strips inside (u = ntm * unit0(g) + nt * ntm * steps + mt * steps + k): a tile's
+    // weight rows stay in one XCD's L2 while the strips stream past; measured equal on single-group layers and 20 % slower on
+    // the four-group synthesis, kept for the A/B.
     auto locate = [&](int u, int* t, int* k, int* steps) {
       int gi = 0;
       if (a.order == 1) {

@@ -826,7 +826,10 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
   a.tps = tile0;
   a.ups = (int)unit0;
   if (p->s3) {
-    a.order = p->dma == 0 ? 1 : 0;        // sntc_conv_plan_set_schedule's stage-path bit doubles as the unit-order A/B switch here
+    // stream-K unit order: strip-major, as the fp32 kernel (every worker's share mixes the phase groups; with the column tile
+    // outermost the last workers of the 13x13/8 synthesis get nothing but 20-stage tiles: 0.55 against 0.45 ms).  The column-major
+    // order stays selectable for the A/B: sntc_conv_plan_set_schedule's stage-path bit ("off") doubles as the switch here
+    a.order = p->dma == 0 ? 0 : 1;
     // patch staging: the taps of a slab sample the input at unit stride, and every group's patch (tile rows + the tap window's
     // reach in flattened macro pixels + a zero row) fits the patch buffers; <= 32 taps (the kernel keeps one validity bit per tap
     // and row)

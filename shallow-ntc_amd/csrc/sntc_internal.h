@@ -88,7 +88,7 @@ struct GGArgs {
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   int halo;            // bf3_gemm.hip: 1 = patch staging (one activation patch per channel slab shared by its taps); needs sA == 1
                        // and every group's patch within bf3p_patch_rows_max()
-  int order;           // bf3_gemm.hip stream-K unit order: 0 column tile outermost (default), 1 strip-major (as gather_gemm.hip)
+  int order;           // bf3_gemm.hip stream-K unit order: 1 strip-major (default, as gather_gemm.hip), 0 column tile outermost (A/B)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
                        // 8 skip fragment reads, 16 skip the epilogue's stores, 32 its residual loads, 64 the MFMAs, 128 the fused
                        // ResidualBlock tail's second contraction -- to see what a launch waits on; results are meaningless with any bit set
