@@ -204,7 +204,10 @@ class ResidualBlock:
 
     def __call__(self, x):
         a, b, c = self._convs
-        if b.plan.fusable_with(c.plan):                 # c = 192: the 3x3 and the 1x1 + skip run as one launch
+        # c = 192: the 3x3 and the 1x1 + skip run as one launch -- where the launch has the rows to fill the device: the fused
+        # instance's 128-row workgroups run both contractions back to back, and below ~192 of them the two stand-alone launches
+        # (64 x 64 tiles, deep ring) are faster (6144 rows: 0.038 against 0.075 ms; 24576: equal; bit-identical either way)
+        if x.shape[0] * x.shape[1] * x.shape[2] >= ops.FUSED_TAIL_MIN_ROWS and b.plan.fusable_with(c.plan):
             return b.plan.fused(c.plan, a(x), res=x)
         return c(b(a(x)), res=x)
 

@@ -299,6 +299,7 @@ def check_conv_status():
                                            "the results since the last check are invalid; stream-K is now off, run the step again")
 
 
+FUSED_TAIL_MIN_ROWS = 24576      # ResidualBlock tails smaller than this run as two launches (common/_graph.py::ResidualBlock)
 LAUNCH_LOG = None       # a list: every ConvPlan call appends (plan, n, h, w) -- tune_step() uses it to find a step's launches
 AUTOTUNE = False       # inside ``with ops.autotune():`` every ConvPlan measures its launch schedule the first time it sees a shape
 
