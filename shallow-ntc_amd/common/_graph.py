@@ -37,6 +37,15 @@ def s3_rows(kind, stride, h, w):
     return (-(-h // stride)) * (-(-w // stride))
 
 
+def s3_geometry_ok(kind, stride, cout, h, w):
+    """Geometry part of the rule -- a function of the LAYER and of ONE image's size, never of the batch: at least one 256-row
+    strip per image and at least S3_MIN_TILES 256 x 128 tiles per image (GEMM columns: Cout, times stride^2 output phases for the
+    transposed kinds)."""
+    rows = s3_rows(kind, stride, h, w)
+    cols = cout * (stride * stride if kind in ("convT", "sigup") else 1)
+    return rows >= S3_MIN_ROWS and (-(-rows // 256)) * (-(-cols // 128)) >= S3_MIN_TILES
+
+
 class DualPlan:
     """A convolution's fp32 plan and, under ``precision="bf16x3"``, its pre-split split-precision plan.  Which of the two
     runs is a function of the LAYER and of the per-image geometry only -- never of the batch size -- so an encoder and a
@@ -52,11 +61,7 @@ class DualPlan:
         self.cin, self.cout = self.fp32.cin, self.fp32.cout
 
     def takes_s3(self, h, w):
-        if self.s3 is None:
-            return False
-        rows = s3_rows(self.kind, self.stride, h, w)
-        cols = self.cout * (self.stride * self.stride if self.kind in ("convT", "sigup") else 1)
-        return rows >= S3_MIN_ROWS and (-(-rows // 256)) * (-(-cols // 128)) >= S3_MIN_TILES
+        return self.s3 is not None and s3_geometry_ok(self.kind, self.stride, self.cout, h, w)
 
     def __call__(self, x, res=None, aux=None):
         if self.takes_s3(x.shape[1], x.shape[2]):

@@ -201,3 +201,24 @@ def test_learning_rate_schedule_matches_the_reference_closed_form():
         want = 1e-3 * (0.5 if step >= int(0.5 * 50) else 1.0) * min(1.0, (step + 1) / 7)
         got = compression_lr(dict(learning_rate=1e-3, reduce_lr_after=0.5, reduce_lr_factor=0.5, warmup_steps=7), 50, step)
         assert got == pytest.approx(want)
+
+
+def test_bf16x3_layer_rule_is_a_function_of_layer_and_image_geometry():
+    """common/_graph.py: which convolutions take the split-precision kernel under Model(precision="bf16x3") -- decided from the
+    layer and ONE image's size only (an encoder and a decoder must agree whatever their batching), here for the layers of the
+    two_layer_syn model at Kodak size."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd.common import _graph as G
+    ok = G.s3_geometry_ok
+    # hyper-synthesis on 32 x 48 latents: 8 x 12 -> 16 x 24 -> 32 x 48 -> (mu, sigma)
+    assert not ok("convT", 2, 320, 8, 12)            # 96 rows per image: fp32 (its split-K / deep-ring instances)
+    assert ok("convT", 2, 480, 16, 24)               # 384 rows x 1920 phase columns: 30 tiles per image
+    assert ok("convT", 1, 640, 32, 48)               # 1536 rows x 640 columns: 30 tiles
+    assert ok("convT", 8, 24, 32, 48)                # the 13x13 / 8 synthesis: 1536 columns
+    assert ok("conv", 2, 192, 512, 768) and ok("conv", 2, 320, 128, 192)      # the encoder's 5x5 / 2 layers
+    assert not ok("conv", 2, 320, 32, 48)            # 5x5 / 2 320 -> 320 down to 1/32 resolution: 6 tiles per image, slower pre-split
+    assert G.s3_rows("convT", 2, 16, 24) == 384 and G.s3_rows("conv", 2, 515, 771) == 258 * 386
+    st = G.s3_eligible
+    assert st("conv", 192, 96, capi.EPI_STORE) and st("convT", 320, 24, capi.EPI_ADD)
+    assert not st("conv", 3, 192, capi.EPI_STORE) and not st("convT", 320, 3, capi.EPI_STORE)      # Cin % 16, Cout % 4
+    assert not st("conv", 192, 192, capi.EPI_RES_DIV)                                               # GDN epilogues stay fp32
