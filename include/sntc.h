@@ -149,6 +149,29 @@ int sntc_conv_fusable(const sntc_conv_plan* first, const sntc_conv_plan* second)
 int64_t sntc_conv_fused_workspace_bytes(const sntc_conv_plan* first, int n, int h, int w);
 int sntc_conv_forward_fused(const sntc_conv_plan* first, const sntc_conv_plan* second, const float* x, int n, int h, int w, float* y,
                             const float* res, const float* aux, void* workspace, size_t workspace_bytes, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * The whole ResidualBlock (reference common/elic.py:41-68; inside SimpleAttention :85-100 and ElicAnalysis :147-163) in
+ * ONE launch:  y = x + conv1x1_{c/2 -> c}( relu(conv3x3_{c/2 -> c/2}( relu(conv1x1_{c -> c/2}(x)) )) ),  NHWC fp32.
+ * A workgroup owns an 8 x 32 pixel tile: the 1x1 head is computed on the tile's 10 x 34 halo patch straight into LDS
+ * (out-of-image patch pixels = the 3x3's SAME zero padding), the 3x3's nine taps are nine shifted reads of that patch, and
+ * its accumulators feed the 1x1 tail + skip from the registers -- neither c/2-channel intermediate touches HBM.  Every
+ * output is the same k-ordered fp32 fma chain as in the three sntc_conv_forward launches: bit-identical to them, for any
+ * batch size and any number of workgroups.
+ *   w0 [1,1,c,c/2], w1 [3,3,c/2,c/2], w2 [1,1,c/2,c]: the Keras HWIO kernels (device pointers); b0, b1, b2: biases or NULL.
+ * sntc_resblock_supported(c): 1 where the kernel exists (c = 192), else 0 -- callers then run the three layers.
+ * x and y must not alias (tiles read their neighbours' halo); n*h*w*c*4 < 2 GiB per call. */
+typedef struct sntc_resblock_plan sntc_resblock_plan;
+int sntc_resblock_supported(int c);
+int sntc_resblock_plan_create(int c, const float* w0, const float* b0, const float* w1, const float* b1,
+                              const float* w2, const float* b2, void* stream, sntc_resblock_plan** plan);
+int sntc_resblock_plan_update(sntc_resblock_plan* plan, const float* w0, const float* b0, const float* w1, const float* b1,
+                              const float* w2, const float* b2, void* stream);
+void sntc_resblock_plan_destroy(sntc_resblock_plan* plan);
+/* Algorithmic 2*MAC FLOPs of one call: 2 n h w (c c/2 + 9 (c/2)^2 + c/2 c), the three layers' sntc_conv_flops. */
+int64_t sntc_resblock_flops(const sntc_resblock_plan* plan, int n, int h, int w);
+int sntc_resblock_forward(const sntc_resblock_plan* plan, const float* x, int n, int h, int w, float* y, void* stream);
+/* Cap the persistent workgroups of THIS plan's launches (0 = one per CU): tests assert that results do not depend on it. */
+int sntc_resblock_plan_set_workgroups(sntc_resblock_plan* plan, int max_workgroups);
 /* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
  * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */
 int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);

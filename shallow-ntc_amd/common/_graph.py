@@ -191,6 +191,7 @@ class ResidualBlock:
     def __init__(self, name):
         self.name = name
         self._convs = None
+        self._block = None
 
     def _mk(self, c):
         n = self.name
@@ -205,10 +206,19 @@ class ResidualBlock:
         c = cin
         for l in self._convs:
             c = l.build(w, c)
+        # the whole block as one launch (csrc/rb_fused.hip), bit-identical to the three layers below
+        self._block = None
+        if ops.FUSE_RESIDUAL_BLOCK and ops.ResBlockPlan.supported(cin):
+            n = self.name
+            self._block = ops.ResBlockPlan(w[f"{n}/conv0/kernel"], w.get(f"{n}/conv0/bias"), w[f"{n}/conv1/kernel"],
+                                           w.get(f"{n}/conv1/bias"), w[f"{n}/conv2/kernel"], w.get(f"{n}/conv2/bias"))
         return cin
 
     def __call__(self, x):
         a, b, c = self._convs
+        if (self._block is not None and ops.FUSE_RESIDUAL_BLOCK and x.dtype == torch.float32
+                and ops.ResBlockPlan.tiles(*x.shape[:3]) >= ops.FUSED_BLOCK_MIN_TILES):
+            return self._block(x)
         # c = 192: the 3x3 and the 1x1 + skip run as one launch -- where the launch has the rows to fill the device: the fused
         # instance's 128-row workgroups run both contractions back to back, and below ~192 of them the two stand-alone launches
         # (64 x 64 tiles, deep ring) are faster (6144 rows: 0.038 against 0.075 ms; 24576: equal; bit-identical either way)

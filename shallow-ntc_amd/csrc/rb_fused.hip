@@ -1,0 +1,531 @@
+// rb_fused.hip -- the ELIC ResidualBlock (reference common/elic.py:41-68) as ONE launch on a 2-D pixel tile:
+//
+//     y = x + conv1x1_{c/2 -> c}( relu(conv3x3_{c/2 -> c/2}( relu(conv1x1_{c -> c/2}(x)) )) )
+//
+// A workgroup (512 threads = 8 waves, one per CU: the tile's patch fills the LDS) owns a tile of 8 rows x 32 pixels:
+//   head   the 1x1 head on the (8+2) x (32+2) HALO patch, accumulated TRANSPOSED (weights = MFMA A operand, pixels = B
+//          operand read straight from global memory, 16 B per lane): lane l then holds pixel l % 32 and four consecutive
+//          channels per register quad -- one 16-B chunk of the patch's LDS image [16-channel slab][patch pixel][16], so
+//          relu(acc + b0) goes to LDS with ds_write_b128 and out-of-image pixels become the 3x3's zero padding;
+//   3x3    nine taps = nine SHIFTED fragment reads of that one patch (32 consecutive patch pixels per fragment: the
+//          XOR swizzle stays conflict-free under any shift) -- no per-tap global gathers, no staging writes; wave w owns
+//          tile row w and all c/2 output channels (lane = pixel, registers = channels);
+//   tail   relu(acc + b1) is, as it stands in the registers, the B operand of the 1x1 tail (k = lane half, channel quads
+//          in the fragment order of a 16-deep stage); the result leaves with bias, the skip (+ x) and 16-B stores.
+// The three weight sets travel as ONE stream of 6-KB units (a unit = the LDS image of one 16-deep K stage of all c/2
+// output rows) through a three-slot ring filled by LDS-DMA (buffer_load_dwordx4 ... lds, 1-KB pieces); the
+// workgroup is persistent and the stream wraps from one tile's tail into the next tile's head.
+//
+// Every output element is the SAME k-ordered fp32 fma chain as in the three stand-alone gather-GEMM launches
+// (gather_gemm.hip: stage = 16 channels, MFMA e of k-group g sums k in {8g+e, 8g+4+e}; 3x3: channel slab outermost,
+// taps inside; products commute, zero padding contributes fma(0, w, acc)), so results are bit-identical to them.
+#include <algorithm>
+#include <mutex>
+#include <type_traits>
+#include "sntc_internal.h"
+
+namespace sntc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;   // beyond any buffer (< 2 GiB, host check): loads give zeros, stores are dropped
+
+template <int C>
+struct RBCfg {
+  static constexpr int CH = C / 2;             // hidden channels
+  static constexpr int NT = CH / 32;           // 32-channel tiles of the hidden width
+  static constexpr int SL = CH / 16;           // 16-channel slabs of the hidden width
+  static constexpr int TH = 8, TW = 32;        // output tile: rows (= waves) x pixels (= one MFMA fragment)
+  static constexpr int PW = TW + 2, PH = TH + 2, PP = PW * PH;   // halo patch
+  static constexpr int NPT = (PP + 31) / 32;   // 32-pixel tiles of the patch the head computes
+  static constexpr int UNIT = CH * 16;         // floats per ring unit
+  static constexpr int U0 = C / 16;            // head units: K stages of the c -> c/2 contraction
+  static constexpr int U1 = SL * 9;            // 3x3 units: (slab, tap)
+  static constexpr int U2 = (C / 32) * 2;      // tail units: (32-channel output tile, half of K = c/2)
+  static constexpr int UT = U0 + U1 + U2;
+  static constexpr int RING = 3;
+  static constexpr int PATCH = SL * PP * 16;   // floats
+  static constexpr int BIAS = CH + CH + C;     // floats: b0 | b1 | b2
+  static constexpr size_t LDS = (size_t)(PATCH + RING * UNIT + BIAS) * 4;
+  static_assert(UT % RING == 0 && U0 % RING == 0 && (U0 + U1) % RING == 0, "ring slots are compile-time per step");
+  static_assert((UNIT * 4) % 1024 == 0, "a unit is a whole number of 1-KB LDS-DMA pieces (64 lanes x 16 B)");
+  static_assert(NPT > 8 && NPT <= 16, "head: every wave one patch tile, the first NPT - 8 waves two");
+};
+
+struct RBArgs {
+  const float* x;
+  float* y;
+  const float* wpack;      // [UT][CH][16] ring units, LDS image order (swizzled)
+  const float* bias;       // [CH + CH + C]: b0 | b1 | b2 (zeros where a layer has none)
+  unsigned bytes;          // size of x and of y
+  int N, H, W;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rsrc, f32x4 v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
+}
+
+#define RB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int C>
+__global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
+  using K = RBCfg<C>;
+  constexpr int CH = K::CH, NT = K::NT, SL = K::SL, PW = K::PW, PP = K::PP, UNIT = K::UNIT;
+  constexpr int U0 = K::U0, U1 = K::U1, UT = K::UT, RING = K::RING;
+  typedef __attribute__((address_space(3))) void lds_void;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* patch = reinterpret_cast<float*>(smem);        // [SL][PP][16], 16-B chunks XOR-swizzled by (pixel >> 2) & 3
+  float* ring = patch + K::PATCH;                       // [RING][CH][16], the packed units as they are
+  float* lbias = ring + RING * UNIT;                    // b0 | b1 | b2
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // this workgroup's contiguous range of tiles; workgroups b, b + 8, ... (one XCD under round-robin placement) own one
+  // contiguous eighth of the launch, so the halo rows neighbouring tiles share are L2 hits (speed only)
+  const int G = gridDim.x, b = blockIdx.x;
+  const int wl = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
+  const int t_lo = (int)((long long)a.ntiles * wl / G);
+  const int t_hi = (int)((long long)a.ntiles * (wl + 1) / G);
+  if (t_lo >= t_hi) return;
+
+  const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ws =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, UT * UNIT * 4, 0x00020000);
+
+  // weight fragments: row = 32 j + l31 of the unit, 16-B chunk (2 g + h) ^ ((row >> 2) & 3): k = 8 g + 4 h + e in element e
+  const int swz = (l31 >> 2) & 3;
+  const int woff0 = l31 * 16 + (((0 + h) ^ swz) << 2);
+  const int woff1 = l31 * 16 + (((2 + h) ^ swz) << 2);
+  auto read_w = [&](f32x4 (&F)[NT], int slot, int g) {
+    const float* base = ring + slot * UNIT + (g ? woff1 : woff0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) F[j] = *reinterpret_cast<const f32x4*>(base + j * 32 * 16);
+  };
+
+  // unit `unit` (of the stream, already wrapped) -> ring slot `slot`: a linear copy in 1-KB pieces (one wave instruction,
+  // 16 B per lane), piece i by wave i % 8
+  const unsigned dma_voff = (unsigned)lane * 16u;
+  auto dma = [&](int unit, int slot) {
+#pragma unroll
+    for (int i = 0; i < (UNIT * 4) / 1024; i += 8) {
+      if (i + wave < (UNIT * 4) / 1024) {
+        float* dst = ring + slot * UNIT + (i + wave) * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)dst, 16, (int)dma_voff, unit * (UNIT * 4) + (i + wave) * 1024, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // end of a step: everything this wave has in flight has landed (VM = stores the wave may leave outstanding), then the
+  // workgroup barrier publishes the unit the step's DMA brought (it is consumed two steps later, prefetched from one later)
+  auto end_step = [&](auto VM) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(VM)::value) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using VM0 = std::integral_constant<int, 0>;
+  using VM4 = std::integral_constant<int, 4>;
+
+  // ---- once per workgroup: biases into LDS, units 0 and 1 into the ring
+  for (int i = tid; i < K::BIAS; i += 512) lbias[i] = a.bias[i];
+  dma(0, 0);
+  dma(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 Fw0[NT], Fw1[NT], FwN[NT];
+  read_w(Fw0, 0, 0);
+
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    const int per = a.tiles_x * a.tiles_y;
+    const int n = tile / per;
+    const int r = tile - n * per;
+    const int tyi = r / a.tiles_x;
+    const int y0 = tyi * K::TH;
+    const int x0 = (r - tyi * a.tiles_x) * K::TW;
+
+    // ================================================================================================
+    // head: t1 = relu(W0 x + b0) on the halo patch, zero outside the image
+    // ================================================================================================
+    auto head = [&](auto NPXc) {
+      constexpr int NPX = decltype(NPXc)::value;
+      unsigned voff[NPX];
+      bool valid[NPX];
+      int pp[NPX];
+#pragma unroll
+      for (int p = 0; p < NPX; ++p) {
+        pp[p] = 32 * (wave + 8 * p) + l31;
+        const int py = pp[p] / PW;
+        const int px = pp[p] - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        valid[p] = pp[p] < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        voff[p] = valid[p] ? ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)(C * 4) + (unsigned)h * 16u) : kOOB;
+      }
+      f32x16 acc[NT][NPX];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int p = 0; p < NPX; ++p)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[j][p][e] = 0.0f;
+      f32x4 X[2][NPX][2];
+#pragma unroll
+      for (int p = 0; p < NPX; ++p) {
+        X[0][p][0] = buf_load(xs, voff[p], 0);
+        X[0][p][1] = buf_load(xs, voff[p], 32);
+      }
+      static_for<0, U0>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        dma(j + 2, (j + 2) % RING);
+        if constexpr (j + 1 < U0) {
+#pragma unroll
+          for (int p = 0; p < NPX; ++p) {
+            X[(j + 1) & 1][p][0] = buf_load(xs, voff[p], (j + 1) * 64);
+            X[(j + 1) & 1][p][1] = buf_load(xs, voff[p], (j + 1) * 64 + 32);
+          }
+        }
+        read_w(Fw1, j % RING, 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw0[jt][e], X[j & 1][p][0][e], acc[jt][p]);
+        read_w(FwN, (j + 1) % RING, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw1[jt][e], X[j & 1][p][1][e], acc[jt][p]);
+        // every memory instruction behind an MFMA that covers its issue slot (mask 0x8 MFMA, 0x20 VMEM read, 0x100 DS read)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (j + 1 < U0) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NPX, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX - 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
+        if constexpr (j == U0 - 1) {
+          // registers 4 q .. 4 q + 3 of tile jt = channels 32 jt + 8 q + 4 h + (0..3) of pixel l31: chunk 2 (q & 1) + h of slab 2 jt + (q >> 1)
+#pragma unroll
+          for (int p = 0; p < NPX; ++p) {
+            const int sw = (pp[p] >> 2) & 3;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + 32 * jt + 8 * q + 4 * h);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = valid[p] ? fmaxf(acc[jt][p][4 * q + e] + bv[e], 0.0f) : 0.0f;
+                if (pp[p] < PP)
+                  *reinterpret_cast<f32x4*>(patch + (2 * jt + (q >> 1)) * (PP * 16) + pp[p] * 16 + (((2 * (q & 1) + h) ^ sw) << 2)) = v;
+              }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        end_step(VM0{});
+      });
+    };
+    if (wave < K::NPT - 8) head(std::integral_constant<int, 2>{});
+    else head(std::integral_constant<int, 1>{});
+
+    // ================================================================================================
+    // 3x3: wave w = tile row w, lane = pixel, registers = the c/2 output channels
+    // ================================================================================================
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    const int bpp = wave * PW + l31;
+    auto px_off = [&](int tap, int g) {
+      const int p = bpp + (tap / 3) * PW + (tap % 3);
+      return p * 16 + ((((2 * g + h) ^ ((p >> 2) & 3))) << 2);
+    };
+    f32x4 Fp0 = *reinterpret_cast<const f32x4*>(patch + px_off(0, 0));
+    f32x4 Fp1, FpN;
+#pragma unroll 1
+    for (int cc = 0; cc < SL; ++cc) {
+      const float* pslab = patch + cc * (PP * 16);
+      static_for<0, 9>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        dma(U0 + cc * 9 + t + 2, (t + 2) % RING);          // < UT: the last units belong to the tail
+        read_w(Fw1, t % RING, 1);
+        Fp1 = *reinterpret_cast<const f32x4*>(pslab + px_off(t, 1));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[jt] = RB_MFMA(Fw0[jt][e], Fp0[e], acc[jt]);
+        read_w(FwN, (t + 1) % RING, 0);
+        if constexpr (t < 8) FpN = *reinterpret_cast<const f32x4*>(pslab + px_off(t + 1, 0));
+        else FpN = *reinterpret_cast<const f32x4*>(patch + min(cc + 1, SL - 1) * (PP * 16) + px_off(0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[jt] = RB_MFMA(Fw1[jt][e], Fp1[e], acc[jt]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
+        Fp0 = FpN;
+        end_step(VM0{});
+      });
+    }
+
+    // ================================================================================================
+    // tail: y = x + W2 relu(acc + b1) + b2; the accumulators are the B operand as they stand
+    // ================================================================================================
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + CH + 32 * jt + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[jt][4 * q + e] = fmaxf(acc[jt][4 * q + e] + bv[e], 0.0f);
+      }
+    const int oy = y0 + wave, ox = x0 + l31;
+    const unsigned poff = (oy < a.H && ox < a.W) ? ((unsigned)((n * a.H + oy) * a.W + ox) * (unsigned)(C * 4) + (unsigned)h * 16u) : kOOB;
+    static_for<0, C / 32>([&](auto OT) {
+      constexpr int ot = decltype(OT)::value;
+      f32x4 R[4];
+      f32x16 acc2;
+      static_for<0, 2>([&](auto HF) {
+        constexpr int half = decltype(HF)::value;
+        constexpr int u = U0 + U1 + 2 * ot + half;
+        dma((u + 2) % UT, (u + 2) % RING);                  // wraps into the next tile's head (harmless after the last tile)
+        if constexpr (half == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) R[q] = buf_load(xs, poff, ot * 128 + q * 32);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
+        }
+        read_w(Fw1, u % RING, 1);
+        read_w(FwN, (u + 1) % RING, 0);
+        // K = c/2 in stage order: stage st = NT * half + s of this unit, k-groups g = 0, 1, element e
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+          const int st = NT * half + s;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2 = RB_MFMA(Fw0[s][e], acc[st >> 1][8 * (st & 1) + e], acc2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc2 = RB_MFMA(Fw1[s][e], acc[st >> 1][8 * (st & 1) + 4 + e], acc2);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+        if constexpr (half == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
+        if constexpr (half == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + 2 * CH + 32 * ot + 8 * q + 4 * h);
+            f32x4 v = {acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]};
+            v = (v + bv) + R[q];
+            buf_store(ys, v, poff, ot * 128 + q * 32);
+          }
+          end_step(VM4{});
+        } else {
+          end_step(VM0{});
+        }
+      });
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// wpack[u][row][16] in the ring's LDS image order, from the Keras kernels: w0 [1,1,C,CH], w1 [3,3,CH,CH], w2 [1,1,CH,C]
+template <int C>
+__global__ void __launch_bounds__(256) rb_pack_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                       const float* __restrict__ w2, float* __restrict__ wpack) {
+  using K = RBCfg<C>;
+  constexpr int CH = K::CH, NT = K::NT;
+  const int total = K::UT * K::UNIT;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int u = idx / K::UNIT;
+    const int rem = idx - u * K::UNIT;
+    const int row = rem >> 4, pos = rem & 15;
+    const int chunk = (pos >> 2) ^ ((row >> 2) & 3);
+    const int k16 = chunk * 4 + (pos & 3);
+    float v;
+    if (u < K::U0) {
+      v = w0[(size_t)(16 * u + k16) * CH + row];
+    } else if (u < K::U0 + K::U1) {
+      const int s = u - K::U0, cc = s / 9, t = s - cc * 9;
+      v = w1[((size_t)t * CH + 16 * cc + k16) * CH + row];
+    } else {
+      const int s = u - K::U0 - K::U1, ot = s >> 1, half = s & 1;
+      const int st = NT * half + (row >> 5);
+      v = w2[(size_t)(16 * st + k16) * C + 32 * ot + (row & 31)];
+    }
+    wpack[idx] = v;
+  }
+}
+
+__global__ void rb_bias_kernel(const float* b0, const float* b1, const float* b2, float* out, int ch, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ch) out[i] = b0 ? b0[i] : 0.0f;
+  else if (i < 2 * ch) out[i] = b1 ? b1[i - ch] : 0.0f;
+  else if (i < 2 * ch + c) out[i] = b2 ? b2[i - 2 * ch] : 0.0f;
+}
+
+constexpr int kMaxDev = 16;
+struct RBDevice {
+  std::once_flag once;
+  int rc = SNTC_OK;
+  int num_cus = 0;
+};
+RBDevice g_rbdev[kMaxDev];
+
+int rb_init(int* num_cus) {
+  int dev = 0;
+  SNTC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDev) return fail(SNTC_ERR_UNSUPPORTED, "device index beyond the ResidualBlock tables");
+  RBDevice& D = g_rbdev[dev];
+  std::call_once(D.once, [&] {
+    D.rc = [&]() -> int {
+      hipDeviceProp_t prop;
+      SNTC_HIP(hipGetDeviceProperties(&prop, dev));
+      D.num_cus = prop.multiProcessorCount;
+      SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)RBCfg<192>::LDS));
+      return SNTC_OK;
+    }();
+  });
+  *num_cus = D.num_cus;
+  return D.rc;
+}
+
+}  // namespace
+}  // namespace sntc
+
+struct sntc_resblock_plan {
+  int c = 0;
+  float* wpack = nullptr;
+  float* bias = nullptr;
+  int max_workgroups = 0;     // 0: one per CU
+};
+
+using namespace sntc;
+
+static int rb_pack(sntc_resblock_plan* p, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                   const float* b2, hipStream_t s) {
+  using K = RBCfg<192>;
+  hipLaunchKernelGGL(rb_pack_kernel<192>, dim3((K::UT * K::UNIT + 255) / 256), dim3(256), 0, s, w0, w1, w2, p->wpack);
+  hipLaunchKernelGGL(rb_bias_kernel, dim3((K::BIAS + 255) / 256), dim3(256), 0, s, b0, b1, b2, p->bias, K::CH, 192);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "ResidualBlock weight packing");
+  return SNTC_OK;
+}
+
+extern "C" int sntc_resblock_supported(int c) { return c == 192 ? 1 : 0; }
+
+extern "C" int sntc_resblock_plan_create(int c, const float* w0, const float* b0, const float* w1, const float* b1,
+                                         const float* w2, const float* b2, void* stream, sntc_resblock_plan** plan) {
+  if (!plan || !w0 || !w1 || !w2) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_plan_create: null argument");
+  if (!sntc_resblock_supported(c)) return fail(SNTC_ERR_UNSUPPORTED, "sntc_resblock_plan_create: fused ResidualBlock exists for c = 192");
+  int cus = 0;
+  if (int rc = rb_init(&cus)) return rc;
+  using K = RBCfg<192>;
+  auto* p = new sntc_resblock_plan();
+  p->c = c;
+  if (hipMalloc(&p->wpack, sizeof(float) * K::UT * K::UNIT) != hipSuccess || hipMalloc(&p->bias, sizeof(float) * K::BIAS) != hipSuccess) {
+    if (p->wpack) (void)hipFree(p->wpack);
+    delete p;
+    return fail(SNTC_ERR_HIP, "sntc_resblock_plan_create: out of device memory");
+  }
+  if (int rc = rb_pack(p, w0, b0, w1, b1, w2, b2, (hipStream_t)stream)) {
+    (void)hipFree(p->wpack);
+    (void)hipFree(p->bias);
+    delete p;
+    return rc;
+  }
+  *plan = p;
+  return SNTC_OK;
+}
+
+extern "C" int sntc_resblock_plan_update(sntc_resblock_plan* p, const float* w0, const float* b0, const float* w1, const float* b1,
+                                         const float* w2, const float* b2, void* stream) {
+  if (!p || !w0 || !w1 || !w2) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_plan_update: null argument");
+  return rb_pack(p, w0, b0, w1, b1, w2, b2, (hipStream_t)stream);
+}
+
+extern "C" void sntc_resblock_plan_destroy(sntc_resblock_plan* p) {
+  if (!p) return;
+  if (p->wpack) (void)hipFree(p->wpack);
+  if (p->bias) (void)hipFree(p->bias);
+  delete p;
+}
+
+extern "C" int sntc_resblock_plan_set_workgroups(sntc_resblock_plan* p, int max_workgroups) {
+  if (!p || max_workgroups < 0) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_plan_set_workgroups: bad argument");
+  p->max_workgroups = max_workgroups;
+  return SNTC_OK;
+}
+
+extern "C" int64_t sntc_resblock_flops(const sntc_resblock_plan* p, int n, int h, int w) {
+  if (!p || n < 0 || h < 0 || w < 0) return -1;
+  const int64_t c = p->c, ch = p->c / 2;
+  return 2 * (int64_t)n * h * w * (c * ch + 9 * ch * ch + ch * c);
+}
+
+extern "C" int sntc_resblock_forward(const sntc_resblock_plan* p, const float* x, int n, int h, int w, float* y, void* stream) {
+  if (!p || !x || !y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_forward: null argument");
+  if (n < 0 || h < 0 || w < 0) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_forward: negative size");
+  if (x == y) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_forward: y must not alias x (tiles read their neighbours' halo)");
+  if (n == 0 || h == 0 || w == 0) return SNTC_OK;
+  using K = RBCfg<192>;
+  const int64_t bytes = (int64_t)n * h * w * p->c * 4;
+  if (bytes >= (1LL << 31)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_forward: tensor of 2 GiB or more; split the batch");
+  int cus = 0;
+  if (int rc = rb_init(&cus)) return rc;
+  RBArgs a{};
+  a.x = x; a.y = y; a.wpack = p->wpack; a.bias = p->bias;
+  a.bytes = (unsigned)bytes;
+  a.N = n; a.H = h; a.W = w;
+  a.tiles_x = (w + K::TW - 1) / K::TW;
+  a.tiles_y = (h + K::TH - 1) / K::TH;
+  const int64_t nt = (int64_t)n * a.tiles_x * a.tiles_y;
+  if (nt >= (1LL << 31)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_forward: too many tiles");
+  a.ntiles = (int)nt;
+  int grid = std::min<int64_t>(nt, p->max_workgroups > 0 ? p->max_workgroups : cus);
+  hipLaunchKernelGGL(rb_kernel<192>, dim3(grid), dim3(512), K::LDS, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "ResidualBlock launch");
+  return SNTC_OK;
+}

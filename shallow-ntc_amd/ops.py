@@ -21,6 +21,9 @@ KINDS = {"conv": capi.CONV2D, "convT": capi.CONV2D_TRANSPOSE, "sigdown": capi.SI
 
 WGRAD_STREAM = None         # training: the side stream the weight / bias gradients of TConv layers are launched on (Trainer sets it)
 FUSE_RESIDUAL_TAIL = True   # ResidualBlock (c = 192): 3x3 and 1x1 + skip in one launch (bit-identical; False: two launches)
+FUSE_RESIDUAL_BLOCK = not os.environ.get("SNTC_NO_RB_FUSE")   # ResidualBlock (c = 192): head, 3x3 and tail + skip in ONE launch on an 8 x 32
+                            # pixel tile with its halo patch in LDS (csrc/rb_fused.hip; bit-identical to the three launches)
+FUSED_BLOCK_MIN_TILES = 128  # ... where the launch offers at least this many 8 x 32 tiles (one workgroup per CU); below, the layers
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
 ROW_PACKED_FIRST_LAYER = not os.environ.get("SNTC_NO_ROWPACK")    # Cin = 3 analysis layers run as row-packed plans (False: the generic dword-gather path, for the A/B)
@@ -102,6 +105,67 @@ class PlanGroup:
             except Exception:
                 pass
             self._h = None
+
+
+class ResBlockPlan:
+    """One whole ResidualBlock (reference common/elic.py:41-68) as one launch: sntc_resblock_plan (csrc/rb_fused.hip).
+    ``w0`` [1,1,c,c/2], ``w1`` [3,3,c/2,c/2], ``w2`` [1,1,c/2,c] are the Keras kernels, ``b*`` the biases or None."""
+
+    @staticmethod
+    def supported(c):
+        return bool(capi.load().sntc_resblock_supported(int(c)))
+
+    def __init__(self, w0, b0, w1, b1, w2, b2):
+        capi.require_gpu()
+        self.c = int(w0.shape[2])
+        if tuple(w0.shape) != (1, 1, self.c, self.c // 2) or tuple(w1.shape) != (3, 3, self.c // 2, self.c // 2) \
+                or tuple(w2.shape) != (1, 1, self.c // 2, self.c):
+            raise ValueError(f"ResidualBlock kernels {tuple(w0.shape)}, {tuple(w1.shape)}, {tuple(w2.shape)} do not form a block")
+        ts = [None if t is None else t.contiguous() for t in (w0, b0, w1, b1, w2, b2)]
+        self._h = C.c_void_p()
+        capi.call("sntc_resblock_plan_create", self.c, *[_ptr(t) for t in ts], _stream(), C.byref(self._h))
+        torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_resblock_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def update(self, w0, b0, w1, b1, w2, b2):
+        capi.call("sntc_resblock_plan_update", self._h, *[_ptr(t) for t in (w0, b0, w1, b1, w2, b2)], _stream())
+
+    def set_workgroups(self, n):
+        """Cap the persistent workgroups of this plan's launches (0: one per CU); tests: identical bits for any value."""
+        capi.call("sntc_resblock_plan_set_workgroups", self._h, int(n))
+
+    def flops(self, n, h, w):
+        return int(capi.load().sntc_resblock_flops(self._h, n, h, w))
+
+    @staticmethod
+    def tiles(n, h, w):
+        return n * (-(-h // 8)) * (-(-w // 32))
+
+    def __call__(self, x):
+        _check_nhwc(x, self.c)
+        n, h, w, _ = x.shape
+        if x.numel() * 4 >= MAX_INPUT_BYTES and n > 1:
+            half = n // 2
+            return torch.cat([self(x[:half]), self(x[half:])])
+        y = torch.empty_like(x)
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        capi.call("sntc_resblock_forward", self._h, _ptr(x), n, h, w, _ptr(y), _stream())
+        if prof is not None:
+            e1.record()
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=0, nblocks=0, vec=True, kind="resblock", k=3, s=1,
+                             cin=self.c, cout=self.c, n=n, h=h, w=w))
+        return y
 
 
 def to_device(a, device):

@@ -120,6 +120,48 @@ def test_fused_residual_block_tail_is_bit_identical(n, h, w, stream_k, dev):
         first.fused(other, x)
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 8, 32), (2, 13, 45), (1, 64, 96), (3, 37, 100), (1, 5, 7), (2, 40, 33)])
+def test_whole_residual_block_in_one_launch_is_bit_identical(n, h, w, dev):
+    """sntc_resblock_forward (reference common/elic.py:41-68: x + conv1x1(relu(conv3x3(relu(conv1x1(x)))))) on an 8 x 32 pixel
+    tile with its halo patch in LDS gives exactly the bits of the three gather-GEMM launches -- ragged sizes, image borders
+    inside and between tiles, any number of persistent workgroups, with and without biases -- and matches the float64 oracle;
+    a weight update is picked up; unsupported widths and aliased buffers are refused."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(1000 * n + 10 * h + w)
+    c = 192
+    x = dev_t(rng.standard_normal((n, h, w, c)).astype(np.float32), dev)
+    mk = lambda scale, *shape: (rng.standard_normal(shape) * scale).astype(np.float32)
+    w0, b0 = mk(0.08, 1, 1, c, c // 2), mk(1.0, c // 2)
+    w1, b1 = mk(0.05, 3, 3, c // 2, c // 2), mk(1.0, c // 2)
+    w2, b2 = mk(0.1, 1, 1, c // 2, c), mk(1.0, c)
+    for with_bias in (True, False):
+        bs = [dev_t(b, dev) if with_bias else None for b in (b0, b1, b2)]
+        ws = [dev_t(a, dev) for a in (w0, w1, w2)]
+        la = ops.ConvPlan("conv", ws[0], bs[0], 1, "relu")
+        lb = ops.ConvPlan("conv", ws[1], bs[1], 1, "relu")
+        lc = ops.ConvPlan("conv", ws[2], bs[2], 1, None, capi.PRO_NONE, capi.EPI_ADD)
+        three = lc(lb(la(x)), res=x)
+        block = ops.ResBlockPlan(ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])
+        one = block(x)
+        assert torch.equal(one, three), float((one - three).abs().max())
+        for wg in (1, 3, 8, 200):
+            block.set_workgroups(wg)
+            assert torch.equal(block(x), three), wg
+        block.set_workgroups(0)
+    if n * h * w <= 4096:
+        t = np.maximum(O.conv2d(x.cpu().numpy().astype(np.float64), w0, None, 1), 0.0)
+        t = np.maximum(O.conv2d(t, w1, None, 1), 0.0)
+        ref = x.cpu().numpy() + O.conv2d(t, w2, None, 1)
+        assert rel_err(one.cpu().numpy(), ref) < TOL
+    block.update(dev_t(w0 * 0.5, dev), None, ws[1], None, ws[2], None)
+    la.update(dev_t(w0 * 0.5, dev))
+    assert torch.equal(block(x), lc(lb(la(x)), res=x))
+    assert not ops.ResBlockPlan.supported(64)
+    with pytest.raises(capi.SntcError):
+        capi.call("sntc_resblock_forward", block._h, ops._ptr(x), n, h, w, ops._ptr(x), ops._stream())
+
+
 def test_plan_group_update_equals_per_plan_update(dev):
     """sntc_plan_group_update re-packs every plan of the group in one launch exactly as sntc_conv_plan_update does one by
     one: forward convolution, phase-grouped transpose (four weight groups), input-gradient plan on the swapped kernel,
