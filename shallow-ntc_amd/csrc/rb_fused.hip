@@ -139,11 +139,11 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // end of a step: everything this wave has in flight has landed (VM = stores the wave may leave outstanding), then the
-  // workgroup barrier publishes the unit the step's DMA brought (it is consumed two steps later, prefetched from one later)
-  auto end_step = [&](auto VM) {
+  // the barrier of a step: everything this wave has in flight has landed (VM = stores the wave may leave outstanding), then
+  // the workgroup barrier publishes the unit the step's DMA brought (it is consumed two steps later, prefetched from one later)
+  auto sync = [&](auto VM) {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(VM)::value) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(decltype(VM)::value) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -160,31 +160,54 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
   f32x4 Fw0[NT], Fw1[NT], FwN[NT];
   read_w(Fw0, 0, 0);
 
-  for (int tile = t_lo; tile < t_hi; ++tile) {
+  // head geometry of this wave: patch tile `wave` (all waves) and `wave + 8` (the first NPT - 8 waves), pixel 32 t + l31
+  const bool two = wave < K::NPT - 8;
+  int hpp[2], hpy[2], hpx[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    hpp[p] = 32 * (wave + 8 * p) + l31;
+    hpy[p] = hpp[p] / PW;
+    hpx[p] = hpp[p] - hpy[p] * PW;
+  }
+  unsigned hv[2];
+  bool hvalid[2];
+  f32x4 X[2][2][2];                            // [stage parity][patch tile][k-group]
+  int n = 0, y0 = 0, x0 = 0;
+  auto coords = [&](int tile, int* tn, int* ty0, int* tx0) {
     const int per = a.tiles_x * a.tiles_y;
-    const int n = tile / per;
-    const int r = tile - n * per;
+    *tn = tile / per;
+    const int r = tile - *tn * per;
     const int tyi = r / a.tiles_x;
-    const int y0 = tyi * K::TH;
-    const int x0 = (r - tyi * a.tiles_x) * K::TW;
+    *ty0 = tyi * K::TH;
+    *tx0 = (r - tyi * a.tiles_x) * K::TW;
+  };
+  // the head's pixel offsets of tile `tile` and its first K stage on the way (issued a step before the tile begins)
+  auto head_setup = [&](int tile) {
+    int tn, ty0, tx0;
+    coords(tile, &tn, &ty0, &tx0);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int iy = ty0 - 1 + hpy[p], ix = tx0 - 1 + hpx[p];
+      hvalid[p] = hpp[p] < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      hv[p] = hvalid[p] ? ((unsigned)((tn * a.H + iy) * a.W + ix) * (unsigned)(C * 4) + (unsigned)h * 16u) : kOOB;
+    }
+    X[0][0][0] = buf_load(xs, hv[0], 0);
+    X[0][0][1] = buf_load(xs, hv[0], 32);
+    if (two) {
+      X[0][1][0] = buf_load(xs, hv[1], 0);
+      X[0][1][1] = buf_load(xs, hv[1], 32);
+    }
+  };
+  head_setup(t_lo);
+
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    coords(tile, &n, &y0, &x0);
 
     // ================================================================================================
     // head: t1 = relu(W0 x + b0) on the halo patch, zero outside the image
     // ================================================================================================
     auto head = [&](auto NPXc) {
       constexpr int NPX = decltype(NPXc)::value;
-      unsigned voff[NPX];
-      bool valid[NPX];
-      int pp[NPX];
-#pragma unroll
-      for (int p = 0; p < NPX; ++p) {
-        pp[p] = 32 * (wave + 8 * p) + l31;
-        const int py = pp[p] / PW;
-        const int px = pp[p] - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        valid[p] = pp[p] < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        voff[p] = valid[p] ? ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)(C * 4) + (unsigned)h * 16u) : kOOB;
-      }
       f32x16 acc[NT][NPX];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -192,20 +215,15 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
         for (int p = 0; p < NPX; ++p)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[j][p][e] = 0.0f;
-      f32x4 X[2][NPX][2];
-#pragma unroll
-      for (int p = 0; p < NPX; ++p) {
-        X[0][p][0] = buf_load(xs, voff[p], 0);
-        X[0][p][1] = buf_load(xs, voff[p], 32);
-      }
       static_for<0, U0>([&](auto J) {
         constexpr int j = decltype(J)::value;
+        constexpr bool last = j == U0 - 1;
         dma(j + 2, (j + 2) % RING);
-        if constexpr (j + 1 < U0) {
+        if constexpr (!last) {
 #pragma unroll
           for (int p = 0; p < NPX; ++p) {
-            X[(j + 1) & 1][p][0] = buf_load(xs, voff[p], (j + 1) * 64);
-            X[(j + 1) & 1][p][1] = buf_load(xs, voff[p], (j + 1) * 64 + 32);
+            X[(j + 1) & 1][p][0] = buf_load(xs, hv[p], (j + 1) * 64);
+            X[(j + 1) & 1][p][1] = buf_load(xs, hv[p], (j + 1) * 64 + 32);
           }
         }
         read_w(Fw1, j % RING, 1);
@@ -215,6 +233,12 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
           for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
             for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw0[jt][e], X[j & 1][p][0][e], acc[jt][p]);
+        // every memory instruction behind an MFMA that covers its issue slot (mask 0x8 MFMA, 0x20 VMEM read, 0x100 DS read)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (!last) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NPX, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX - 2, 0);
         read_w(FwN, (j + 1) % RING, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -222,22 +246,17 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
           for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
             for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw1[jt][e], X[j & 1][p][1][e], acc[jt][p]);
-        // every memory instruction behind an MFMA that covers its issue slot (mask 0x8 MFMA, 0x20 VMEM read, 0x100 DS read)
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (j + 1 < U0) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NPX, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX - 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX - 1, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
-        if constexpr (j == U0 - 1) {
+        if constexpr (last) {
           // registers 4 q .. 4 q + 3 of tile jt = channels 32 jt + 8 q + 4 h + (0..3) of pixel l31: chunk 2 (q & 1) + h of slab 2 jt + (q >> 1)
 #pragma unroll
           for (int p = 0; p < NPX; ++p) {
-            const int sw = (pp[p] >> 2) & 3;
+            const int sw = (hpp[p] >> 2) & 3;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -245,17 +264,16 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + 32 * jt + 8 * q + 4 * h);
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = valid[p] ? fmaxf(acc[jt][p][4 * q + e] + bv[e], 0.0f) : 0.0f;
-                if (pp[p] < PP)
-                  *reinterpret_cast<f32x4*>(patch + (2 * jt + (q >> 1)) * (PP * 16) + pp[p] * 16 + (((2 * (q & 1) + h) ^ sw) << 2)) = v;
+                for (int e = 0; e < 4; ++e) v[e] = hvalid[p] ? fmaxf(acc[jt][p][4 * q + e] + bv[e], 0.0f) : 0.0f;
+                if (hpp[p] < PP)
+                  *reinterpret_cast<f32x4*>(patch + (2 * jt + (q >> 1)) * (PP * 16) + hpp[p] * 16 + (((2 * (q & 1) + h) ^ sw) << 2)) = v;
               }
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        end_step(VM0{});
+        sync(VM0{});
       });
     };
-    if (wave < K::NPT - 8) head(std::integral_constant<int, 2>{});
+    if (two) head(std::integral_constant<int, 2>{});
     else head(std::integral_constant<int, 1>{});
 
     // ================================================================================================
@@ -285,6 +303,9 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) acc[jt] = RB_MFMA(Fw0[jt][e], Fp0[e], acc[jt]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
         read_w(FwN, (t + 1) % RING, 0);
         if constexpr (t < 8) FpN = *reinterpret_cast<const f32x4*>(pslab + px_off(t + 1, 0));
         else FpN = *reinterpret_cast<const f32x4*>(patch + min(cc + 1, SL - 1) * (PP * 16) + px_off(0, 0));
@@ -295,12 +316,11 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
         Fp0 = FpN;
-        end_step(VM0{});
+        sync(VM0{});
       });
     }
 
@@ -331,23 +351,26 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
         }
+        if constexpr (u == UT - 1) {
+          if (tile + 1 < t_hi) head_setup(tile + 1);         // the next tile's first K stage travels under this step
+          __builtin_amdgcn_sched_barrier(0);
+        }
         read_w(Fw1, u % RING, 1);
         read_w(FwN, (u + 1) % RING, 0);
         // K = c/2 in stage order: stage st = NT * half + s of this unit, k-groups g = 0, 1, element e
+        static_for<0, 2 * NT>([&](auto SG) {
+          constexpr int sg = decltype(SG)::value, s = sg >> 1, g = sg & 1, st = NT * half + s;
 #pragma unroll
-        for (int s = 0; s < NT; ++s) {
-          const int st = NT * half + s;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc2 = RB_MFMA(Fw0[s][e], acc[st >> 1][8 * (st & 1) + e], acc2);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc2 = RB_MFMA(Fw1[s][e], acc[st >> 1][8 * (st & 1) + 4 + e], acc2);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-        if constexpr (half == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - 2, 0);
+          for (int e = 0; e < 4; ++e) acc2 = RB_MFMA((g ? Fw1 : Fw0)[s][e], acc[st >> 1][8 * (st & 1) + 4 * g + e], acc2);
+          if constexpr (sg == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+            if constexpr (half == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
@@ -359,9 +382,9 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
             v = (v + bv) + R[q];
             buf_store(ys, v, poff, ot * 128 + q * 32);
           }
-          end_step(VM4{});
+          sync(VM4{});
         } else {
-          end_step(VM0{});
+          sync(VM0{});
         }
       });
     });
