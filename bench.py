@@ -256,7 +256,7 @@ def main():
     torch.cuda.synchronize()
 
     def decode_eager():
-        return [model.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
+        return [model.decode(z_hat, sym, hw, check=False) for z_hat, sym, hw, _x in codes]
 
     nstreams = len(codes) if args.streams == 0 else args.streams
     side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
@@ -269,7 +269,7 @@ def main():
             st = side[i % nstreams]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                outs.append(model.decode(z_hat, sym, hw))
+                outs.append(model.decode(z_hat, sym, hw, check=False))
         for st in side:
             cur.wait_stream(st)
         return outs
@@ -318,8 +318,8 @@ def main():
 
     def e2e_one(batch):
         ids, x, hw = batch
-        z_hat, sym, _, _ = model.encode(x)
-        return model.decode(z_hat, sym, hw, reference=x)
+        z_hat, sym, _, _ = model.encode(x, check=False)
+        return model.decode(z_hat, sym, hw, reference=x, check=False)
 
     def e2e_step():
         return on_streams(e2e_one)
@@ -344,6 +344,7 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         wall = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        ops.check_conv_status()         # the timed steps deferred their stream-K health check (check=False): raise here, not a wrong number
         if evs:
             per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
             stats.update(steps=steps, warmup=warmup, mean_ms=round(1e3 * wall / steps, 4), median_ms=round(float(np.median(per)), 4),
@@ -385,12 +386,12 @@ def main():
     # timing noise: region medians 3.30 ms either way.)
     enc_fn = w1_x = w1_step = None
     if not args.decode_only:
-        enc_fn = lambda: on_streams(lambda b: model.encode(b[1]))
+        enc_fn = lambda: on_streams(lambda b: model.encode(b[1], check=False))
         w1_x = synthetic_batch(64, 256, 256, 4321 + rank, dev)   # encode+decode on the synthetic 256x256 batches the north star asks for
 
         def w1_step():
-            z_hat, sym, _, _ = model.encode(w1_x)
-            model.decode(z_hat, sym, (256, 256), reference=w1_x)
+            z_hat, sym, _, _ = model.encode(w1_x, check=False)
+            model.decode(z_hat, sym, (256, 256), reference=w1_x, check=False)
 
         tune(enc_fn)                                             # untimed set-up of the regions below, done before anything is timed
         tune(w1_step)
@@ -456,13 +457,13 @@ def main():
         # stay exact fp32), with its own parity figures against the fp32 model on the same codes.
         model3 = Model(device=dev, precision="bf16x3", **cfg)
         model3.set_weights(model.get_weights())
-        dec3 = lambda: on_codes(lambda c: model3.decode(c[0], c[1], c[2]))
-        r3, _ = region(dec3, R_STEPS, pixels_per_step, lambda: [model3.decode(z_hat, sym, hw) for z_hat, sym, hw, _x in codes])
+        dec3 = lambda: on_codes(lambda c: model3.decode(c[0], c[1], c[2], check=False))
+        r3, _ = region(dec3, R_STEPS, pixels_per_step, lambda: [model3.decode(z_hat, sym, hw, check=False) for z_hat, sym, hw, _x in codes])
         diff = tot = 0
         sse32 = sse3 = 0
         for z_hat, sym, hw, x in codes:
-            p32, s32 = model.decode(z_hat, sym, hw, reference=x)
-            p3, s3 = model3.decode(z_hat, sym, hw, reference=x)
+            p32, s32 = model.decode(z_hat, sym, hw, reference=x, check=False)
+            p3, s3 = model3.decode(z_hat, sym, hw, reference=x, check=False)
             d = (p32.to(torch.int16) - p3.to(torch.int16)).abs()
             diff += int((d != 0).sum()); tot += d.numel()
             assert int(d.max()) <= 1, "bf16 x 3 decode differs from fp32 by more than one code value"
@@ -474,17 +475,67 @@ def main():
             speedup_over_fp32=round(regions["decode"]["ms_per_step"] / r3["ms_per_step"], 3), pixel_values=tot,
             pixels_differing_from_fp32=diff, max_code_difference=1 if diff else 0,
             d_psnr_vs_fp32_db=round(float(psnr(sse3) - psnr(sse32)), 7))
-        enc3 = lambda: on_streams(lambda b: model3.encode(b[1]))
+        enc3 = lambda: on_streams(lambda b: model3.encode(b[1], check=False))
         tune(enc3)
         r3e, _ = region(enc3, R_STEPS_ENC, pixels_per_step)
         sym_diff = sym_tot = 0
         for ids, xb, hw in batches:
-            _, s_a, _, _ = model.encode(xb)
-            _, s_b, _, _ = model3.encode(xb)
+            _, s_a, _, _ = model.encode(xb, check=False)
+            _, s_b, _, _ = model3.encode(xb, check=False)
             sym_diff += int((s_a != s_b).sum()); sym_tot += s_a.numel()
         regions["encode_bf16x3"] = dict(r3e, speedup_over_fp32=round(regions["encode"]["ms_per_step"] / r3e["ms_per_step"], 3),
                                         symbols=sym_tot, symbols_differing_from_fp32=sym_diff)
         del model3
+        # ---- SGA iterative inference (row a21, BASELINE configs[4]: two_layer_syn2 + itinf, common/itinf_lib.py:26-93): one step
+        # = Gumbel-softmax rounding of (z, y), hyper-synthesis + synthesis forward, analytic input gradients, Adam on the latents.
+        # No host synchronisation inside the step (the loop fetches metrics only where it logs them).
+        sga_cfg = {**configs.two_layer_syn2(rd_lambda=0.02, hidden_channels=24), **configs.itinf()}
+        sga_model = Model(device=dev, quality_metrics=False, **sga_cfg)
+        sga = {}
+        for label, (bn, bh, bw) in (("tecnick_5x1200x1200", (5, 1200, 1200)), ("kodak_1x512x768", (1, 512, 768))):
+            xb = synthetic_batch(bn, bh, bw, 555 + rank, dev)
+            sga_model.initialize_itinf(xb)
+            step_fn = lambda: sga_model.itinf_train_step(xb, fetch=False)
+            tune(step_fn)
+            st = {}
+            timed(step_fn, R_STEPS, R_WARM, st)
+            sga_model.itinf_last_metrics()                      # one fetch after the loop: raises if anything was flagged / non-finite
+            med = st["median_ms"] * 1e-3
+            sga[label] = dict(ms_per_step=st["median_ms"], seconds_per_3000_steps=round(3000 * med, 2),
+                              mpixels_per_s=round(world * bn * bh * bw / med / 1e6, 2), timing=st, roofline=region_frac(step_fn, med))
+        regions["sga_step"] = dict(workload="mshyper/configs/two_layer_syn2.py (24 hidden channels) + itinf.py: one SGA step on the latents of a batch",
+                                   **sga)
+        del sga_model
+        # ---- the real bitstream (row f2): images -> bytes (analysis, hyper path, rANS encode of z and y, host copy) and bytes ->
+        # uint8 pixels (rANS decode of z, hyper-synthesis, rANS decode of y, synthesis).  The random-init model codes almost
+        # nothing, so the hyper-synthesis bias is set as in tests/test_hip_bitstream.py to put the scales in a coding range.
+        bs_model = Model(device=dev, **cfg)
+        wts = dict(model.get_weights())
+        bias = wts["hyper_synthesis/layer_2/bias"].copy()
+        bias[320:] = np.random.default_rng(0).uniform(-1.0, 2.5, size=320)
+        wts["hyper_synthesis/layer_2/bias"] = bias.astype(np.float32)
+        bs_model.set_weights(wts)
+        t0 = time.perf_counter()
+        bs_model._get_codec()
+        torch.cuda.synchronize()
+        codec_setup_s = time.perf_counter() - t0
+        blobs = []
+        comp_fn = lambda: blobs.__setitem__(slice(None), [bs_model.compress(x) for _ids, x, _hw in batches])
+        tune(comp_fn)
+        st_c, st_d = {}, {}
+        timed(comp_fn, 5, 2, st_c)
+        decomp_fn = lambda: [bs_model.decompress(b) for b in blobs]
+        timed(decomp_fn, 5, 2, st_d)
+        file_bpp = 8.0 * sum(len(b) for b in blobs) / pixels_per_step
+        for label, st, fn in (("compress", st_c, comp_fn), ("decompress", st_d, decomp_fn)):
+            med = st["median_ms"] * 1e-3
+            regions[label] = dict(workload="the Kodak-shaped set, one bitstream per batch shape; " +
+                                           ("images -> bytes on the host" if label == "compress" else "bytes on the host -> uint8 pixels"),
+                                  ms_per_step=st["median_ms"], mpixels_per_s=round(world * pixels_per_step / med / 1e6, 2), timing=st,
+                                  file_bpp=round(file_bpp, 4), table_build_s=round(codec_setup_s, 3),
+                                  fraction_of_decode_value=round(world * pixels_per_step / med / 1e6 / value, 3) if label == "decompress" else None,
+                                  roofline=region_frac(fn, med))
+        del bs_model
         rows = []                          # per-image (bpp, psnr, mse) of the rank's set, then ONE all-gather
         for ids, x, hw in batches:
             for d, i in zip(model.evaluate_batched(x), ids):
@@ -509,6 +560,8 @@ def main():
                 name = f"gg_kernel<{shape}, {vec}, false, false, 0, {'true' if '+1x1' in e['kind'] else 'false'}>"
                 if e["variant"] >= 11:                                      # the pre-split bf16 x 3 kernel (csrc/bf3_gemm.hip)
                     name = f"bf3_kernel<4, 2, 2, {4 if e['variant'] == 11 else 2}>"
+                if e["kind"] == "resblock":                                 # the whole ResidualBlock in one launch (csrc/rb_fused.hip)
+                    name = f"rb_kernel<{e['cin']}>"
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
                 k["flops"] += e["flops"]
@@ -542,7 +595,7 @@ def main():
                                              ms_per_step=round(v["ms"] / 3, 4)) for n, v in per_kernel.items()})
 
         if not args.decode_only:             # the same table for the analysis side (ELIC encoder: MFMA utilisation)
-            enc = kernel_table(lambda: [model.encode(x) for _ids, x, _hw in batches], 1)
+            enc = kernel_table(lambda: [model.encode(x, check=False) for _ids, x, _hw in batches], 1)
             tot_ms, tot_fl = sum(v["ms"] for v in enc.values()), sum(v["flops"] for v in enc.values())
             # counters of the same kernels from the committed encode-side passes (profiles/r*_encode_pmc_summary.json: separate
             # rocprofv3 --pmc runs of tools/profile_layers.py), with the same staleness flag as `traffic` above

@@ -197,11 +197,15 @@ int sntc_dequant_split3(const int32_t* symbols, const float* hyper, int64_t npix
 /* Stream-K health.  The persistent stream-K schedule needs every worker of a launch resident at once, which HIP does not
  * promise on a device that other streams or processes share.  A worker that waits in vain (bounded spin) for its neighbour's
  * hand-off no longer traps: it sets bit 0 of a sticky per-device status word and the launch completes with INVALID results.
- * sntc_conv_status copies that word to *flags (synchronising `stream`) and clears it -- call it where the host synchronises
- * anyway (the Python driver does, at every device -> host copy of metrics); non-zero means: discard the results since the last
- * check, and re-run after sntc_conv_set_stream_k(0), which makes every later call use the static one-workgroup-per-tile /
- * split-K schedules (bit-identical results).  The reference has no counterpart (single stream, cuDNN). */
+ * sntc_conv_status exchanges that word with 0 in one atomic on `stream`, copies the old value to *flags and synchronises
+ * `stream` -- call it where the host synchronises anyway (the Python driver does: at every device -> host copy of metrics, in
+ * compress / decompress, and in encode / decode unless the caller defers the check); launches still in flight on OTHER streams
+ * are not covered: join side streams first.  Non-zero means: discard the results since the last check, and re-run after
+ * sntc_conv_set_stream_k(0), which makes every later call use the static one-workgroup-per-tile / split-K schedules
+ * (bit-identical results).  sntc_conv_status_inject ORs `flags` into the word on `stream` (tests: the raise
+ * paths of the callers).  The reference has no counterpart (single stream, cuDNN; common/transforms.py:81-90). */
 int sntc_conv_status(int* flags, void* stream);
+int sntc_conv_status_inject(int flags, void* stream);
 int sntc_conv_set_stream_k(int enabled);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sntc_split3": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "sntc_dequant_split3": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P]),
     "sntc_conv_status": (C.c_int, [C.POINTER(C.c_int), _P]),
+    "sntc_conv_status_inject": (C.c_int, [C.c_int, _P]),
     "sntc_conv_set_stream_k": (C.c_int, [C.c_int]),
     "sntc_conv_launch_info": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sntc_conv_tune_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),

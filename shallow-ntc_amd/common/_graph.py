@@ -208,7 +208,7 @@ class ResidualBlock:
             c = l.build(w, c)
         # the whole block as one launch (csrc/rb_fused.hip), bit-identical to the three layers below
         self._block = None
-        if ops.FUSE_RESIDUAL_BLOCK and ops.ResBlockPlan.supported(cin):
+        if (ops.FUSE_RESIDUAL_BLOCK or self._convs[0].precision != "fp32") and ops.ResBlockPlan.supported(cin):
             n = self.name
             self._block = ops.ResBlockPlan(w[f"{n}/conv0/kernel"], w.get(f"{n}/conv0/bias"), w[f"{n}/conv1/kernel"],
                                            w.get(f"{n}/conv1/bias"), w[f"{n}/conv2/kernel"], w.get(f"{n}/conv2/bias"))
@@ -216,8 +216,13 @@ class ResidualBlock:
 
     def __call__(self, x):
         a, b, c = self._convs
-        if (self._block is not None and ops.FUSE_RESIDUAL_BLOCK and x.dtype == torch.float32
-                and ops.ResBlockPlan.tiles(*x.shape[:3]) >= ops.FUSED_BLOCK_MIN_TILES):
+        if a.precision != "fp32":
+            # split-precision model: which arithmetic a layer takes may depend on the layer and on ONE image's geometry, never on
+            # the batch (DualPlan).  c = 192: always the exact fp32 block; other widths: the three layers, each by DualPlan's rule
+            if self._block is not None and x.dtype == torch.float32:
+                return self._block(x)
+            return c(b(a(x)), res=x)
+        if self._block is not None and ops.FUSE_RESIDUAL_BLOCK and ops.ResBlockPlan.tiles(*x.shape[:3]) >= ops.FUSED_BLOCK_MIN_TILES:
             return self._block(x)
         # c = 192: the 3x3 and the 1x1 + skip run as one launch -- where the launch has the rows to fill the device: the fused
         # instance's 128-row workgroups run both contractions back to back, and below ~192 of them the two stand-alone launches

@@ -24,7 +24,9 @@ def itinf_on_data_batch(train_eval_config, train_writer, val_writer, model, data
     model.initialize_itinf(data_batch)                         # :62
     step = 0
     while step < num_steps:                                    # :67-82
-        metrics = model.itinf_train_step(data_batch)
+        # the step's scalars stay on the device unless this step is logged (:67-75: the tf.function step returns tensors and
+        # only the logged ones are converted): no host synchronisation inside the 3000-step loop
+        metrics = model.itinf_train_step(data_batch, fetch=step % log_every == 0)
         if step % log_every == 0:
             if train_writer is not None:
                 train_writer.write_scalars(step, metrics.scalars_float)

@@ -469,9 +469,13 @@ def irdft_matrix(shape, layout=None):
     return np.concatenate([f.real, f.imag], axis=-1)
 
 
-def rdft_to_kernel(rdft, spatial, cin, cout):
+WRITER_LAYOUT_KEY = "_sntc_writer/rdft_layout"     # int32 index into RDFT_LAYOUTS: bundles THIS repository writes say which column
+                                                   # order their rdft variables use (a TensorFlow reader never asks for the key)
+
+
+def rdft_to_kernel(rdft, spatial, cin, cout, layout=None):
     """RDFTParameter variable -> SignalConv2D kernel [kh, kw, cin, cout] (float32)."""
-    m = irdft_matrix(spatial)
+    m = irdft_matrix(spatial, layout)
     r = np.asarray(rdft, np.float64)
     r = r.reshape(r.shape[0], -1)
     if r.shape[0] != m.shape[1] or r.shape[1] != cin * cout:
@@ -492,9 +496,16 @@ class CheckpointMapper:
     """Collects {our variable name: ndarray} by walking the object graph the way the reference's classes are
     written (attribute names from reference common/elic.py, common/transforms.py, mshyper/models.py)."""
 
-    def __init__(self, tensors, graph: ObjectGraph):
+    def __init__(self, tensors, graph: ObjectGraph, prefix=None):
         self.t, self.g = tensors, graph
         self.out = OrderedDict()
+        # the rdft column order: recorded by this repository's own writer; a bundle without the record is either TensorFlow's
+        # (module default + loud warning) or one an EARLIER build of this repository wrote, which is refused: its order was
+        # 'interleaved' through round 2 and 'real_then_imag' in round 3, and nothing in it says which
+        self.rdft_layout = None
+        if WRITER_LAYOUT_KEY in tensors:
+            self.rdft_layout = RDFT_LAYOUTS[int(np.asarray(tensors[WRITER_LAYOUT_KEY]).reshape(-1)[0])]
+        self._ours_unmarked = prefix is not None and Path(str(prefix) + ".optimizer.npz").exists() and self.rdft_layout is None
 
     def var(self, node):
         return self.t[self.g.variable_key(node)]
@@ -506,8 +517,13 @@ class CheckpointMapper:
 
     def signal_conv(self, node, name, spatial, cin, cout, bias=True):     # tfc.SignalConv2D, kernel_parameter="rdft"
         kp = self.g.path(node, ("_kernel_parameter", "kernel_parameter", "kernel"), "rdft")
-        _warn_rdft("import")
-        self.out[f"{name}/kernel"] = rdft_to_kernel(self.var(kp), spatial, cin, cout)
+        if self._ours_unmarked and not os.environ.get("SNTC_RDFT_LAYOUT"):
+            raise ValueError("this bundle was written by an earlier build of this repository (it has an .optimizer.npz side file but no "
+                             f"{WRITER_LAYOUT_KEY} record): its rdft column order is unknown ('interleaved' through round 2, "
+                             "'real_then_imag' in round 3).  Set SNTC_RDFT_LAYOUT to the order it was written with to import it.")
+        if self.rdft_layout is None:
+            _warn_rdft("import")
+        self.out[f"{name}/kernel"] = rdft_to_kernel(self.var(kp), spatial, cin, cout, self.rdft_layout)
         if bias:
             self.out[f"{name}/bias"] = self.var(self.g.child(node, "_bias_parameter", "bias_parameter", "bias"))
 
@@ -618,7 +634,7 @@ def load_reference_checkpoint(prefix, transform_config):
     if OBJECT_GRAPH_KEY not in tensors:
         raise KeyError(f"{prefix}: no {OBJECT_GRAPH_KEY}; not an object-based checkpoint")
     g = ObjectGraph(tensors[OBJECT_GRAPH_KEY])
-    m = CheckpointMapper(tensors, g)
+    m = CheckpointMapper(tensors, g, prefix)
     model = g.child(0, "model")
     a_cls = transform_config["analysis"]["cls"]
     ana = g.child(model, "_analysis")
@@ -786,5 +802,7 @@ def save_reference_checkpoint(prefix, weights, transform_config, step=0):
     tensors = OrderedDict(b.tensors)
     tensors[OBJECT_GRAPH_KEY] = ObjectGraph.serialize(b.nodes)
     tensors["save_counter" + VAR_SUFFIX] = np.array(int(step), np.int64)
+    if a_cls in SIGNAL_STACKS or s_cls in SIGNAL_STACKS:
+        tensors[WRITER_LAYOUT_KEY] = np.array(RDFT_LAYOUTS.index(RDFT_LAYOUT), np.int32)
     write_bundle(prefix, tensors)
     return prefix

@@ -994,14 +994,27 @@ extern "C" int sntc_conv_set_stream_k(int enabled) {
   return SNTC_OK;
 }
 
+// read-and-clear in ONE atomic: a flag raised by a launch on another stream between a copy and a later memset would be lost
+__global__ void status_exchange_kernel(int* word, int* out) { *out = atomicExch(word, 0); }
+__global__ void status_or_kernel(int* word, int flags) { atomicOr(word, flags); }
+
 extern "C" int sntc_conv_status(int* flags, void* stream) {
   if (!flags) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_status: null argument");
   int rc = gg_init();
   if (rc) return rc;
-  int* word = gg_status_word();
+  int* word = gg_status_word();      // two ints: the sticky word, and the slot the exchange below returns it through
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemcpyAsync(flags, word, sizeof(int), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(status_exchange_kernel, dim3(1), dim3(1), 0, s, word, word + 1);
+  SNTC_HIP(hipGetLastError());
+  SNTC_HIP(hipMemcpyAsync(flags, word + 1, sizeof(int), hipMemcpyDeviceToHost, s));
   SNTC_HIP(hipStreamSynchronize(s));
-  if (*flags) SNTC_HIP(hipMemsetAsync(word, 0, sizeof(int), s));
+  return SNTC_OK;
+}
+
+extern "C" int sntc_conv_status_inject(int flags, void* stream) {
+  int rc = gg_init();
+  if (rc) return rc;
+  hipLaunchKernelGGL(status_or_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gg_status_word(), flags);
+  SNTC_HIP(hipGetLastError());
   return SNTC_OK;
 }

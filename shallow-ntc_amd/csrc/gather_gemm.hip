@@ -1224,8 +1224,8 @@ static int fill_tables(DeviceTables& T, int dev) {
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes_bf3(v)));
     T.resident_bf3[v] = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes_bf3(v))})) * T.num_cus;
   }
-  SNTC_HIP(hipMalloc(&T.status, sizeof(int)));
-  SNTC_HIP(hipMemset(T.status, 0, sizeof(int)));
+  SNTC_HIP(hipMalloc(&T.status, 2 * sizeof(int)));      // [0] the sticky word, [1] where sntc_conv_status's exchange returns it
+  SNTC_HIP(hipMemset(T.status, 0, 2 * sizeof(int)));
   return SNTC_OK;
 }
 

@@ -251,6 +251,7 @@ class Codec:
             zp, zl = rans_encode(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz, lz)
             yp, yl = rans_encode(sym, scale_table_ids(hyper), self.y_tables, sy, ly)
             zb, yb = zp.cpu().numpy().tobytes(), yp.cpu().numpy().tobytes()
+            ops.check_conv_status()       # the copies synchronised the stream: a flagged stream-K launch raises here, not a wrong file
         head = MAGIC + struct.pack(self.HEAD, VERSION | (ARITH[m._precision] << 8), n, H, W, y.shape[-1], z.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2],
                                    sz, sy, lz, ly)
         return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
@@ -300,4 +301,6 @@ class Codec:
                 raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents {(n, h, w, c)}")
             sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy, ly)
             y_hat = ops.dequant_split3(sym, hyper) if m._synthesis.takes_s3(h, w) else ops.dequant_scale_normal(sym, hyper)
-            return m._pixels(y_hat, (H, W))
+            px = m._pixels(y_hat, (H, W))
+            ops.check_conv_status()       # waits for the launches: wrong pixels never leave without an error
+            return px

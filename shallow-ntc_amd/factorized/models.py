@@ -67,15 +67,22 @@ class Model(_ms.Model):
         bits, _ = ops.noisy_factorized(prior, y_t)
         return None, bits, y_t
 
-    def encode(self, x):
+    def encode(self, x, check=True):
         lat = self.infer_latent_rvs(self._as_device_images(x))
         y_hat, bits = self._get_prior()(lat.uq[0].loc)
+        if check:
+            with torch.cuda.device(self.device):
+                ops.check_conv_status()
         return y_hat, None, None, bits
 
-    def decode(self, y_hat, symbols, image_hw, reference=None):
+    def decode(self, y_hat, symbols, image_hw, reference=None, check=True):
         with torch.cuda.device(self.device):
             recon = self._synthesis(y_hat)
             if reference is None:
-                return ops.to_pixels(recon, image_hw[0], image_hw[1])
-            sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
-        return px, sse
+                out = ops.to_pixels(recon, image_hw[0], image_hw[1])
+            else:
+                sse, px = ops.pixels_sse(reference, recon, want_pixels=True)
+                out = (px, sse)
+            if check:
+                ops.check_conv_status()
+        return out

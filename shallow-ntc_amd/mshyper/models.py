@@ -370,7 +370,9 @@ class Model:
             return None
         return ops.image_quality(ops.pixels_float(x, h, w), ops.pixels_float(recon, h, w), 255.0)
 
-    def _finish_metrics(self, x_shape, bits_z, bits_y, sse, msssim=None):
+    def _finish_metrics(self, x_shape, bits_z, bits_y, sse, msssim=None, sched=None):
+        """``sched`` = (scheduled_lr, sched_rd_lambda, tau) of the step the numbers belong to, when that is not the current one
+        (metrics of an SGA step fetched later)."""
         n, h, w, c = x_shape
         num_pixels = np.float32(h * w)                                                  # :302
         bits_z = None if bits_z is None else bits_z.astype(np.float32)
@@ -383,21 +385,21 @@ class Model:
         bpp = np.float32(hyper_bpp + latent_bpp)
         mses, psnrs = image_utils.mse_psnr_from_sse(sse, h * w * c)                     # :315
         mse, psnr = np.float32(mses.mean(dtype=np.float32)), np.float32(psnrs.mean(dtype=np.float32))
-        lam = self._scheduled_rd_lambda
+        lam = self._scheduled_rd_lambda if sched is None else sched[1]
         rd_loss = np.float32(bpp + np.float32(lam) * mse)                               # :343
         if not np.isfinite(rd_loss):                                                    # :356
             raise capi.NonFiniteError(capi.ERR_NONFINITE, "rd_loss : Tensor had NaN/Inf values")
         metrics = Metrics.make()
         metrics.record_scalar("sched_rd_lambda", lam)
         if self.latent_config["uq"].get("method") == "sga":
-            metrics.record_scalar("tau", self.latent_config["uq"]["tau"])
+            metrics.record_scalar("tau", self.latent_config["uq"]["tau"] if sched is None else sched[2])
         if msssim is not None:                                                          # :321-331
             ms = np.float32(np.asarray(msssim, np.float32).mean(dtype=np.float32))
             with np.errstate(divide="ignore"):
                 db = np.float32((-10.0 * np.log10(1.0 - np.asarray(msssim, np.float64))).mean())
             metrics.record_scalars(dict(msssim=float(ms), msssim_db=float(db)))
         metrics.record_scalars(dict(rd_loss=float(rd_loss), bpp=float(bpp), mse=float(mse), psnr=float(psnr),
-                                    scheduled_lr=self._scheduled_lr))
+                                    scheduled_lr=self._scheduled_lr if sched is None else sched[0]))
         if self._profile:                                                               # :350-351
             metrics.record_scalars(dict(getattr(self, "_timing", {})))
         return float(rd_loss), metrics
@@ -509,26 +511,33 @@ class Model:
         return out
 
     # -- codec regions -------------------------------------------------------------
-    def encode(self, x):
-        """x -> (z_hat, symbols int32, bits_z[n], bits_y[n]); needs the hyper-synthesis for mu, sigma."""
+    def encode(self, x, check=True):
+        """x -> (z_hat, symbols int32, bits_z[n], bits_y[n]); needs the hyper-synthesis for mu, sigma.  ``check``: wait for the
+        launches and raise if a stream-K hand-off timed out (``ops.check_conv_status``); a caller that keeps several calls in
+        flight passes False and checks where it synchronises itself."""
         x = self._as_device_images(x)
         with torch.cuda.device(self.device):
             lat = self.infer_latent_rvs(x)
             z_hat, bits_z = self._get_prior()(lat.uq[0].loc)
             hyper = self._hyper_synthesis(z_hat)
             _, bits_y, sym = ops.entropy_scale_normal(lat.uq[1].loc, hyper, want_symbols=True)
+            if check:
+                ops.check_conv_status()
         return z_hat, sym, bits_z, bits_y
 
-    def decode(self, z_hat, symbols, image_hw, reference=None):
+    def decode(self, z_hat, symbols, image_hw, reference=None, check=True):
         """(z_hat, symbols) -> hyper-synthesis -> y_hat = symbols + mu -> synthesis -> uint8 pixels
-        [n, H, W, 3] (and the per-image integer SSE against ``reference`` if given)."""
+        [n, H, W, 3] (and the per-image integer SSE against ``reference`` if given).  ``check`` as in ``encode``."""
         with torch.cuda.device(self.device):
             hyper = self._hyper_synthesis(z_hat)
             if self._synthesis.takes_s3(symbols.shape[1], symbols.shape[2]):      # bf16x3: y_hat leaves the dequantisation pre-split
                 y_hat = ops.dequant_split3(symbols, hyper)
             else:
                 y_hat = ops.dequant_scale_normal(symbols, hyper)
-            return self._pixels(y_hat, image_hw, reference)
+            out = self._pixels(y_hat, image_hw, reference)
+            if check:
+                ops.check_conv_status()
+            return out
 
     def _pixels(self, y_hat, image_hw, reference=None):
         """synthesis -> unpad -> floats_to_pixels -> quantize_image (reference :297-317) as uint8 [n, H, W, 3], plus the
@@ -583,14 +592,18 @@ class Model:
         self._adam = [dict(m=torch.zeros_like(rv.loc), v=torch.zeros_like(rv.loc)) for rv in self.latent_rvs.uq]
         self.itinf = True
         self._itinf_step = 0
+        self._itinf_pending = None
 
     @property
     def itinf_trainable_variables(self):
         return self.latent_rvs.trainable_variables
 
-    def itinf_train_step(self, image_batch, noise=None, seed=0):
+    def itinf_train_step(self, image_batch, noise=None, seed=0, fetch=True):
         """One SGA step: loss = bpp + lambda * MSE(unrounded 0-255 floats), gradients to [z_loc, y_loc] only,
-        Keras-Adam update (:397-408).  ``noise`` = (gumbel_z, gumbel_y) makes the step deterministic."""
+        Keras-Adam update (:397-408).  ``noise`` = (gumbel_z, gumbel_y) makes the step deterministic.
+        ``fetch`` False: the step's three scalars stay on the device and nothing synchronises (the reference's step is a
+        tf.function whose metrics are only converted where the loop logs them, common/itinf_lib.py:67-75); returns None, and
+        ``itinf_last_metrics()`` fetches the most recent step's metrics when the caller wants them."""
         x = self._as_device_images(image_batch)
         cfg = self.latent_config["uq"]
         if cfg.get("method") != "sga":
@@ -608,11 +621,23 @@ class Model:
             for p, g, st in zip(locs, grads, self._adam):
                 ops.adam_step(p, g, st["m"], st["v"], lr, t, self._optimizer_config.get("beta_1", 0.9),
                               self._optimizer_config.get("beta_2", 0.999), self._optimizer_config.get("epsilon", 1e-7))
-            host = torch.stack([r["bits_z"], r["bits_y"], r["sse"]]).cpu().numpy()
-            ops.check_conv_status()
-        _, metrics = self._finish_metrics(x.shape, host[0] if len(locs) == 2 else None, host[1], host[2])
+            # the metrics depend on (step, lr, lambda, tau) of THIS step: keep them with the device scalars
+            self._itinf_pending = dict(dev=torch.stack([r["bits_z"], r["bits_y"], r["sse"]]), shape=tuple(x.shape), two=len(locs) == 2,
+                                       scalars=(self._scheduled_lr, self._scheduled_rd_lambda, tau))
         self._itinf_step += 1
         self.last_grads = tuple(grads)
+        return self.itinf_last_metrics() if fetch else None
+
+    def itinf_last_metrics(self):
+        """Metrics of the most recent ``itinf_train_step`` (one device -> host copy; raises if a stream-K launch since the last
+        check was flagged)."""
+        pend = getattr(self, "_itinf_pending", None)
+        if pend is None:
+            raise RuntimeError("no SGA step has run since initialize_itinf")
+        with torch.cuda.device(self.device):
+            host = pend["dev"].cpu().numpy()
+            ops.check_conv_status()
+        _, metrics = self._finish_metrics(pend["shape"], host[0] if pend["two"] else None, host[1], host[2], sched=pend["scalars"])
         return metrics
 
     def itinf_validation_step(self, image_batch, training=False) -> Metrics:

@@ -23,7 +23,7 @@ WGRAD_STREAM = None         # training: the side stream the weight / bias gradie
 FUSE_RESIDUAL_TAIL = True   # ResidualBlock (c = 192): 3x3 and 1x1 + skip in one launch (bit-identical; False: two launches)
 FUSE_RESIDUAL_BLOCK = not os.environ.get("SNTC_NO_RB_FUSE")   # ResidualBlock (c = 192): head, 3x3 and tail + skip in ONE launch on an 8 x 32
                             # pixel tile with its halo patch in LDS (csrc/rb_fused.hip; bit-identical to the three launches)
-FUSED_BLOCK_MIN_TILES = 128  # ... where the launch offers at least this many 8 x 32 tiles (one workgroup per CU); below, the layers
+FUSED_BLOCK_MIN_TILES = 256  # ... where the launch offers at least one 8 x 32 tile per CU (one workgroup per CU); below, the layers
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
 ROW_PACKED_FIRST_LAYER = not os.environ.get("SNTC_NO_ROWPACK")    # Cin = 3 analysis layers run as row-packed plans (False: the generic dword-gather path, for the A/B)

@@ -767,21 +767,28 @@ class Trainer:
                  m=self.store.m.cpu().numpy(), v=self.store.v.cpu().numpy(),
                  layout=np.array(json.dumps({k: [int(o), list(map(int, shp))] for k, (o, shp) in self.store.offsets.items()})))
         # tf.train.CheckpointManager's state file: what tf.train.latest_checkpoint (reference eval_lib.py:42-44) reads.
-        # CheckpointManager(max_to_keep=train_eval_config.get('max_ckpts_to_keep', 1)), train_lib.py:124-126: the newest N by
-        # step stay and are all listed; only files of checkpoints THIS naming scheme wrote (ckpt-<digits>.*) are ever removed.
+        # CheckpointManager(max_to_keep=train_eval_config.get('max_ckpts_to_keep', 1)), train_lib.py:124-126, keeps by RECENCY:
+        # the checkpoint just written always stays (also when the directory holds bundles with higher step numbers: a reused
+        # workdir, a step reset), next to the newest N - 1 others; only files this naming scheme wrote (ckpt-<digits>.*) are ever
+        # removed, and only AFTER the state file names the survivors (a crash in between leaves stale files, never a state file
+        # that points at deleted ones).
         import os
         import re
         name = f"ckpt-{self.step_count}"
-        steps = sorted({int(m.group(1)) for f in ckdir.glob("ckpt-*") if (m := re.fullmatch(r"ckpt-(\d+)\..+", f.name))})
-        keep = steps[-max(1, int(max_to_keep)):]
-        for f in ckdir.glob("ckpt-*"):
-            m = re.fullmatch(r"ckpt-(\d+)\..+", f.name)
-            if m and int(m.group(1)) not in keep:
-                f.unlink()
+        files = [(f, int(m.group(1))) for f in ckdir.glob("ckpt-*") if (m := re.fullmatch(r"ckpt-(\d+)\..+", f.name))]
+        age = {}
+        for f, k in files:
+            age[k] = max(age.get(k, 0.0), f.stat().st_mtime)
+        others = sorted((k for k in age if k != self.step_count), key=lambda k: (age[k], k))
+        keep = others[len(others) - (max(1, int(max_to_keep)) - 1):] if max_to_keep > 1 else []
+        keep = keep + [self.step_count]
         state = f'model_checkpoint_path: "{name}"\n' + "".join(f'all_model_checkpoint_paths: "ckpt-{k}"\n' for k in keep)
         tmp = ckdir / "checkpoint.tmp"
         tmp.write_text(state)
         os.replace(tmp, ckdir / "checkpoint")                  # the state file changes atomically, after the bundle is complete
+        for f, k in files:
+            if k not in keep:
+                f.unlink()
         return prefix
 
     def restore_optimizer(self, prefix):

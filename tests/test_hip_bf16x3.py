@@ -229,3 +229,20 @@ def test_model_in_bf16x3_meets_the_baseline_bars(synth, dev, monkeypatch):
     p32 = m32.decode(*m32.encode(x)[:2], (256, 320))
     d = (p32.to(torch.int16) - px.to(torch.int16)).abs()
     assert int(d.max()) <= 1
+
+
+def test_split_precision_analysis_does_not_depend_on_the_batch(dev):
+    """Under precision="bf16x3" the arithmetic a layer takes is a function of the layer and of ONE image's geometry (DualPlan;
+    the ResidualBlocks run the exact fp32 block or layers, which are bit-identical to each other): an image's latents are
+    the same bits alone and inside a batch of four, and so are its decoded pixels."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, precision="bf16x3", **configs.two_layer_syn(rd_lambda=0.02))
+    x = torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(4, 256, 384, seed=11))).to(dev)
+    z4, s4, _, _ = model.encode(x)
+    z1, s1, _, _ = model.encode(x[2:3].contiguous())
+    assert torch.equal(z4[2:3], z1) and torch.equal(s4[2:3], s1)
+    p4 = model.decode(z4, s4, (256, 384))
+    p1 = model.decode(z1, s1, (256, 384))
+    assert torch.equal(p4[2:3], p1)

@@ -120,3 +120,39 @@ def test_gpu_words_equal_the_golden_stream(dev):
         gold = torch.from_numpy(g[f"words_s{segs}"].view(np.int16)).to(dev)
         back = ec.rans_decode(gold, g[f"lens_s{segs}"], tids, tuple(vals.shape), dt, segs, lanes)
         assert torch.equal(back, vals)
+
+
+@pytest.mark.gpu
+def test_a_flagged_stream_k_launch_raises_in_every_codec_path(dev):
+    """A stream-K hand-off that timed out leaves INVALID results and a sticky device flag (include/sntc.h, Stream-K health).
+    compress / decompress / encode / decode must raise on it -- never hand out a wrong file or wrong pixels -- and the
+    library then runs the static schedule, with which the same calls succeed and agree with the un-flagged results."""
+    from shallow_ntc_amd import _capi, ops
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.02))
+    x = torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(1, 256, 256, seed=3))).to(dev)
+    blob = model.compress(x)
+    px = model.decompress(blob)
+    z_hat, sym, _, _ = model.encode(x)
+    inject = lambda: _capi.call("sntc_conv_status_inject", 1, ops._stream())
+    try:
+        for call in (lambda: model.compress(x), lambda: model.decompress(blob), lambda: model.encode(x),
+                     lambda: model.decode(z_hat, sym, (256, 256))):
+            inject()
+            with pytest.raises(_capi.SntcError, match="stream-K"):
+                call()
+            # the flag was read and cleared in one atomic; the schedule is static now and the call goes through
+            flags = __import__("ctypes").c_int(-1)
+            _capi.call("sntc_conv_status", __import__("ctypes").byref(flags), ops._stream())
+            assert flags.value == 0
+        assert model.compress(x) == blob
+        assert torch.equal(model.decompress(blob), px)
+        # a deferred check (check=False) leaves the flag for the caller's own synchronisation point
+        inject()
+        model.decode(z_hat, sym, (256, 256), check=False)
+        with pytest.raises(_capi.SntcError, match="stream-K"):
+            ops.check_conv_status()
+    finally:
+        _capi.call("sntc_conv_set_stream_k", 1)

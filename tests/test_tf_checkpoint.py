@@ -279,8 +279,34 @@ def test_signal_conv_checkpoints_round_trip(which, tmp_path):
     rdft_keys = [k for k in raw if "/rdft/" in k]
     assert len(rdft_keys) == sum(1 for k in w if k.endswith("/kernel") and k.split("/")[0] in ("analysis", "synthesis"))
     assert all(raw[k].shape[0] in (30, 90) for k in rdft_keys)          # 5x5 -> 2*5*3 rows, 9x9 -> 2*9*5 rows
-    with pytest.warns(RuntimeWarning, match="import of tfc.SignalConv2D kernels"):
+    # this repository's writer records the rdft column order it used; the reader honours the record (no warning: the order is known)
+    assert tc.RDFT_LAYOUTS[int(raw[tc.WRITER_LAYOUT_KEY])] == tc.RDFT_LAYOUT
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         got = tc.load_reference_checkpoint(prefix, tconf)
     assert set(got) == set(w)
     for k in w:
         np.testing.assert_allclose(got[k], w[k], rtol=2e-6, atol=2e-6, err_msg=k)
+    # ... also when the module default has changed since the bundle was written
+    other = [l for l in tc.RDFT_LAYOUTS if l != tc.RDFT_LAYOUT][0]
+    saved = tc.RDFT_LAYOUT
+    try:
+        tc.RDFT_LAYOUT = other
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            again = tc.load_reference_checkpoint(prefix, tconf)
+    finally:
+        tc.RDFT_LAYOUT = saved
+    for k in w:
+        np.testing.assert_allclose(again[k], w[k], rtol=2e-6, atol=2e-6, err_msg=k)
+    # a bundle without the record is TensorFlow's as far as anyone can tell: module default, loud warning ...
+    bare = {k: v for k, v in raw.items() if k != tc.WRITER_LAYOUT_KEY}
+    tc.write_bundle(tmp_path / "bare-7", bare)
+    tc._rdft_warned.clear()
+    with pytest.warns(RuntimeWarning, match="import of tfc.SignalConv2D kernels"):
+        tc.load_reference_checkpoint(tmp_path / "bare-7", tconf)
+    # ... unless the side file of this repository's trainer says an EARLIER build wrote it: refused, the order is unknown
+    (tmp_path / "bare-7.optimizer.npz").write_bytes(b"")
+    with pytest.raises(ValueError, match="earlier build"):
+        tc.load_reference_checkpoint(tmp_path / "bare-7", tconf)

@@ -63,6 +63,6 @@ def run(fn, label):
 
 
 z_hat, sym, _, _ = model.encode(x)
-run(lambda: model.decode(z_hat, sym, (h, w)), "decode")
+run(lambda: model.decode(z_hat, sym, (h, w), check=False), "decode")
 if not args.decode_only:
-    run(lambda: model.encode(x), "encode")
+    run(lambda: model.encode(x, check=False), "encode")
