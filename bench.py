@@ -132,6 +132,9 @@ def launch_check(args, json_fd=1):
     info = D.describe_world(None)
     table = D.gather_rows([[float(rank), 2.0 * rank]], [rank], world)
     t = D.max_over_ranks(float(rank))
+    # the schedule broadcast of the timed path (rank 0 measures, everyone runs its choices): one all_gather_object
+    choices = D.share_from_rank0([(0, "conv", 192, 192, 18, 256, 384, 3, 0)] if rank == 0 else None)
+    assert choices == [(0, "conv", 192, 192, 18, 256, 384, 3, 0)], choices
     D.barrier()
     if rank == 0:
         assert t == world - 1 and table[:, 0].tolist() == list(range(world))
@@ -370,13 +373,23 @@ def main():
     def tune(fn):
         """One untimed, serial, single-stream pass of a region's step in which every convolution plan measures its (tile,
         schedule) candidates on the shapes it meets and keeps the fastest (ops.autotune / sntc_conv_plan_tune).  All
-        candidates compute the same chains: the timed steps below run other launches of the same arithmetic, same bits."""
+        candidates compute the same chains: the timed steps below run other launches of the same arithmetic, same bits.
+        With N > 1 ranks only rank 0 measures; its choices reach the others by one all_gather_object, so every rank runs
+        identical launches (a rank with another schedule would be a skewed scaling point) and the job spends the tuning
+        time once.  The other ranks run the step once, untimed, so that their allocations are warm as well."""
         if args.no_autotune:
             return
         t0 = time.perf_counter()
-        with ops.autotune():
+        if rank == 0:
+            with ops.autotune():
+                fn()
+        else:
             fn()
         torch.cuda.synchronize()
+        if world > 1:
+            choices = D.share_from_rank0(ops.export_tuning() if rank == 0 else None)
+            if rank != 0:
+                ops.import_tuning(choices)
         tune_seconds[0] += time.perf_counter() - t0
 
     # (Not the Kodak decode: its two batch shapes run on two streams at once, and a schedule measured with the device to itself

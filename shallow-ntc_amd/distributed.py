@@ -94,6 +94,15 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def share_from_rank0(obj):
+    """Rank 0's ``obj`` on every rank (one ``all_gather_object``; the payloads here are a few KB of schedule choices)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return obj
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, obj if dist.get_rank() == 0 else None)
+    return got[0]
+
+
 def gather_rows(local_rows, indices, num_items, device="cpu", width=None):
     """All-gather per-image metric rows.  local_rows: float array [len(indices), k] for the image
     ids in ``indices``.  Returns the full [num_items, k] table on every rank, ordered by image id.

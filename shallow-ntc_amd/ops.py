@@ -173,6 +173,10 @@ def to_device(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
 
 
+_PLAN_REGISTRY = []     # weak references to every ConvPlan in creation order: the plan's index is its identity across the ranks of
+                        # a job (every rank builds the same models in the same order) -- export_tuning() / import_tuning()
+
+
 class ConvPlan:
     """One packed convolution (sntc_conv_plan): Conv2D / Conv2DTranspose / SignalConv2D (+GDN pool)."""
 
@@ -205,6 +209,8 @@ class ConvPlan:
         capi.call("sntc_conv_plan_create", C.byref(desc), _ptr(w), _ptr(b), _stream(), C.byref(self._h))
         torch.cuda.current_stream().synchronize()   # packing reads w/b; they may be freed after this
         self._tuned = {}
+        import weakref
+        _PLAN_REGISTRY.append(weakref.ref(self))
         if FORCE_TILE:
             self.set_tile(FORCE_TILE)
 
@@ -441,6 +447,33 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None):
             log.append(dict(layer=f"{plan.kind} k{plan.k[0]} s{plan.stride} {plan.cin}->{plan.cout}", shape=[n, h, w], model=list(start),
                             chosen=None if chosen is None else list(chosen), step_ms=round(best, 4)))
     return base, best
+
+
+def export_tuning():
+    """Every measured launch schedule of this process as plain data: [(plan index in creation order, kind, cin, cout, n, h, w,
+    variant, stream_k)].  One rank measures (``with ops.autotune()``), the others ``import_tuning`` what it found, so that all
+    ranks of a job run IDENTICAL launches (same bits either way -- every candidate computes the same chains -- but a rank
+    that picked another schedule would be a skewed scaling point, and N ranks need not spend N x the tuning time)."""
+    out = []
+    for idx, ref in enumerate(_PLAN_REGISTRY):
+        p = ref()
+        if p is None:
+            continue
+        for (n, h, w), (v, sk) in sorted(p._tuned.items()):
+            out.append((idx, p.kind, p.cin, p.cout, int(n), int(h), int(w), int(v), int(sk)))
+    return out
+
+
+def import_tuning(entries):
+    """Apply another rank's ``export_tuning()``; a plan whose (kind, cin, cout) does not match the entry's is a job whose ranks
+    built different models: refused loudly."""
+    for idx, kind, cin, cout, n, h, w, v, sk in entries:
+        p = _PLAN_REGISTRY[idx]() if idx < len(_PLAN_REGISTRY) else None
+        if p is None or (p.kind, p.cin, p.cout) != (kind, cin, cout):
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, f"import_tuning: plan {idx} here is "
+                                 f"{None if p is None else (p.kind, p.cin, p.cout)}, the entry was measured on {(kind, cin, cout)}: "
+                                 "the ranks did not build the same plans in the same order")
+        p.set_choice(n, h, w, v, sk)
 
 
 def set_stream_k(enabled):

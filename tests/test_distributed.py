@@ -138,6 +138,18 @@ def test_bench_self_launches_two_ranks():
     assert len({d["host_pid"] for d in line["rccl"]["devices"]}) == 2          # two processes, not one
 
 
+def test_bench_self_launches_eight_ranks():
+    """The driver's widest launch (`--gpus 8`: one process per GPU of the node) on the CPU: eight gloo ranks rendezvous, run
+    the path's collectives incl. the schedule broadcast from rank 0, and rank 0's line names all eight."""
+    import json
+    r = _run_bench(dict(SNTC_DIST_BACKEND="gloo", OMP_NUM_THREADS="1"), "--gpus", "8", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["rccl"]["world"] == 8
+    assert sorted(d["rank"] for d in line["rccl"]["devices"]) == list(range(8))
+    assert len({d["host_pid"] for d in line["rccl"]["devices"]}) == 8
+
+
 def test_bench_launcher_propagates_a_failing_rank():
     r = _run_bench(dict(SNTC_DIST_BACKEND="gloo", SNTC_LAUNCH_CHECK_FAIL_RANK="1"), "--gpus", "2", "--launch-check")
     assert r.returncode != 0
@@ -170,7 +182,7 @@ def test_unit_dealing_gives_the_same_table_for_any_world_size():
     number of units (a rank with nothing to do still takes part in the gather)."""
     ctx = mp.get_context("spawn")
     tables = {}
-    for world, num_units in ((1, 13), (2, 13), (2, 1)):
+    for world, num_units in ((1, 13), (2, 13), (2, 1), (8, 13), (8, 5)):
         q = ctx.Queue()
         port = _free_port()
         procs = [ctx.Process(target=_units_worker, args=(r, world, port, num_units, q)) for r in range(world)]
@@ -187,3 +199,4 @@ def test_unit_dealing_gives_the_same_table_for_any_world_size():
             np.testing.assert_array_equal(table, outs[0][1])
         tables[(world, num_units)] = outs[0][1]
     np.testing.assert_array_equal(tables[(1, 13)], tables[(2, 13)])
+    np.testing.assert_array_equal(tables[(1, 13)], tables[(8, 13)])          # the node's eight ranks: same table again

@@ -523,3 +523,26 @@ def test_row_packed_first_layer(k, s, cin, cout, n, h, w, act, dev):
     assert torch.equal(alone, y[:1])
     with pytest.raises(Exception):
         ops.ConvPlan("conv", dev_t(rng.standard_normal((5, 5, 4, 16)).astype(np.float32), dev), None, 2, rowpack=True)   # 5 * 4 > 16
+
+
+@pytest.mark.gpu
+def test_tuning_choices_travel_between_ranks_as_plain_data(dev):
+    """ops.export_tuning() / import_tuning(): what rank 0 measured, applied by another rank's plans in creation order -- the
+    same launches everywhere, identical bits (every candidate computes the same chains); plans that do not match are refused."""
+    from shallow_ntc_amd import _capi as capi
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(5)
+    w = dev_t((rng.standard_normal((3, 3, 96, 96)) * 0.05).astype(np.float32), dev)
+    x = dev_t(rng.standard_normal((2, 40, 56, 96)).astype(np.float32), dev)
+    base = len(ops._PLAN_REGISTRY)
+    a = ops.ConvPlan("conv", w, None, 1, "relu")
+    ref = a(x)
+    a.tune(x)
+    entries = [e for e in ops.export_tuning() if e[0] == base]
+    assert len(entries) == 1 and entries[0][1:7] == ("conv", 96, 96, 2, 40, 56)
+    # "another rank": a fresh plan of the same layer takes the choice under ITS index and computes the same bits
+    b = ops.ConvPlan("conv", w, None, 1, "relu")
+    ops.import_tuning([(base + 1,) + entries[0][1:]])
+    assert b._tuned == a._tuned and torch.equal(b(x), ref)
+    with pytest.raises(capi.SntcError, match="same plans"):
+        ops.import_tuning([(base + 1, "conv", 192, 96) + entries[0][4:]])

@@ -491,12 +491,11 @@ def test_train_eval_loop_and_itinf_loop_drivers(dev, tmp_path):
     for suffix in (".index", ".data-00000-of-00001"):
         (rck / f"ckpt-99{suffix}").write_bytes(b"stale")
         os.utime(rck / f"ckpt-99{suffix}", (1, 1))
-    model3 = Model(device=dev, rd_lambda=0.02, transform_config=cfg, scheduled_num_steps=3,
-                   optimizer_config=dict(learning_rate=1e-3, global_clipnorm=1.0, warmup_steps=0), quality_metrics=False)
-    train_lib.simple_train_eval_loop(dict(num_steps=3, log_metrics_every_steps=100, checkpoint_every_steps=3), reuse, model3, forever(), batches[:1])
-    assert sorted(p.name for p in rck.glob("*.index")) == ["ckpt-3.index"]
-    assert 'model_checkpoint_path: "ckpt-3"' in (rck / "checkpoint").read_text() and "ckpt-99" not in (rck / "checkpoint").read_text()
-    assert eval_lib.load_latest_ckpt(reuse, device=dev)._step == 3
+    assert model2.trainer is not None and model2.trainer.step_count == 9
+    model2.trainer.save_checkpoint(reuse)
+    assert sorted(p.name for p in rck.glob("*.index")) == ["ckpt-9.index"]
+    assert 'model_checkpoint_path: "ckpt-9"' in (rck / "checkpoint").read_text() and "ckpt-99" not in (rck / "checkpoint").read_text()
+    assert eval_lib.load_latest_ckpt(reuse, device=dev)._step == 9
     a = restored.validation_step(batches[0]).scalars_float
     b = model.validation_step(batches[0]).scalars_float
     assert a["bpp"] == b["bpp"] and a["psnr"] == b["psnr"]
