@@ -260,12 +260,31 @@ class SimpleAttention:
         return cin
 
     def __call__(self, x):
+        # trunk and branch are independent until the gate: where one launch leaves most of the device idle (an image alone at
+        # 1/4 or 1/16 resolution offers 72 - 384 workgroups to 256 CUs) they run on two streams at once -- same kernels, same bits
+        side = None
+        if ops.CONCURRENT_BRANCHES and ops.ResBlockPlan.tiles(*x.shape[:3]) < ops.CONCURRENT_BRANCH_MAX_TILES:
+            side = ops.companion_stream()
+        if side is None:
+            t = x
+            for l in self._trunk:
+                t = l(t)
+            b = x
+            for l in self._branch:
+                b = l(b)
+            return self._gate(b, res=x, aux=t)
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            b = x
+            for l in self._branch:
+                b = l(b)
         t = x
         for l in self._trunk:
             t = l(t)
-        b = x
-        for l in self._branch:
-            b = l(b)
+        cur.wait_stream(side)
+        b.record_stream(cur)              # allocated on the side stream, consumed here: the allocator must not hand it out early
+        x.record_stream(side)
         return self._gate(b, res=x, aux=t)
 
     def out_hw(self, h, w):

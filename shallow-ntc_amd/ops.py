@@ -24,6 +24,8 @@ FUSE_RESIDUAL_TAIL = True   # ResidualBlock (c = 192): 3x3 and 1x1 + skip in one
 FUSE_RESIDUAL_BLOCK = not os.environ.get("SNTC_NO_RB_FUSE")   # ResidualBlock (c = 192): head, 3x3 and tail + skip in ONE launch on an 8 x 32
                             # pixel tile with its halo patch in LDS (csrc/rb_fused.hip; bit-identical to the three launches)
 FUSED_BLOCK_MIN_TILES = 256  # ... where the launch offers at least one 8 x 32 tile per CU (one workgroup per CU); below, the layers
+CONCURRENT_BRANCHES = not os.environ.get("SNTC_NO_BRANCH_STREAMS")   # SimpleAttention: trunk and branch on two streams when the launches are small
+CONCURRENT_BRANCH_MAX_TILES = 1024  # ... i.e. up to a few 8 x 32 pixel tiles per CU (two launches then share the rounds a single one leaves ragged)
 MAX_INPUT_BYTES = 1 << 31   # sntc_conv_forward: inputs are addressed with 32-bit buffer offsets
 PROFILE = None   # set to a list to record one entry per convolution launch (bench.py)
 ROW_PACKED_FIRST_LAYER = not os.environ.get("SNTC_NO_ROWPACK")    # Cin = 3 analysis layers run as row-packed plans (False: the generic dword-gather path, for the A/B)
@@ -34,6 +36,23 @@ BF16X3_EXPERIMENT = False   # bench.py regions.decode_bf16x3 only: plans created
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_COMPANIONS = {}
+
+
+def companion_stream():
+    """A second stream paired with the CURRENT one (one per current stream and device, created on first use): independent
+    sub-graphs of a small launch run on it next to the caller's stream.  None while a HIP graph is being captured or a
+    schedule is being measured (ops.autotune times launches with the device to itself)."""
+    if AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return None
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    st = _COMPANIONS.get(key)
+    if st is None:
+        st = _COMPANIONS[key] = torch.cuda.Stream(device=cur.device)
+    return st
 
 
 def _ptr(t):

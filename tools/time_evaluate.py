@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The reference's evaluation flow (eval_lib: one image at a time, MS-SSIM on): wall time for a Kodak-shaped set."""
+"""The reference's evaluation flow (mshyper/models.py:425-433, eval_lib: one image at a time): wall time for a Kodak-shaped
+set, strictly serial (lookahead 1) and with the default look-ahead grouping, PSNR only and with MS-SSIM."""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -13,12 +14,19 @@ from shallow_ntc_amd.mshyper import configs
 from shallow_ntc_amd.mshyper.models import Model
 dev = torch.device("cuda:0")
 model = Model(device=dev, **configs.CONFIGS["two_layer_syn"]())
-shapes = [(512, 768)] * 18 + [(768, 512)] * 6
+shapes = [(768, 512) if i in (3, 8, 9, 16, 17, 18) else (512, 768) for i in range(24)]
 images = [torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(1, h, w, seed=i))).to(dev) for i, (h, w) in enumerate(shapes)]
-list(model.evaluate(images[:2]))
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-rows = [m.scalars_float for m in model.evaluate(images)]
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"evaluate(): {len(rows)} images one at a time in {dt * 1e3:.1f} ms ({dt / len(rows) * 1e3:.2f} ms per image, {sum(h * w for h, w in shapes) / dt / 1e6:.1f} Mpixel/s), keys {sorted(rows[0])}")
+px = sum(h * w for h, w in shapes)
+for quality in (False, True):
+    model._quality_metrics = quality
+    for look in (1, 4):
+        list(model.evaluate(images, lookahead=look))
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rows = [m.scalars_float for m in model.evaluate(images, lookahead=look)]
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
+        print(f"evaluate(lookahead={look}, msssim={quality}): {dt / len(rows) * 1e3:.3f} ms per image, {px / dt / 1e6:.1f} Mpixel/s", flush=True)
