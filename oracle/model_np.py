@@ -140,13 +140,16 @@ class Model:
         return (z, y)
 
     # ---- generative path + losses, eval branch (mshyper/models.py:234-359) ---------------
-    def frame_loss(self, params, x, latents, sga=None, be=None, force_symbols=None):
+    def frame_loss(self, params, x, latents, sga=None, be=None, force_symbols=None, force_z=None):
         """sga=None: training=False hard rounding.  sga=dict(tau, gumbel_z, gumbel_y): the explicit-
         sampling training branch used by itinf_train_step (models.py:260-268,285-291).
         force_symbols (tests only): integer symbols to use INSTEAD of round(y - mu), so that the rate and the
         reconstruction of another implementation's symbols can be checked separately from the (counted) positions
         where its float32 y - mu fell on the other side of a rounding boundary; ``tie_distance`` then reports
-        | |frac(y - mu)| - 0.5 | of the oracle at every position."""
+        | |frac(y - mu)| - 0.5 | of the oracle at every position.
+        force_z (tests only): integer hyper-latents to use INSTEAD of round(z) -- a float32 implementation whose z lies within
+        ~1e-6 of a rounding tie can land on the other side, which moves mu / sigma over that hyper-latent's receptive field; with
+        z pinned the rest of the chain is compared like for like, and ``z_tie_distance`` reports | |frac(z)| - 0.5 | of the oracle."""
         x = np.asarray(x, np.float64)
         ms, bs, fs = _prior_lists(params)
         ln2 = math.log(2.0)
@@ -163,7 +166,12 @@ class Model:
             bits_y = bits
         else:
             z_loc, y_loc = latents
-            if sga is None:
+            if sga is None and force_z is not None:
+                z_hat = np.asarray(force_z, np.float64)
+                bits_z = ops.deep_factorized_logprob(z_hat, ms, bs, fs).sum(axis=(1, 2, 3)) / -ln2
+                dz = np.asarray(z_loc, np.float64)
+                out["z_tie_distance"] = np.abs(np.abs(dz - np.floor(dz) - 0.5))
+            elif sga is None:
                 z_hat, bits_z = ops.batched_deep_factorized(z_loc, ms, bs, fs)
             else:
                 z_hat = ops.sga_round(z_loc, sga["tau"], sga["gumbel_z"], offset=0.0)

@@ -333,3 +333,95 @@ def test_bf16x3_image_to_bpp_psnr_at_full_width(name, hw, dev):
     assert abs(rep["d_bpp"]) <= 1e-4, rep            # BASELINE.json north_star tolerance
     assert abs(rep["d_psnr"]) <= 1e-3, rep
     assert flips <= sym.size * 2e-4, rep
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The margin, not one image: all 24 Kodak-shaped images (18 landscape + 6 portrait, Kodak's own order) through the same
+# end-to-end comparison at two operating points; every image is held to the bars by itself and the distribution
+# (max / median |d bpp|, |d PSNR|, symbol flips, hyper-latent flips) is written out for DESIGN.md / README.md
+# (tools/parity_tables.py renders those tables from the committed JSON -- no hand-typed parity number).
+# ---------------------------------------------------------------------------------------------------------------------------
+KODAK_POINTS = {"2.3bpp": "high_rate", "0.25bpp": 0.25}
+
+
+@pytest.mark.parametrize("label", list(KODAK_POINTS))
+def test_kodak_set_margin_distribution(label, dev):
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    shapes = [(768, 512) if i in (3, 8, 9, 16, 17, 18) else (512, 768) for i in range(24)]
+    images = [data_lib.normalize_image(data_lib.synthetic_images(1, h, w, seed=700 + i)) for i, (h, w) in enumerate(shapes)]
+    point = KODAK_POINTS[label]
+    if isinstance(point, str):
+        model, w = _model("two_layer_syn", dev, **OPERATING_POINTS[point])
+    else:
+        model, w = _model_at_bpp("two_layer_syn", dev, images[0], point)
+    ref_model = model_np.Model(configs.CONFIGS["two_layer_syn"]()["transform_config"], rd_lambda=0.02)
+    # the float64 oracle on each orientation's images as ONE batch (its library convolutions thread better that way: the two
+    # operating points together are 48 full-width 512 x 768 evaluations); every image is then read out by itself
+    oracle = {}
+    for shape in sorted(set(shapes)):
+        ids = [i for i, s in enumerate(shapes) if s == shape]
+        xb = np.concatenate([images[i] for i in ids])
+        rl = ref_model.infer_latents(w, xb, be=train_ref)
+        rf = ref_model.frame_loss(w, xb, rl, be=train_ref)
+        npix = float(shape[0] * shape[1])
+        for k, i in enumerate(ids):
+            oracle[i] = dict(lat=tuple(t[k:k + 1] for t in rl), symbols_y=rf["symbols_y"][k:k + 1], z_hat=rf["z_hat"][k:k + 1],
+                             bpp=float((rf["bits_z"][k] + rf["bits_y"][k]) / npix), psnr=float(rf["psnrs"][k]))
+    rows = []
+    for i, x in enumerate(images):
+        lat = model.infer_latent_rvs(x)
+        r = model._rate_and_reconstruction(lat, want_symbols=True)
+        _, metrics = model.frame_loss_given_latent_rvs(x, lat, training=False)
+        m = metrics.scalars_float
+        ref, rlat = oracle[i], oracle[i]["lat"]
+        sym, z_gpu = r["symbols"].cpu().numpy(), r["z_hat"].cpu().numpy()
+        zdiff = z_gpu != ref["z_hat"]
+        row = dict(image=i, shape=list(shapes[i]), symbols=int(sym.size), symbol_flips=int((sym != ref["symbols_y"]).sum()),
+                   z_flips=int(zdiff.sum()), bpp_f64=float(ref["bpp"]), d_bpp=m["bpp"] - float(ref["bpp"]),
+                   psnr_f64=float(ref["psnr"]), d_psnr=m["psnr"] - float(ref["psnr"]))
+        if row["z_flips"]:
+            # a hyper-latent the ORACLE itself puts on a rounding tie (any float32 implementation, the reference's included, can
+            # land on either side) moves mu / sigma over its receptive field: it must really be a tie, there may be at most two,
+            # and with the hyper-latents pinned to the GPU's the image is held to the bars like every other
+            pinned = ref_model.frame_loss(w, x, rlat, be=train_ref, force_z=z_gpu)
+            row.update(z_tie_distance_max=float(pinned["z_tie_distance"][zdiff].max()),
+                       symbol_flips_at_gpu_z=int((sym != pinned["symbols_y"]).sum()),
+                       d_bpp_at_gpu_z=m["bpp"] - float(pinned["bpp"]), d_psnr_at_gpu_z=m["psnr"] - float(pinned["psnr"]))
+            assert row["z_flips"] <= 2 and row["z_tie_distance_max"] <= 2e-5, row
+            held = (row["d_bpp_at_gpu_z"], row["d_psnr_at_gpu_z"], row["symbol_flips_at_gpu_z"])
+        else:
+            held = (row["d_bpp"], row["d_psnr"], row["symbol_flips"])
+        rows.append(row)
+        # the BASELINE.json bars, per image, no escape
+        assert abs(held[0]) <= 1e-4, row
+        assert abs(held[1]) <= 1e-3, row
+        assert held[2] <= sym.size * 1e-4, row
+    ab = lambda k: np.abs(np.array([r[k] for r in rows], np.float64))
+    clean = [r for r in rows if not r["z_flips"]]
+    tied = [r for r in rows if r["z_flips"]]
+    abc = lambda k, rs: np.abs(np.array([r[k] for r in rs], np.float64)) if rs else np.zeros(1)
+    summary = dict(images=len(rows), bpp_f64_range=[min(r["bpp_f64"] for r in rows), max(r["bpp_f64"] for r in rows)],
+                   images_without_z_flips=len(clean),
+                   max_abs_d_bpp=float(abc("d_bpp", clean).max()), median_abs_d_bpp=float(np.median(abc("d_bpp", clean))),
+                   max_abs_d_psnr=float(abc("d_psnr", clean).max()), median_abs_d_psnr=float(np.median(abc("d_psnr", clean))),
+                   max_symbol_flips=int(abc("symbol_flips", clean).max()), total_symbol_flips=int(abc("symbol_flips", clean).sum()),
+                   images_with_symbol_flips=int((abc("symbol_flips", clean) > 0).sum()),
+                   share_of_the_bpp_bar_used=float(abc("d_bpp", clean).max() / 1e-4),
+                   share_of_the_psnr_bar_used=float(abc("d_psnr", clean).max() / 1e-3),
+                   images_with_z_flips=len(tied), max_z_flips=int(ab("z_flips").max()),
+                   z_tie_distance_max=float(max((r["z_tie_distance_max"] for r in tied), default=0.0)),
+                   raw_max_abs_d_bpp_with_z_flips=float(abc("d_bpp", tied).max()),
+                   raw_max_symbol_flips_with_z_flips=int(abc("symbol_flips", tied).max()),
+                   max_abs_d_bpp_at_gpu_z=float(abc("d_bpp_at_gpu_z", tied).max()),
+                   max_abs_d_psnr_at_gpu_z=float(abc("d_psnr_at_gpu_z", tied).max()),
+                   max_symbol_flips_at_gpu_z=int(abc("symbol_flips_at_gpu_z", tied).max()))
+    out = ROOT / "gpurun_out"
+    if out.is_dir():
+        f = out / "e2e_parity_kodak24.json"
+        rep = json.loads(f.read_text()) if f.exists() else {}
+        rep[label] = dict(summary=summary, per_image=rows)
+        f.write_text(json.dumps(rep, indent=1))
+    print(json.dumps({label: summary}))
+    if isinstance(point, float):                      # the set really sits around the published operating point
+        assert 0.3 * point <= summary["bpp_f64_range"][0] and summary["bpp_f64_range"][1] <= 3.0 * point, summary
