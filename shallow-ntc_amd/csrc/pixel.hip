@@ -86,6 +86,41 @@ __global__ void __launch_bounds__(256) pixels_sse_kernel(const float* __restrict
   if (threadIdx.x == 0) atomicAdd(sse + img, part[0] + part[1] + part[2] + part[3]);
 }
 
+// The same four values per thread: 16-B loads, one packed 32-bit pixel store, 32-bit partial sums per iteration (4 x 255^2 fits
+// with room), per row a 32-bit index split.  Needs rowlen % 4 == 0 and (ws * c) % 4 == 0, i.e. 16-B aligned rows in both tensors
+// (every image width the configs use); the host falls back to the scalar kernel otherwise.  Same integers, same order-independent sum.
+__global__ void __launch_bounds__(256) pixels_sse_vec4_kernel(const float* __restrict__ x, const float* __restrict__ xh, int h, int w,
+                                                              int c, int hs, int ws, uint8_t* __restrict__ px,
+                                                              unsigned long long* __restrict__ sse) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int img = blockIdx.y;
+  const int64_t per = (int64_t)h * w * c;
+  const unsigned row4 = (unsigned)(w * c) >> 2, srow4 = (unsigned)(ws * c) >> 2;
+  const unsigned per4 = (unsigned)(per >> 2);
+  const f32x4* xv = x ? reinterpret_cast<const f32x4*>(x + img * per) : nullptr;
+  const f32x4* hv = reinterpret_cast<const f32x4*>(xh + (int64_t)img * hs * ws * c);
+  unsigned* pv = px ? reinterpret_cast<unsigned*>(px + img * per) : nullptr;
+  unsigned long long acc = 0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < per4; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / row4;
+    const f32x4 b4 = hv[r * srow4 + (i - r * row4)];
+    const int b0 = to_pixel(b4[0]), b1 = to_pixel(b4[1]), b2 = to_pixel(b4[2]), b3 = to_pixel(b4[3]);
+    if (pv) pv[i] = (unsigned)b0 | ((unsigned)b1 << 8) | ((unsigned)b2 << 16) | ((unsigned)b3 << 24);
+    if (xv) {
+      const f32x4 a4 = xv[i];
+      const int d0 = to_pixel(a4[0]) - b0, d1 = to_pixel(a4[1]) - b1, d2 = to_pixel(a4[2]) - b2, d3 = to_pixel(a4[3]) - b3;
+      acc += (unsigned)(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+    }
+  }
+  if (!x) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sse + img, part[0] + part[1] + part[2] + part[3]);
+}
+
 __global__ void __launch_bounds__(256) float_sse_kernel(const float* __restrict__ x, const float* __restrict__ xh, int h, int w,
                                                         int c, int hs, int ws, double* __restrict__ sse) {
   const int img = blockIdx.y;
@@ -383,8 +418,22 @@ extern "C" int sntc_pixels_sse(const float* x, const float* x_hat, int n, int h,
   hipStream_t s = (hipStream_t)stream;
   if (x) SNTC_HIP(hipMemsetAsync(sse_out, 0, sizeof(unsigned long long) * n, s));
   const int64_t per = (int64_t)h * w * c;
+  const bool vec = (w * c) % 4 == 0 && (ws * c) % 4 == 0 && per < (1LL << 33) && ((int64_t)hs * ws * c) % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x_hat)) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(pixels_out) % 4 == 0;
+  if (vec) {
+    int b = blocks_for(per >> 2);
+    // with an SSE every block ends in ONE atomic on its image's word, and atomics on one address serialise at the memory side
+    // (~0.1 us each: 1024 blocks per image cost 100 us by themselves): about 2048 blocks per launch, at most 256 per image
+    const int cap = x ? std::max(16, std::min(256, 2048 / n)) : 1024;
+    if (b > cap) b = cap;
+    hipLaunchKernelGGL(pixels_sse_vec4_kernel, dim3(b, n), dim3(256), 0, s, x, x_hat, h, w, c, hs, ws, pixels_out, sse_out);
+    SNTC_HIP(hipGetLastError());
+    return SNTC_OK;
+  }
   int b = blocks_for(per);
-  if (b > 512) b = 512;
+  const int cap1 = x ? std::max(16, std::min(256, 2048 / n)) : 512;
+  if (b > cap1) b = cap1;
   hipLaunchKernelGGL(pixels_sse_kernel, dim3(b, n), dim3(256), 0, s, x, x_hat, h, w, c, hs, ws, pixels_out, sse_out);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;

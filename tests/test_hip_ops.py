@@ -253,25 +253,26 @@ def test_two_layer_tail(ch, has_res, act, dev):
     assert rel_err(got, ref) < TOL
 
 
-def test_pad_crop_pixels(dev):
+@pytest.mark.parametrize("wd", [50, 52])        # 52: rows of 16-B multiples -> the four-values-per-thread pixel kernel
+def test_pad_crop_pixels(wd, dev):
     from shallow_ntc_amd import ops
     rng = np.random.default_rng(3)
-    x = (rng.integers(0, 256, size=(2, 37, 50, 3)).astype(np.float32) / np.float32(255) - np.float32(0.5))
+    x = (rng.integers(0, 256, size=(2, 37, wd, 3)).astype(np.float32) / np.float32(255) - np.float32(0.5))
     xp = ops.pad_reflect(dev_t(x, dev), 64, 64)
     np.testing.assert_array_equal(xp.cpu().numpy(), O.pad_images(x, 64).astype(np.float32))
-    np.testing.assert_array_equal(ops.crop(xp, 37, 50).cpu().numpy(), x)
+    np.testing.assert_array_equal(ops.crop(xp, 37, wd).cpu().numpy(), x)
     xh = (x + rng.normal(0, 0.05, size=x.shape)).astype(np.float32)
     xh[0, 0, 0, 0] = 2.0      # saturates to 255
     xh[0, 0, 0, 1] = -3.0     # saturates to 0
     xh[0, 0, 1, 0] = np.float32(100.5) / np.float32(255) - np.float32(0.5)   # lands near a .5 tie
-    xh_p = np.pad(xh, ((0, 0), (0, 27), (0, 14), (0, 0)))
+    xh_p = np.pad(xh, ((0, 0), (0, 27), (0, 64 - wd), (0, 0)))
     sse, px = ops.pixels_sse(dev_t(x, dev), dev_t(xh_p, dev), want_pixels=True)
     ref_px = O.floats_to_pixels(xh, training=False)
     ref_x = O.floats_to_pixels(x, training=False)
     np.testing.assert_array_equal(px.cpu().numpy(), ref_px)
     ref_sse = ((ref_x.astype(np.int64) - ref_px.astype(np.int64)) ** 2).reshape(2, -1).sum(1)
     np.testing.assert_array_equal(sse.cpu().numpy(), ref_sse)
-    np.testing.assert_array_equal(ops.to_pixels(dev_t(xh_p, dev), 37, 50).cpu().numpy(), ref_px)
+    np.testing.assert_array_equal(ops.to_pixels(dev_t(xh_p, dev), 37, wd).cpu().numpy(), ref_px)
     fs = ops.float_sse(dev_t(x, dev), dev_t(xh_p, dev)).cpu().numpy()
     ref_fs = (((x.astype(np.float64) - xh.astype(np.float64)) * 255.0) ** 2).reshape(2, -1).sum(1)
     assert np.abs(fs - ref_fs).max() / ref_fs.max() < 1e-5
