@@ -14,7 +14,8 @@
 //          in the fragment order of a 16-deep stage); the result leaves with bias, the skip (+ x) and 16-B stores.
 // The three weight sets travel as ONE stream of 6-KB units (a unit = the LDS image of one 16-deep K stage of all c/2
 // output rows) through a three-slot ring filled by LDS-DMA (buffer_load_dwordx4 ... lds, 1-KB pieces); the
-// workgroup is persistent and the stream wraps from one tile's tail into the next tile's head.
+// workgroup is persistent and the stream wraps from one tile's tail into the next tile's head.  Tiles are walked down the
+// image and the patch is a ring of rows: a tile below the previous one re-uses its two top halo rows and computes 8 new ones.
 //
 // Every output element is the SAME k-ordered fp32 fma chain as in the three stand-alone gather-GEMM launches
 // (gather_gemm.hip: stage = 16 channels, MFMA e of k-group g sums k in {8g+e, 8g+4+e}; 3x3: channel slab outermost,
@@ -160,95 +161,143 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
   f32x4 Fw0[NT], Fw1[NT], FwN[NT];
   read_w(Fw0, 0, 0);
 
-  // head geometry of this wave: patch tile `wave` (all waves) and `wave + 8` (the first NPT - 8 waves), pixel 32 t + l31
+  // Tiles are walked DOWN the image (column-major inside an image), and the patch is a ring of PH rows: image row r lives in
+  // patch row (r + 1) % PH.  A tile right below the one this workgroup has just finished finds its two top halo rows in
+  // place and computes only its 8 new rows (8 x 34 = 272 patch pixels instead of 340: 9 fragment tiles instead of 11) --
+  // "incremental"; the first tile of a workgroup and the top tile of every column compute all ten -- "full".
+  // Head work of this wave, in fragment tiles of 32 flat patch pixels f = 32 t + l31 -> (f / PW, f % PW) of the rows computed:
+  //   full:        tile `wave` (all three channel tiles) and, waves 0 .. NPT - 9, tile `wave + 8` (all three)
+  //   incremental: tile `wave` (all three) and, waves 0 .. NT - 1, channel tile `wave` of tile 8 (the 16 leftover pixels)
   const bool two = wave < K::NPT - 8;
-  int hpp[2], hpy[2], hpx[2];
+  static_assert(K::NPT - 8 == NT, "the same waves take the second tile (full) and one channel tile of tile 8 (incremental)");
+  constexpr int PH = K::PH, NEW = K::TH * PW;
+  int hf[3], hfy[3], hfx[3];                  // [0] tile wave, [1] tile wave + 8 (full), [2] tile 8 (incremental)
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    hpp[p] = 32 * (wave + 8 * p) + l31;
-    hpy[p] = hpp[p] / PW;
-    hpx[p] = hpp[p] - hpy[p] * PW;
+  for (int p = 0; p < 3; ++p) {
+    hf[p] = 32 * (p == 0 ? wave : p == 1 ? wave + 8 : 8) + l31;
+    hfy[p] = hf[p] / PW;
+    hfx[p] = hf[p] - hfy[p] * PW;
   }
-  unsigned hv[2];
-  bool hvalid[2];
-  f32x4 X[2][2][2];                            // [stage parity][patch tile][k-group]
+  unsigned hv[2];                              // [0] tile wave, [1] the second tile of this wave in the mode of the tile
+  bool hvalid[2], hin[2];
+  int hpp[2];                                  // patch pixel the lane's result goes to
+  bool h_inc = false;
+  f32x4 X[3][2][2];                            // [K stage % 3][patch tile][k-group]: the pixel fragments travel two stages ahead
   int n = 0, y0 = 0, x0 = 0;
-  auto coords = [&](int tile, int* tn, int* ty0, int* tx0) {
+  auto coords = [&](int tile, int* tn, int* ty0, int* tx0, bool* inc) {
     const int per = a.tiles_x * a.tiles_y;
     *tn = tile / per;
     const int r = tile - *tn * per;
-    const int tyi = r / a.tiles_x;
+    const int txi = r / a.tiles_y;
+    const int tyi = r - txi * a.tiles_y;
     *ty0 = tyi * K::TH;
-    *tx0 = (r - tyi * a.tiles_x) * K::TW;
+    *tx0 = txi * K::TW;
+    *inc = tile > t_lo && tyi > 0;
   };
   // the head's pixel offsets of tile `tile` and its first K stage on the way (issued a step before the tile begins)
   auto head_setup = [&](int tile) {
     int tn, ty0, tx0;
-    coords(tile, &tn, &ty0, &tx0);
+    coords(tile, &tn, &ty0, &tx0, &h_inc);
+    const int r0 = h_inc ? 2 : 0;
+    const int ybase = ty0 % PH + r0;             // patch row of the first row computed, before the wrap
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int iy = ty0 - 1 + hpy[p], ix = tx0 - 1 + hpx[p];
-      hvalid[p] = hpp[p] < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int q = p == 0 ? 0 : (h_inc ? 2 : 1);
+      const int fy = hfy[q], fx = hfx[q];
+      const int iy = ty0 - 1 + r0 + fy, ix = tx0 - 1 + fx;
+      int pr = ybase + fy;
+      pr = pr >= PH ? pr - PH : pr;
+      pr = pr >= PH ? pr - PH : pr;
+      hin[p] = hf[q] < (h_inc ? NEW : PP);
+      hvalid[p] = hin[p] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       hv[p] = hvalid[p] ? ((unsigned)((tn * a.H + iy) * a.W + ix) * (unsigned)(C * 4) + (unsigned)h * 16u) : kOOB;
+      hpp[p] = pr * PW + fx;
     }
-    X[0][0][0] = buf_load(xs, hv[0], 0);
-    X[0][0][1] = buf_load(xs, hv[0], 32);
-    if (two) {
-      X[0][1][0] = buf_load(xs, hv[1], 0);
-      X[0][1][1] = buf_load(xs, hv[1], 32);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      X[st][0][0] = buf_load(xs, hv[0], st * 64);
+      X[st][0][1] = buf_load(xs, hv[0], st * 64 + 32);
+      if (two) {
+        X[st][1][0] = buf_load(xs, hv[1], st * 64);
+        X[st][1][1] = buf_load(xs, hv[1], st * 64 + 32);
+      }
     }
   };
   head_setup(t_lo);
 
   for (int tile = t_lo; tile < t_hi; ++tile) {
-    coords(tile, &n, &y0, &x0);
+    bool inc_now;
+    coords(tile, &n, &y0, &x0, &inc_now);
 
     // ================================================================================================
     // head: t1 = relu(W0 x + b0) on the halo patch, zero outside the image
     // ================================================================================================
-    auto head = [&](auto NPXc) {
-      constexpr int NPX = decltype(NPXc)::value;
-      f32x16 acc[NT][NPX];
+    auto head = [&](auto NPXc, auto EXc) {
+      constexpr int NPX = decltype(NPXc)::value;          // fragment tiles with all NT channel tiles
+      constexpr bool EX = decltype(EXc)::value;           // + channel tile `wave` of one more fragment tile (its data in slot 1)
+      constexpr int NLD = NPX + (EX ? 1 : 0);             // fragment tiles whose pixels this wave loads
+      f32x16 acc[NT][NPX], accx;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accx[e] = 0.0f;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int p = 0; p < NPX; ++p)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[j][p][e] = 0.0f;
+      const int wxoff = wave * 32 * 16;                   // EX: the unit's row block of channel tile `wave`
       static_for<0, U0>([&](auto J) {
         constexpr int j = decltype(J)::value;
         constexpr bool last = j == U0 - 1;
+        // the pixel fragments of stage j + AHEAD are issued in step j (stages 0 and 1 came with head_setup): one step (1.5 us) is
+        // not always enough for a first touch of x in HBM, two are; the two-tile variant (the first tile of a column, 1 in 32)
+        // has no registers for a third buffer and stays one stage ahead
+        constexpr int AHEAD = NPX == 2 ? 1 : 2;
+        constexpr bool ld = j + AHEAD < U0 && j + AHEAD >= 2;
         dma(j + 2, (j + 2) % RING);
-        if constexpr (!last) {
+        if constexpr (ld) {
 #pragma unroll
-          for (int p = 0; p < NPX; ++p) {
-            X[(j + 1) & 1][p][0] = buf_load(xs, hv[p], (j + 1) * 64);
-            X[(j + 1) & 1][p][1] = buf_load(xs, hv[p], (j + 1) * 64 + 32);
+          for (int p = 0; p < NLD; ++p) {
+            X[(j + AHEAD) % 3][p][0] = buf_load(xs, hv[p], (j + AHEAD) * 64);
+            X[(j + AHEAD) % 3][p][1] = buf_load(xs, hv[p], (j + AHEAD) * 64 + 32);
           }
         }
         read_w(Fw1, j % RING, 1);
+        f32x4 Fx0, Fx1;
+        if constexpr (EX) {
+          Fx0 = *reinterpret_cast<const f32x4*>(ring + (j % RING) * UNIT + wxoff + woff0);
+          Fx1 = *reinterpret_cast<const f32x4*>(ring + (j % RING) * UNIT + wxoff + woff1);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-            for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw0[jt][e], X[j & 1][p][0][e], acc[jt][p]);
+            for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw0[jt][e], X[j % 3][p][0][e], acc[jt][p]);
+        if constexpr (EX) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accx = RB_MFMA(Fx0[e], X[j % 3][NPX][0][e], accx);
+        }
         // every memory instruction behind an MFMA that covers its issue slot (mask 0x8 MFMA, 0x20 VMEM read, 0x100 DS read)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (!last) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NPX, 0);
+        if constexpr (ld) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NLD, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX - 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + (EX ? 2 : 0), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX + (EX ? 4 : 0) - 2, 0);
         read_w(FwN, (j + 1) % RING, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-            for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw1[jt][e], X[j & 1][p][1][e], acc[jt][p]);
+            for (int p = 0; p < NPX; ++p) acc[jt][p] = RB_MFMA(Fw1[jt][e], X[j % 3][p][1][e], acc[jt][p]);
+        if constexpr (EX) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accx = RB_MFMA(Fx1[e], X[j % 3][NPX][1][e], accx);
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX - 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NPX + (EX ? 4 : 0) - 1, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
@@ -265,16 +314,34 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = hvalid[p] ? fmaxf(acc[jt][p][4 * q + e] + bv[e], 0.0f) : 0.0f;
-                if (hpp[p] < PP)
+                if (hin[p])
                   *reinterpret_cast<f32x4*>(patch + (2 * jt + (q >> 1)) * (PP * 16) + hpp[p] * 16 + (((2 * (q & 1) + h) ^ sw) << 2)) = v;
               }
           }
+          if constexpr (EX) {
+            const int sw = (hpp[NPX] >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + 32 * wave + 8 * q + 4 * h);
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = hvalid[NPX] ? fmaxf(accx[4 * q + e] + bv[e], 0.0f) : 0.0f;
+              if (hin[NPX])
+                *reinterpret_cast<f32x4*>(patch + (2 * wave + (q >> 1)) * (PP * 16) + hpp[NPX] * 16 + (((2 * (q & 1) + h) ^ sw) << 2)) = v;
+            }
+          }
         }
-        sync(VM0{});
+        if constexpr (ld && AHEAD == 2) sync(std::integral_constant<int, 2 * NLD>{});   // stage j + 2's fragments stay in flight across the barrier
+        else sync(VM0{});
       });
     };
-    if (two) head(std::integral_constant<int, 2>{});
-    else head(std::integral_constant<int, 1>{});
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    if (!two) head(I1{}, No{});
+    else if (inc_now) head(I1{}, Yes{});
+    else head(I2{}, No{});
 
     // ================================================================================================
     // 3x3: wave w = tile row w, lane = pixel, registers = the c/2 output channels
@@ -284,9 +351,11 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
-    const int bpp = wave * PW + l31;
+    int bpp[3];                                // tap row dy of tile row `wave`: image row y0 - 1 + wave + dy, patch row (y0 + wave + dy) % PH
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) bpp[dy] = ((y0 + wave + dy) % PH) * PW + l31;
     auto px_off = [&](int tap, int g) {
-      const int p = bpp + (tap / 3) * PW + (tap % 3);
+      const int p = bpp[tap / 3] + (tap % 3);
       return p * 16 + ((((2 * g + h) ^ ((p >> 2) & 3))) << 2);
     };
     f32x4 Fp0 = *reinterpret_cast<const f32x4*>(patch + px_off(0, 0));
