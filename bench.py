@@ -615,7 +615,9 @@ def main():
             enc_pmc, enc_src, enc_stale = {}, None, None
             for f in sorted((ROOT / "profiles").glob("*_encode_pmc_summary.json"), reverse=True):
                 enc_pmc, enc_src = json.loads(f.read_text()), f"profiles/{f.name}"
-                enc_stale = enc_pmc.get("_meta", {}).get("gather_gemm_sha16") != cur_sha
+                rb_sha = hashlib.sha256((ROOT / "shallow-ntc_amd/csrc/rb_fused.hip").read_bytes()).hexdigest()[:16]
+                meta = enc_pmc.get("_meta", {})
+                enc_stale = meta.get("gather_gemm_sha16") != cur_sha or meta.get("rb_fused_sha16") != rb_sha
                 break
 
             def counters(n):

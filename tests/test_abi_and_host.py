@@ -4,6 +4,7 @@ refuses to run without a GPU instead of falling back."""
 import json
 import math
 import re
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -222,3 +223,11 @@ def test_bf16x3_layer_rule_is_a_function_of_layer_and_image_geometry():
     assert st("conv", 192, 96, capi.EPI_STORE) and st("convT", 320, 24, capi.EPI_ADD)
     assert not st("conv", 3, 192, capi.EPI_STORE) and not st("convT", 320, 3, capi.EPI_STORE)      # Cin % 16, Cout % 4
     assert not st("conv", 192, 192, capi.EPI_RES_DIV)                                               # GDN epilogues stay fp32
+
+
+def test_parity_prose_is_rendered_from_the_committed_reports():
+    """No hand-typed parity number in DESIGN.md / README.md: their parity tables and sentence are what tools/parity_tables.py
+    renders from profiles/*_e2e_parity*.json (the reports the -m gpu parity tests write on the MI355X)."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "parity_tables.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

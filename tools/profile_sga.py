@@ -28,12 +28,13 @@ model = Model(device=dev, **cfg)
 x = (torch.rand((args.batch, *args.hw, 3), device=dev) - 0.5).contiguous()
 model.initialize_itinf(x)
 for _ in range(3):
-    model.itinf_train_step(x, seed=1)
+    model.itinf_train_step(x, seed=1, fetch=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(args.steps):
-    model.itinf_train_step(x, seed=1)
+    model.itinf_train_step(x, seed=1, fetch=False)        # as the loop driver runs it: no host synchronisation per step
 torch.cuda.synchronize()
+model.itinf_last_metrics()
 dt = (time.perf_counter() - t0) / args.steps
 print(f"SGA step: {dt * 1e3:.3f} ms  ({args.batch} x {args.hw[0]}x{args.hw[1]}) -> 3000 steps = {3000 * dt:.1f} s")
 ops.PROFILE = []
