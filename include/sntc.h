@@ -159,11 +159,15 @@ int sntc_conv_forward_fused(const sntc_conv_plan* first, const sntc_conv_plan* s
  * batch size and any number of workgroups.
  *   w0 [1,1,c,c/2], w1 [3,3,c/2,c/2], w2 [1,1,c/2,c]: the Keras HWIO kernels (device pointers); b0, b1, b2: biases or NULL.
  * sntc_resblock_supported(c): 1 where the kernel exists (c = 192), else 0 -- callers then run the three layers.
- * x and y must not alias (tiles read their neighbours' halo); n*h*w*c*4 < 2 GiB per call. */
+ * x and y must not alias (tiles read their neighbours' halo); n*h*w*c*4 < 2 GiB per call.
+ * precision 0: exact fp32 (the above).  precision 1: the same kernel structure in bf16 x 3 split precision (three bfloat16
+ * terms per fp32 operand, six cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights pre-split at plan creation,
+ * pixels split in registers; x and y stay fp32 NHWC): fp32-level accuracy against float64, NOT bit-identical to precision 0 --
+ * what Model(precision="bf16x3") runs, batch-invariant like everything else. */
 typedef struct sntc_resblock_plan sntc_resblock_plan;
 int sntc_resblock_supported(int c);
 int sntc_resblock_plan_create(int c, const float* w0, const float* b0, const float* w1, const float* b1,
-                              const float* w2, const float* b2, void* stream, sntc_resblock_plan** plan);
+                              const float* w2, const float* b2, int precision, void* stream, sntc_resblock_plan** plan);
 int sntc_resblock_plan_update(sntc_resblock_plan* plan, const float* w0, const float* b0, const float* w1, const float* b1,
                               const float* w2, const float* b2, void* stream);
 void sntc_resblock_plan_destroy(sntc_resblock_plan* plan);

@@ -57,7 +57,7 @@ SIGNATURES = {
     "sntc_conv_fused_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_conv_forward_fused": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "sntc_resblock_supported": (C.c_int, [C.c_int]),
-    "sntc_resblock_plan_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
+    "sntc_resblock_plan_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, C.POINTER(_P)]),
     "sntc_resblock_plan_update": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sntc_resblock_plan_destroy": (None, [_P]),
     "sntc_resblock_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),

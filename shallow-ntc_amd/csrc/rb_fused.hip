@@ -25,64 +25,12 @@
 #include <type_traits>
 #include "sntc_internal.h"
 
-namespace sntc {
+#include "rb_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+namespace sntc {
+using namespace rb;
 
 namespace {
-
-constexpr unsigned kOOB = 0x80000000u;   // beyond any buffer (< 2 GiB, host check): loads give zeros, stores are dropped
-
-template <int C>
-struct RBCfg {
-  static constexpr int CH = C / 2;             // hidden channels
-  static constexpr int NT = CH / 32;           // 32-channel tiles of the hidden width
-  static constexpr int SL = CH / 16;           // 16-channel slabs of the hidden width
-  static constexpr int TH = 8, TW = 32;        // output tile: rows (= waves) x pixels (= one MFMA fragment)
-  static constexpr int PW = TW + 2, PH = TH + 2, PP = PW * PH;   // halo patch
-  static constexpr int NPT = (PP + 31) / 32;   // 32-pixel tiles of the patch the head computes
-  static constexpr int UNIT = CH * 16;         // floats per ring unit
-  static constexpr int U0 = C / 16;            // head units: K stages of the c -> c/2 contraction
-  static constexpr int U1 = SL * 9;            // 3x3 units: (slab, tap)
-  static constexpr int U2 = (C / 32) * 2;      // tail units: (32-channel output tile, half of K = c/2)
-  static constexpr int UT = U0 + U1 + U2;
-  static constexpr int RING = 3;
-  static constexpr int PATCH = SL * PP * 16;   // floats
-  static constexpr int BIAS = CH + CH + C;     // floats: b0 | b1 | b2
-  static constexpr size_t LDS = (size_t)(PATCH + RING * UNIT + BIAS) * 4;
-  static_assert(UT % RING == 0 && U0 % RING == 0 && (U0 + U1) % RING == 0, "ring slots are compile-time per step");
-  static_assert((UNIT * 4) % 1024 == 0, "a unit is a whole number of 1-KB LDS-DMA pieces (64 lanes x 16 B)");
-  static_assert(NPT > 8 && NPT <= 16, "head: every wave one patch tile, the first NPT - 8 waves two");
-};
-
-struct RBArgs {
-  const float* x;
-  float* y;
-  const float* wpack;      // [UT][CH][16] ring units, LDS image order (swizzled)
-  const float* bias;       // [CH + CH + C]: b0 | b1 | b2 (zeros where a layer has none)
-  unsigned bytes;          // size of x and of y
-  int N, H, W;
-  int tiles_x, tiles_y, ntiles;
-};
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
-  return __builtin_bit_cast(f32x4, v);
-}
-
-__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rsrc, f32x4 v, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
-}
 
 #define RB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -528,7 +476,9 @@ int rb_init(int* num_cus) {
 
 struct sntc_resblock_plan {
   int c = 0;
+  int precision = 0;          // 0: exact fp32 (rb_fused.hip); 1: bf16 x 3 split precision (rb_fused_bf3.hip)
   float* wpack = nullptr;
+  void* wpack3 = nullptr;     // the pre-split weight stream (precision 1 only)
   float* bias = nullptr;
   int max_workgroups = 0;     // 0: one per CU
 };
@@ -542,29 +492,39 @@ static int rb_pack(sntc_resblock_plan* p, const float* w0, const float* b0, cons
   hipLaunchKernelGGL(rb_bias_kernel, dim3((K::BIAS + 255) / 256), dim3(256), 0, s, b0, b1, b2, p->bias, K::CH, 192);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "ResidualBlock weight packing");
+  if (p->wpack3) return rb3_pack(w0, w1, w2, p->wpack3, s);
   return SNTC_OK;
 }
 
 extern "C" int sntc_resblock_supported(int c) { return c == 192 ? 1 : 0; }
 
+static void rb_free(sntc_resblock_plan* p) {
+  if (p->wpack) (void)hipFree(p->wpack);
+  if (p->wpack3) (void)hipFree(p->wpack3);
+  if (p->bias) (void)hipFree(p->bias);
+  delete p;
+}
+
 extern "C" int sntc_resblock_plan_create(int c, const float* w0, const float* b0, const float* w1, const float* b1,
-                                         const float* w2, const float* b2, void* stream, sntc_resblock_plan** plan) {
+                                         const float* w2, const float* b2, int precision, void* stream, sntc_resblock_plan** plan) {
   if (!plan || !w0 || !w1 || !w2) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_plan_create: null argument");
   if (!sntc_resblock_supported(c)) return fail(SNTC_ERR_UNSUPPORTED, "sntc_resblock_plan_create: fused ResidualBlock exists for c = 192");
+  if (precision != 0 && precision != 1) return fail(SNTC_ERR_UNSUPPORTED, "sntc_resblock_plan_create: precision 0 (fp32) or 1 (bf16 x 3)");
   int cus = 0;
   if (int rc = rb_init(&cus)) return rc;
+  if (precision == 1)
+    if (int rc = rb3_init()) return rc;
   using K = RBCfg<192>;
   auto* p = new sntc_resblock_plan();
   p->c = c;
-  if (hipMalloc(&p->wpack, sizeof(float) * K::UT * K::UNIT) != hipSuccess || hipMalloc(&p->bias, sizeof(float) * K::BIAS) != hipSuccess) {
-    if (p->wpack) (void)hipFree(p->wpack);
-    delete p;
+  p->precision = precision;
+  if (hipMalloc(&p->wpack, sizeof(float) * K::UT * K::UNIT) != hipSuccess || hipMalloc(&p->bias, sizeof(float) * K::BIAS) != hipSuccess ||
+      (precision == 1 && hipMalloc(&p->wpack3, rb3_pack_bytes()) != hipSuccess)) {
+    rb_free(p);
     return fail(SNTC_ERR_HIP, "sntc_resblock_plan_create: out of device memory");
   }
   if (int rc = rb_pack(p, w0, b0, w1, b1, w2, b2, (hipStream_t)stream)) {
-    (void)hipFree(p->wpack);
-    (void)hipFree(p->bias);
-    delete p;
+    rb_free(p);
     return rc;
   }
   *plan = p;
@@ -578,10 +538,7 @@ extern "C" int sntc_resblock_plan_update(sntc_resblock_plan* p, const float* w0,
 }
 
 extern "C" void sntc_resblock_plan_destroy(sntc_resblock_plan* p) {
-  if (!p) return;
-  if (p->wpack) (void)hipFree(p->wpack);
-  if (p->bias) (void)hipFree(p->bias);
-  delete p;
+  if (p) rb_free(p);
 }
 
 extern "C" int sntc_resblock_plan_set_workgroups(sntc_resblock_plan* p, int max_workgroups) {
@@ -616,6 +573,10 @@ extern "C" int sntc_resblock_forward(const sntc_resblock_plan* p, const float* x
   if (nt >= (1LL << 31)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_resblock_forward: too many tiles");
   a.ntiles = (int)nt;
   int grid = std::min<int64_t>(nt, p->max_workgroups > 0 ? p->max_workgroups : cus);
+  if (p->precision == 1) {
+    a.wpack = reinterpret_cast<const float*>(p->wpack3);
+    return rb3_launch(a, grid, (hipStream_t)stream);
+  }
   hipLaunchKernelGGL(rb_kernel<192>, dim3(grid), dim3(512), K::LDS, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "ResidualBlock launch");

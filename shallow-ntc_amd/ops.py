@@ -134,15 +134,20 @@ class ResBlockPlan:
     def supported(c):
         return bool(capi.load().sntc_resblock_supported(int(c)))
 
-    def __init__(self, w0, b0, w1, b1, w2, b2):
+    def __init__(self, w0, b0, w1, b1, w2, b2, precision="fp32"):
+        """``precision`` "bf16x3": the split-precision instantiation (csrc/rb_fused_bf3.hip) -- fp32-level accuracy, not
+        bit-identical to "fp32"; fp32 tensors in and out either way."""
         capi.require_gpu()
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision {precision!r}")
+        self.precision = precision
         self.c = int(w0.shape[2])
         if tuple(w0.shape) != (1, 1, self.c, self.c // 2) or tuple(w1.shape) != (3, 3, self.c // 2, self.c // 2) \
                 or tuple(w2.shape) != (1, 1, self.c // 2, self.c):
             raise ValueError(f"ResidualBlock kernels {tuple(w0.shape)}, {tuple(w1.shape)}, {tuple(w2.shape)} do not form a block")
         ts = [None if t is None else t.contiguous() for t in (w0, b0, w1, b1, w2, b2)]
         self._h = C.c_void_p()
-        capi.call("sntc_resblock_plan_create", self.c, *[_ptr(t) for t in ts], _stream(), C.byref(self._h))
+        capi.call("sntc_resblock_plan_create", self.c, *[_ptr(t) for t in ts], int(precision == "bf16x3"), _stream(), C.byref(self._h))
         torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
 
     def __del__(self):
@@ -182,7 +187,8 @@ class ResBlockPlan:
         capi.call("sntc_resblock_forward", self._h, _ptr(x), n, h, w, _ptr(y), _stream())
         if prof is not None:
             e1.record()
-            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=0, nblocks=0, vec=True, kind="resblock", k=3, s=1,
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=0, nblocks=0, vec=True,
+                             kind="resblock" if self.precision == "fp32" else "resblock3", k=3, s=1,
                              cin=self.c, cout=self.c, n=n, h=h, w=w))
         return y
 

@@ -246,3 +246,34 @@ def test_split_precision_analysis_does_not_depend_on_the_batch(dev):
     p4 = model.decode(z4, s4, (256, 384))
     p1 = model.decode(z1, s1, (256, 384))
     assert torch.equal(p4[2:3], p1)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 8, 32), (2, 13, 45), (1, 64, 96), (3, 37, 100), (2, 40, 33)])
+def test_whole_residual_block_in_split_precision(n, h, w, dev):
+    """sntc_resblock_forward with precision 1 (csrc/rb_fused_bf3.hip; reference common/elic.py:41-68): the whole c = 192 block in
+    bf16 x 3 on pre-split weights, pixels split in registers -- fp32-level accuracy against the float64 oracle (within 4x the exact
+    fp32 block's own error), the same bits for any number of persistent workgroups and for an image alone or inside a batch."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(77 * n + h + w)
+    c = 192
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    mk = lambda scale, *shape: (rng.standard_normal(shape) * scale).astype(np.float32)
+    w0, b0 = mk(0.08, 1, 1, c, c // 2), mk(1.0, c // 2)
+    w1, b1 = mk(0.05, 3, 3, c // 2, c // 2), mk(1.0, c // 2)
+    w2, b2 = mk(0.1, 1, 1, c // 2, c), mk(1.0, c)
+    t = np.maximum(O.conv2d(x.astype(np.float64), w0, b0, 1), 0.0)
+    t = np.maximum(O.conv2d(t, w1, b1, 1), 0.0)
+    ref = x + O.conv2d(t, w2, b2, 1)
+    args = [dev_t(a, dev) for a in (w0, b0, w1, b1, w2, b2)]
+    xd = dev_t(x, dev)
+    exact = ops.ResBlockPlan(*args)
+    split = ops.ResBlockPlan(*args, precision="bf16x3")
+    e32 = rel_err(exact(xd).cpu().numpy(), ref)
+    y = split(xd)
+    e3 = rel_err(y.cpu().numpy(), ref)
+    assert e3 < 5e-6 and e3 < 4 * e32 + 2e-7, (e3, e32)
+    for wg in (1, 3, 200):
+        split.set_workgroups(wg)
+        assert torch.equal(split(xd), y), wg
+    split.set_workgroups(0)
+    assert torch.equal(split(xd[:1].contiguous()), y[:1])

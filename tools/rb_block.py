@@ -40,19 +40,22 @@ def main():
     lb = ops.ConvPlan("conv", w1, b1, 1, "relu")
     lc = ops.ConvPlan("conv", w2, b2, 1, None, capi.PRO_NONE, capi.EPI_ADD)
     block = ops.ResBlockPlan(w0, b0, w1, b1, w2, b2)
+    split = ops.ResBlockPlan(w0, b0, w1, b1, w2, b2, precision="bf16x3")
     for n, h, w in shapes:
         x = mk(1.0, n, h, w, c)
         three = lambda: lb.fused(lc, la(x), res=x) if lb.fusable_with(lc) else lc(lb(la(x)), res=x)
         one = lambda: block(x)
         same = torch.equal(one(), three())
         gf = block.flops(n, h, w) / 1e9
-        t3, t1 = [], []
+        t3, t1, ts = [], [], []
         for _ in range(5):
             t3.append(burst(three))
             t1.append(burst(one))
-        m3, m1 = float(np.median(t3)), float(np.median(t1))
+            ts.append(burst(lambda: split(x)))
+        m3, m1, ms = float(np.median(t3)), float(np.median(t1)), float(np.median(ts))
         print(f"{n:3d}x{h}x{w}: layers {m3:.4f} ms {gf / m3:.1f} TF | block {m1:.4f} ms {gf / m1:.1f} TF (min {min(t1):.4f}) | "
-              f"x{m3 / m1:.3f} | bit-identical {same} | tiles {ops.ResBlockPlan.tiles(n, h, w)}", flush=True)
+              f"x{m3 / m1:.3f} | bit-identical {same} | bf16x3 block {ms:.4f} ms {gf / ms:.1f} TF-eq x{m1 / ms:.2f} | "
+              f"tiles {ops.ResBlockPlan.tiles(n, h, w)}", flush=True)
 
 
 if __name__ == "__main__":
