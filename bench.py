@@ -575,6 +575,8 @@ def main():
                     name = f"bf3_kernel<4, 2, 2, {4 if e['variant'] == 11 else 2}>"
                 if e["kind"] == "resblock":                                 # the whole ResidualBlock in one launch (csrc/rb_fused.hip)
                     name = f"rb_kernel<{e['cin']}>"
+                if e["kind"] == "resblock3":                                # ... in bf16 x 3 (csrc/rb_fused_bf3.hip)
+                    name = f"rb3_kernel<{e['cin']}>"
                 k = per_kernel.setdefault(name, dict(ms=0.0, flops=0, launches=0))
                 k["ms"] += e["e0"].elapsed_time(e["e1"])
                 k["flops"] += e["flops"]

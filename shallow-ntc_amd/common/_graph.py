@@ -113,8 +113,8 @@ class Conv:
 
 
 def set_precision(node, precision):
-    """Mark every convolution under ``node`` (before it is built) with the arithmetic it should prefer."""
-    if isinstance(node, Conv):
+    """Mark every convolution and ResidualBlock under ``node`` (before it is built) with the arithmetic it should prefer."""
+    if isinstance(node, (Conv, ResidualBlock, SimpleAttention)):
         node.precision = precision
     for child in getattr(node, "layers", ()) or ():
         set_precision(child, precision)
@@ -188,6 +188,8 @@ class Seq:
 class ResidualBlock:
     """elic.py:41-68."""
 
+    precision = "fp32"        # "bf16x3" (set_precision): the whole-block kernel in split precision where it exists (c = 192)
+
     def __init__(self, name):
         self.name = name
         self._convs = None
@@ -208,17 +210,19 @@ class ResidualBlock:
             c = l.build(w, c)
         # the whole block as one launch (csrc/rb_fused.hip), bit-identical to the three layers below
         self._block = None
-        if (ops.FUSE_RESIDUAL_BLOCK or self._convs[0].precision != "fp32") and ops.ResBlockPlan.supported(cin):
+        if (ops.FUSE_RESIDUAL_BLOCK or self.precision != "fp32") and ops.ResBlockPlan.supported(cin):
             n = self.name
             self._block = ops.ResBlockPlan(w[f"{n}/conv0/kernel"], w.get(f"{n}/conv0/bias"), w[f"{n}/conv1/kernel"],
-                                           w.get(f"{n}/conv1/bias"), w[f"{n}/conv2/kernel"], w.get(f"{n}/conv2/bias"))
+                                           w.get(f"{n}/conv1/bias"), w[f"{n}/conv2/kernel"], w.get(f"{n}/conv2/bias"),
+                                           precision=self.precision)
         return cin
 
     def __call__(self, x):
         a, b, c = self._convs
-        if a.precision != "fp32":
+        if self.precision != "fp32":
             # split-precision model: which arithmetic a layer takes may depend on the layer and on ONE image's geometry, never on
-            # the batch (DualPlan).  c = 192: always the exact fp32 block; other widths: the three layers, each by DualPlan's rule
+            # the batch (DualPlan).  c = 192: ALWAYS the split-precision block (csrc/rb_fused_bf3.hip), whatever the launch size;
+            # other widths: the three fp32 layers (bit-identical for any batch)
             if self._block is not None and x.dtype == torch.float32:
                 return self._block(x)
             return c(b(a(x)), res=x)
@@ -253,8 +257,12 @@ class SimpleAttention:
         t, b, g = self._mk(cin)
         return Seq(t + b + [g]).shapes(cin)
 
+    precision = "fp32"
+
     def build(self, w, cin):
         self._trunk, self._branch, self._gate = self._mk(cin)
+        for l in self._trunk + self._branch:
+            l.precision = self.precision
         for l in self._trunk + self._branch + [self._gate]:
             l.build(w, cin)
         return cin

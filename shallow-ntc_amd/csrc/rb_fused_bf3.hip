@@ -219,6 +219,11 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
         for (int p = 0; p < NPX; ++p)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[j][p][e] = 0.0f;
+      // the split of a stage's pixel fragments (~65 vector instructions per fragment tile) runs a step ahead, between the previous
+      // stage's MFMAs: a stage that begins with its own split leaves the matrix pipe idle for the ~300 cycles the chain takes
+      S3 xs3[NLD];
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) xs3[p] = split8(X[0][p][0], X[0][p][1]);
       static_for<0, U0>([&](auto J) {
         constexpr int j = decltype(J)::value;
         constexpr bool last = j == U0 - 1;
@@ -237,16 +242,31 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
         bf16x8 Fx[3];
         if constexpr (EX) read_w1(Fx, j % RING, wave);
 #pragma unroll
-        for (int p = 0; p < NPX; ++p) {
-          const S3 xp = split8(X[j % 3][p][0], X[j % 3][p][1]);
+        for (int p = 0; p < NPX; ++p)
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) acc[jt][p] = mac6(Wc.w[jt], xp, acc[jt][p]);
+          for (int jt = 0; jt < NT; ++jt) acc[jt][p] = mac6(Wc.w[jt], xs3[p], acc[jt][p]);
+        if constexpr (EX) accx = mac6(Fx, xs3[NPX], accx);
+        S3 xn3[NLD];
+        if constexpr (!last) {
+#pragma unroll
+          for (int p = 0; p < NLD; ++p) xn3[p] = split8(X[(j + 1) % 3][p][0], X[(j + 1) % 3][p][1]);
         }
-        if constexpr (EX) {
-          const S3 xp = split8(X[j % 3][NPX][0], X[j % 3][NPX][1]);
-          accx = mac6(Fx, xp, accx);
+        // the fragment reads behind the first MFMA, then the next stage's split dealt between the MFMAs (mask 0x8 MFMA, 0x100 DS
+        // read, 0x2 VALU)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NT + (EX ? 3 : 0), 0);
+        if constexpr (!last) {
+#pragma unroll
+          for (int q = 0; q < 6 * NT * NPX + (EX ? 6 : 0) - 1; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (72 * NLD + 6 * NT * NPX) / (6 * NT * NPX), 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!last) {
+#pragma unroll
+          for (int p = 0; p < NLD; ++p) xs3[p] = xn3[p];
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p) Wc.w[0][p] = Wn0[p];
         if constexpr (last) {
@@ -305,8 +325,7 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
       const int p = bpp[tap / 3] + (tap % 3);
       return p * 16 + ((((2 * h + half) ^ ((p >> 2) & 3))) << 2);
     };
-    f32x4 P0 = *reinterpret_cast<const f32x4*>(patch + px_off(0, 0));
-    f32x4 P1 = *reinterpret_cast<const f32x4*>(patch + px_off(0, 1));
+    S3 xc3 = split8(*reinterpret_cast<const f32x4*>(patch + px_off(0, 0)), *reinterpret_cast<const f32x4*>(patch + px_off(0, 1)));
 #pragma unroll 1
     for (int cc = 0; cc < SL; ++cc) {
       const float* pslab = patch + cc * (PP * 16);
@@ -324,14 +343,20 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
           N0 = *reinterpret_cast<const f32x4*>(nslab + px_off(0, 0));
           N1 = *reinterpret_cast<const f32x4*>(nslab + px_off(0, 1));
         }
-        const S3 xp = split8(P0, P1);
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) acc[jt] = mac6(Wc.w[jt], xp, acc[jt]);
+        for (int jt = 0; jt < NT; ++jt) acc[jt] = mac6(Wc.w[jt], xc3, acc[jt]);
+        const S3 xn3 = split8(N0, N1);           // the next tap's split, between this tap's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NT + 2, 0);
+#pragma unroll
+        for (int q = 0; q < 6 * NT - 1; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 3; ++p) Wc.w[0][p] = Wn0[p];
-        P0 = N0;
-        P1 = N1;
+        xc3 = xn3;
         sync(VM0{});
       });
     }
