@@ -41,14 +41,29 @@ __device__ __forceinline__ void split1(float x, __bf16* hi, __bf16* mid, __bf16*
   *hi = hh; *mid = mm; *lo = (__bf16)r2;
 }
 
+// Eight fp32 values -> three planes of eight bfloat16, by TRUNCATION: hi = the top 16 bits of x, mid = the top 16 bits of
+// x - hi, lo = the top 16 bits of x - hi - mid.  Every term takes the 8 leading significant bits of what is left, so
+// hi + mid + lo == x exactly (24 significant bits), as with the round-to-nearest split of the weights; per pair of values:
+// 2 AND, 2 SUB, 2 AND, 2 SUB and three byte permutes that put the two values' upper halves side by side -- 44 plain vector
+// instructions per fragment (the cast-based form compiled to ~65, among them v_pk_add_f32, which is expensive next to MFMAs).
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ S3 split8(const f32x4 a, const f32x4 b) {
+  u32x4v P[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = q < 2 ? a[2 * q] : b[2 * q - 4], x1 = q < 2 ? a[2 * q + 1] : b[2 * q - 3];
+    const unsigned h0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u, h1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+    const float r0 = x0 - __builtin_bit_cast(float, h0), r1 = x1 - __builtin_bit_cast(float, h1);
+    const unsigned m0 = __builtin_bit_cast(unsigned, r0) & 0xffff0000u, m1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float s0 = r0 - __builtin_bit_cast(float, m0), s1 = r1 - __builtin_bit_cast(float, m1);
+    // v_perm_b32: bytes 0-3 of the selector's value space are the SECOND operand, 4-7 the first: [x1.hi16 : x0.hi16]
+    P[0][q] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    P[1][q] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    P[2][q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+  }
   S3 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 x0, x1, x2;
-    split1(e < 4 ? a[e] : b[e - 4], &x0, &x1, &x2);
-    o.p[0][e] = x0; o.p[1][e] = x1; o.p[2][e] = x2;
-  }
+  for (int p = 0; p < 3; ++p) o.p[p] = __builtin_bit_cast(bf16x8, P[p]);
   return o;
 }
 
@@ -63,6 +78,29 @@ __device__ __forceinline__ f32x16 mac6(const bf16x8 (&w)[3], const S3& x, f32x16
   acc = RB3_MFMA(w[0], x.p[1], acc);             // hi * mid
   acc = RB3_MFMA(w[0], x.p[0], acc);             // hi * hi
   return acc;
+}
+
+// term t (0 .. 5, smallest first) of acc += W * X
+__device__ __forceinline__ f32x16 mac1(const bf16x8 (&w)[3], const S3& x, f32x16 acc, int t) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  return RB3_MFMA(w[PA[t]], x.p[PB[t]], acc);
+}
+
+// three accumulators (the three channel tiles of one pixel fragment), their chains INTERLEAVED: row tile 0's fragments are in
+// registers when the step begins, tiles 1 and 2 arrive from LDS under its first three MFMAs; after that no MFMA follows one on
+// the same accumulator directly
+__device__ __forceinline__ void mac6x3(const bf16x8 (&w0)[3], const bf16x8 (&w1)[3], const bf16x8 (&w2)[3], const S3& x, f32x16& a0,
+                                       f32x16& a1, f32x16& a2) {
+  a0 = mac1(w0, x, a0, 0);
+  a0 = mac1(w0, x, a0, 1);
+  a0 = mac1(w0, x, a0, 2);
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    a1 = mac1(w1, x, a1, t);
+    a2 = mac1(w2, x, a2, t);
+    if (t < 3) a0 = mac1(w0, x, a0, t + 3);
+  }
 }
 
 template <int C>
@@ -199,9 +237,18 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
   };
   head_setup(t_lo);
 
+#ifdef SNTC_DIAG
+  // make DIAG=1: cycles per phase (s_memtime around head / 3x3 / tail, summed over the workgroup's tiles) overwrite the first
+  // floats of y at the end of the launch -- tools/rb_phases.py reads them; results are meaningless in such a build
+  unsigned long long tph[4] = {0, 0, 0, 0};
+#define RB3_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define RB3_STAMP(v)
+#endif
   for (int tile = t_lo; tile < t_hi; ++tile) {
     bool inc_now;
     coords(tile, &n, &y0, &x0, &inc_now);
+    RB3_STAMP(ts0);
 
     // ================================================================================================
     // head
@@ -242,9 +289,7 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
         bf16x8 Fx[3];
         if constexpr (EX) read_w1(Fx, j % RING, wave);
 #pragma unroll
-        for (int p = 0; p < NPX; ++p)
-#pragma unroll
-          for (int jt = 0; jt < NT; ++jt) acc[jt][p] = mac6(Wc.w[jt], xs3[p], acc[jt][p]);
+        for (int p = 0; p < NPX; ++p) mac6x3(Wc.w[0], Wc.w[1], Wc.w[2], xs3[p], acc[0][p], acc[1][p], acc[2][p]);
         if constexpr (EX) accx = mac6(Fx, xs3[NPX], accx);
         S3 xn3[NLD];
         if constexpr (!last) {
@@ -313,6 +358,7 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
     // ================================================================================================
     // 3x3
     // ================================================================================================
+    RB3_STAMP(ts1);
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -343,8 +389,8 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
           N0 = *reinterpret_cast<const f32x4*>(nslab + px_off(0, 0));
           N1 = *reinterpret_cast<const f32x4*>(nslab + px_off(0, 1));
         }
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) acc[jt] = mac6(Wc.w[jt], xc3, acc[jt]);
+        static_assert(NT == 3, "mac6x3");
+        mac6x3(Wc.w[0], Wc.w[1], Wc.w[2], xc3, acc[0], acc[1], acc[2]);
         const S3 xn3 = split8(N0, N1);           // the next tap's split, between this tap's MFMAs
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * NT + 2, 0);
@@ -364,6 +410,7 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
     // ================================================================================================
     // tail: the accumulators, converted once, are the B operand: k-step s of channel tile jt = registers 8 s .. 8 s + 7
     // ================================================================================================
+    RB3_STAMP(ts2);
     S3 Bop[2 * NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -394,10 +441,6 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
         }
-        if constexpr (u == UT - 1) {
-          if (tile + 1 < t_hi) head_setup(tile + 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
         read_rest(Wc, u % RING);
         read_w1(Wn0, (u + 1) % RING, 0);
         // the unit's three row tiles are the k-steps NT * half + (0 .. NT - 1) of this 32-channel output tile
@@ -416,14 +459,36 @@ __global__ void __launch_bounds__(512, 2) rb3_kernel(const RBArgs a) {
             v = (v + bv) + R[q];
             buf_store(ys, v, poff, ot * 128 + q * 32);
           }
-          sync(VM4{});
+          if constexpr (u == UT - 1) {
+            // the next tile's first two K stages are issued LAST, so that this step's wait can leave them (and the stores) in
+            // flight: 4 stores + 4 loads per fragment tile
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + 1 < t_hi) {
+              head_setup(tile + 1);
+              if (two) sync(std::integral_constant<int, 12>{});
+              else sync(std::integral_constant<int, 8>{});
+            } else {
+              sync(VM4{});
+            }
+          } else {
+            sync(VM4{});
+          }
         } else {
-          sync(VM0{});
+          sync(VM4{});                           // the four residual loads of this output tile stay in flight: they are used a step later
         }
       });
     });
+#ifdef SNTC_DIAG
+    RB3_STAMP(ts3);
+    tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += 1;
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SNTC_DIAG
+  __syncthreads();
+  if (tid == 0)
+    for (int k = 0; k < 4; ++k) a.y[blockIdx.x * 4 + k] = (float)tph[k];
+#endif
 }
 
 // wpack3[u][plane][row][32 B]: the pre-split units in LDS image order, from the Keras kernels (rb_fused.hip's rb_pack_kernel
