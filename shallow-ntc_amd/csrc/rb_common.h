@@ -63,6 +63,37 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rsrc, f32x4 v, 
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
 }
 
+// 4 x 4 transpose of 16-B quads across the four lanes of a lane quad (lanes 4 m .. 4 m + 3), in registers (two rounds of DPP
+// quad_perm exchanges): T[j] of lane i <- T[i] of lane j.  The tail's accumulators hold, per lane = pixel, the register quad q
+// = channels 8 q + 4 h .. + 3; after the transpose lane i of a quad holds chunk 2 i + h of the FOUR pixels of its quad, so that
+// store (and residual load) j of the output tile covers whole 128-B lines of eight pixels -- eight consecutive lanes write one
+// pixel's 32 channels -- instead of 32-B pieces of 32 lines: the texture addresser, not the MFMA pipe, was timing the tail.
+__device__ __forceinline__ float rb_dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float rb_dpp_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose(f32x4 (&T)[4], int lane_in_quad) {
+  const bool o1 = (lane_in_quad & 1) != 0, o2 = (lane_in_quad & 2) != 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float got = rb_dpp_xor1(o1 ? T[2 * b][e] : T[2 * b + 1][e]);
+      T[2 * b][e] = o1 ? got : T[2 * b][e];
+      T[2 * b + 1][e] = o1 ? T[2 * b + 1][e] : got;
+    }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float got = rb_dpp_xor2(o2 ? T[q][e] : T[q + 2][e]);
+      T[q][e] = o2 ? got : T[q][e];
+      T[q + 2][e] = o2 ? T[q + 2][e] : got;
+    }
+}
+
 }  // namespace rb
 
 // bf16 x 3 instantiation (rb_fused_bf3.hip)

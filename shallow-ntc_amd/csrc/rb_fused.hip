@@ -352,8 +352,13 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[jt][4 * q + e] = fmaxf(acc[jt][4 * q + e] + bv[e], 0.0f);
       }
-    const int oy = y0 + wave, ox = x0 + l31;
-    const unsigned poff = (oy < a.H && ox < a.W) ? ((unsigned)((n * a.H + oy) * a.W + ox) * (unsigned)(C * 4) + (unsigned)h * 16u) : kOOB;
+    // output / residual addressing AFTER the quad transpose (rb_common.h): access j of an output tile is pixel 4 (l31 / 4) + j of
+    // this wave's tile row, 16-B chunk 2 (l31 % 4) + h of its 32 channels
+    const int oy = y0 + wave, ox4 = x0 + (l31 & ~3), li = l31 & 3;
+    unsigned poff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      poff[j] = (oy < a.H && ox4 + j < a.W) ? ((unsigned)((n * a.H + oy) * a.W + ox4 + j) * (unsigned)(C * 4) + (unsigned)(2 * li + h) * 16u) : kOOB;
     static_for<0, C / 32>([&](auto OT) {
       constexpr int ot = decltype(OT)::value;
       f32x4 R[4];
@@ -364,7 +369,7 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
         dma((u + 2) % UT, (u + 2) % RING);                  // wraps into the next tile's head (harmless after the last tile)
         if constexpr (half == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) R[q] = buf_load(xs, poff, ot * 128 + q * 32);
+          for (int q = 0; q < 4; ++q) R[q] = buf_load(xs, poff[q], ot * 128);
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
         }
@@ -392,13 +397,15 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) Fw0[jt] = FwN[jt];
         if constexpr (half == 1) {
+          f32x4 T[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + 2 * CH + 32 * ot + 8 * q + 4 * h);
-            f32x4 v = {acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]};
-            v = (v + bv) + R[q];
-            buf_store(ys, v, poff, ot * 128 + q * 32);
+            T[q] = f32x4{acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]} + bv;
           }
+          quad_transpose(T, li);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) buf_store(ys, T[j] + R[j], poff[j], ot * 128);
           sync(VM4{});
         } else {
           sync(VM0{});
