@@ -173,9 +173,18 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
   };
   head_setup(t_lo);
 
+#ifdef SNTC_DIAG
+  // make DIAG=1: cycles per phase (s_memtime around head / 3x3 / tail, summed over the workgroup's tiles) overwrite the first
+  // floats of y at the end of the launch -- tools/rb_phases.py reads them; results are meaningless in such a build
+  unsigned long long tph[4] = {0, 0, 0, 0};
+#define RB_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define RB_STAMP(v)
+#endif
   for (int tile = t_lo; tile < t_hi; ++tile) {
     bool inc_now;
     coords(tile, &n, &y0, &x0, &inc_now);
+    RB_STAMP(ts0);
 
     // ================================================================================================
     // head: t1 = relu(W0 x + b0) on the halo patch, zero outside the image
@@ -294,6 +303,7 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
     // ================================================================================================
     // 3x3: wave w = tile row w, lane = pixel, registers = the c/2 output channels
     // ================================================================================================
+    RB_STAMP(ts1);
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -344,6 +354,7 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
     // ================================================================================================
     // tail: y = x + W2 relu(acc + b1) + b2; the accumulators are the B operand as they stand
     // ================================================================================================
+    RB_STAMP(ts2);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -412,8 +423,17 @@ __global__ void __launch_bounds__(512, 2) rb_kernel(const RBArgs a) {
         }
       });
     });
+#ifdef SNTC_DIAG
+    RB_STAMP(ts3);
+    tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += 1;
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SNTC_DIAG
+  __syncthreads();
+  if (tid == 0)
+    for (int k = 0; k < 4; ++k) a.y[blockIdx.x * 4 + k] = (float)tph[k];
+#endif
 }
 
 // wpack[u][row][16] in the ring's LDS image order, from the Keras kernels: w0 [1,1,C,CH], w1 [3,3,CH,CH], w2 [1,1,CH,C]

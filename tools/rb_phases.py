@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cycles per phase of the split-precision ResidualBlock kernel -- needs a DIAG build (make -C shallow-ntc_amd/csrc clean && make DIAG=1):
+"""Cycles per phase of the two ResidualBlock kernels -- needs a DIAG build (make -C shallow-ntc_amd/csrc clean && make DIAG=1):
 the kernel then overwrites the first floats of its output with s_memtime sums per workgroup (csrc/rb_fused_bf3.hip)."""
 import sys
 from pathlib import Path
@@ -14,12 +14,13 @@ rng = np.random.default_rng(0)
 c = 192
 mk = lambda scale, *shape: torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32)).to(dev)
 args = [mk(0.08, 1, 1, c, c // 2), mk(1, c // 2), mk(0.05, 3, 3, c // 2, c // 2), mk(1, c // 2), mk(0.1, 1, 1, c // 2, c), mk(1, c)]
-split = ops.ResBlockPlan(*args, precision="bf16x3")
 x = mk(1.0, 18, 256, 384, c)
-for _ in range(3):
-    y = split(x)
-torch.cuda.synchronize()
-t = y.reshape(-1)[:1024].cpu().numpy().reshape(256, 4)
-per = t[:, :3] / t[:, 3:4]
-m = per.mean(0)
-print("shader cycles per tile: head %.0f (MFMA-bound 16.1 k)  3x3 %.0f (62.2 k)  tail %.0f (13.8 k)  total %.0f; tiles per workgroup %.1f" % (*m, m.sum(), t[:, 3].mean()))
+for precision, bound in (("fp32", (43.0, 165.9, 36.9)), ("bf16x3", (16.1, 62.2, 13.8))):
+    plan = ops.ResBlockPlan(*args, precision=precision)
+    for _ in range(3):
+        y = plan(x)
+    torch.cuda.synchronize()
+    t = y.reshape(-1)[:1024].cpu().numpy().reshape(256, 4)
+    m = (t[:, :3] / t[:, 3:4]).mean(0)
+    print("%s: shader cycles per tile: head %.0f (MFMA-bound %.1f k)  3x3 %.0f (%.1f k)  tail %.0f (%.1f k)  total %.0f; tiles per workgroup %.1f"
+          % (precision, m[0], bound[0], m[1], bound[1], m[2], bound[2], m.sum(), t[:, 3].mean()))
