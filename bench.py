@@ -593,7 +593,8 @@ def main():
         import hashlib
         traffic, traffic_src, traffic_stale = None, None, None
         cur_sha = hashlib.sha256((ROOT / "shallow-ntc_amd/csrc/gather_gemm.hip").read_bytes()).hexdigest()[:16]
-        for f in sorted(f for f in (ROOT / "profiles").glob("*_pmc_summary.json") if "encode" not in f.name)[::-1]:
+        import re as _re
+        for f in sorted(f for f in (ROOT / "profiles").glob("*_pmc_summary.json") if _re.fullmatch(r"r\d+_pmc_summary\.json", f.name))[::-1]:
             summ = json.loads(f.read_text())
             for kn, e in summ.items():
                 if kn != "_meta" and name in kn and "hbm_side_bytes_per_launch" in e:
