@@ -342,10 +342,21 @@ int sntc_rans_encode(const int32_t* values, const uint16_t* table_ids, int nimag
 /* gathers the streams into one payload; offsets int64 [nstreams + 1] = exclusive prefix sum of len_words */
 int sntc_rans_compact(const uint16_t* scratch, int64_t cap_words, const int32_t* len_words, const int64_t* offsets,
                       int nstreams, uint16_t* payload, void* stream);
-/* bad_streams (int32[1], device) counts streams that did not end at their initial state / length: corruption */
+/* bad_streams (int32[1], device) counts streams that did not end at their initial state / length: corruption.
+ * dec / lut / lut_meta (all three or none; NULL = the plain decoder, a binary search of cdf per symbol) are the decoder's own
+ *   view of the same tables, which it keeps in LDS:
+ *   dec      uint32, table t's entry s at dec[offset_t + 3 t + s] = (cdf[s] << 16) | (freq[s] - 1), three 0xffffffff after every
+ *            table, the array padded to a multiple of 4 entries (total_entries + 3 ntables, rounded up);
+ *   lut      per table a START TABLE of 2^bits uint16 entries, lut[lut_off + b] = the largest symbol s with
+ *            cdf[s] <= b << (16 - bits), 0 <= bits <= 16; lut_meta[t] = (lut_off << 5) | bits; lut_entries a multiple of 8 and
+ *            <= sntc_rans_lut_budget(ntables, total_entries), the room the other tables leave in a CU's LDS.
+ *   The decoded values do not depend on them; with about one start entry per symbol a step costs three LDS round trips
+ *   instead of log2(n) + 2. */
+int64_t sntc_rans_lut_budget(int ntables, int total_entries);
 int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
                      int64_t elems_per_image, int segments, int lanes, const uint16_t* cdf, const uint32_t* meta, int ntables,
-                     int total_entries, int32_t* values, int32_t* bad_streams, void* stream);
+                     int total_entries, const uint32_t* dec, const uint16_t* lut, const uint32_t* lut_meta, int lut_entries,
+                     int32_t* values, int32_t* bad_streams, void* stream);
 /* table id of every y element = round(clamp(exp(raw), 0, 63)), raw = hyper[..., c:]; of every z element = channel */
 int sntc_scale_table_ids(const float* hyper, int64_t npix, int c, uint16_t* table_ids, void* stream);
 /* table id = channel (deep-factorized prior: one table per channel). */

@@ -98,7 +98,8 @@ SIGNATURES = {
     "sntc_rans_cap_words": (C.c_int64, [C.c_int64, C.c_int]),
     "sntc_rans_encode": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
     "sntc_rans_compact": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int, _P, _P]),
-    "sntc_rans_decode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "sntc_rans_lut_budget": (C.c_int64, [C.c_int, C.c_int]),
+    "sntc_rans_decode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P]),
     "sntc_scale_table_ids": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "sntc_channel_table_ids": (C.c_int, [C.c_int64, C.c_int, _P, _P]),
     "sntc_round_to_int": (C.c_int, [_P, C.c_int64, _P, _P]),

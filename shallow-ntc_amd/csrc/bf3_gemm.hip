@@ -923,19 +923,21 @@ __global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------
-// variants + launch (ids continue csrc/gather_gemm.hip's: 11 = 256 x 256, 12 = 256 x 128; both 512 threads, one workgroup per CU)
+// variants + launch (ids continue csrc/gather_gemm.hip's: 11 = 256 x 256, 12 = 256 x 128, 13 = 256 x 192 -- the exact fit of the
+// N = 192 layers, which lose a quarter of either of the others to padding; all 512 threads, one workgroup per CU)
 // ---------------------------------------------------------------------------------------------
 static const void* bf3p_kernel(int v, bool halo) {
   switch (v) {
     case 11: return halo ? reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4, true, false>) : reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 4, false, false>);
     case 12: return halo ? reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2, true, true>) : reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 2, false, false>);
+    case 13: return halo ? reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 3, true, false>) : reinterpret_cast<const void*>(&bf3_kernel<4, 2, 2, 3, false, false>);
     default: return nullptr;
   }
 }
 
 int bf3p_variant_bm(int v) { return 256; }
-int bf3p_variant_bn(int v) { return v == 11 ? 256 : 128; }
-size_t bf3p_sk_slab_floats(int v) { return (size_t)(v == 11 ? 8 : 4) * 16 * 512; }
+int bf3p_variant_bn(int v) { return v == 11 ? 256 : v == 13 ? 192 : 128; }
+size_t bf3p_sk_slab_floats(int v) { return (size_t)(v == 11 ? 8 : v == 13 ? 6 : 4) * 16 * 512; }
 
 static size_t bf3p_lds_bytes(int v, bool halo) {
   const size_t rinfo = 2 * bf3p_variant_bm(v) * sizeof(int4);
@@ -953,7 +955,7 @@ int bf3p_init() {
   if (dev < 0 || dev >= 16) return fail(SNTC_ERR_UNSUPPORTED, "device index beyond the residency tables");
   std::call_once(g_bf3p_once[dev], [&] {
     g_bf3p_rc[dev] = SNTC_OK;
-    for (int v : {11, 12})
+    for (int v : {11, 12, 13})
       for (bool halo : {false, true}) {
         hipError_t e = hipFuncSetAttribute(bf3p_kernel(v, halo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf3p_lds_bytes(v, halo));
         if (e != hipSuccess) g_bf3p_rc[dev] = hip_fail(e, "bf3p_init");

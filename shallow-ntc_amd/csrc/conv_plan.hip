@@ -165,7 +165,7 @@ typedef sntc_conv_plan::Choice TuneChoice;
 
 extern "C" int sntc_conv_plan_set_tile(sntc_conv_plan* p, int variant) {
   if (!p) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_plan_set_tile: null plan");
-  if (variant < 0 || variant > (p->s3 ? 12 : kNumVariants) || (p->s3 && variant != 0 && variant < 11))
+  if (variant < 0 || variant > (p->s3 ? 13 : kNumVariants) || (p->s3 && variant != 0 && variant < 11))
     return fail(SNTC_ERR_UNSUPPORTED, "sntc_conv_plan_set_tile: unknown tile variant");
   p->tile = variant;
   return SNTC_OK;
@@ -595,7 +595,7 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n, const
   const int msteps = max_steps(p);
   const int cus = std::max(8, gg_num_cus());
   double best_cost = 1e300;
-  for (int v : {11, 12}) {
+  for (int v : {11, 12, 13}) {
     if (p->tile >= 11 && v != p->tile) continue;
     if (force && v != force->variant) continue;
     int64_t tiles, units;
@@ -623,7 +623,7 @@ static Sched schedule_s3(const sntc_conv_plan* p, const Geo& g, int64_t n, const
     }
     // measured on the 480 -> 640 layer, padding aside: 256 x 128 (fragments double-buffered, bookkeeping inside the MFMA shadows)
     // 225 TFLOP/s-equivalent, 256 x 256 (single fragment set: 128 accumulators leave no room for a second) 245 on its padded tile
-    cost /= (v == 11 ? 1.0 : 0.92);
+    cost /= (v == 11 ? 1.0 : v == 13 ? 0.97 : 0.92);
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
@@ -858,7 +858,7 @@ extern "C" int sntc_conv_forward(const sntc_conv_plan* p, const float* x, int n,
 // caller's buffers, for one (n, h, w), and records the winner in the plan.  Split-K factors are not candidates (they are a
 // function of the layer and the per-image geometry only, by contract).
 static void tune_candidates(const sntc_conv_plan* p, const Geo& g, int n, std::vector<std::pair<TuneChoice, Sched>>* out) {
-  const int v0 = p->s3 ? 11 : 1, v1 = p->s3 ? 12 : kNumVariants;
+  const int v0 = p->s3 ? 11 : 1, v1 = p->s3 ? 13 : kNumVariants;
   for (int v = v0; v <= v1; ++v)
     for (int sk = 1; sk >= 0; --sk) {
       TuneChoice c;

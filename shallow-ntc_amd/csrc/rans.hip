@@ -29,6 +29,22 @@ struct RansTables {
   int total;                   // entries in cdf
 };
 
+// The decoder's own view of the same tables (optional: sntc_rans_decode's dec / lut arguments, built by the host from cdf):
+//   dec  entry s of table t, at dec[off_t + 3 t + s] = (cdf[s] << 16) | (freq[s] - 1), followed by three 0xffffffff -- ONE read
+//        gives a symbol's (start, frequency), and with key = (slot << 16) | 0xfffe, "key >= entry" is "slot >= cdf[s]" for every
+//        real entry (freq - 1 <= 0xfffe: a table has >= 2 symbols) and false for the sentinels;
+//   lut  per table a START TABLE of 2^bits entries, lut[lut_off + (slot >> (16 - bits))] = the largest symbol whose cdf is <= the
+//        first slot of that bucket: the search starts there.  lmeta[t] = (lut_off << 5) | bits.
+struct RansDecTables {
+  const unsigned* dec;
+  const unsigned short* lut;
+  const uint2* meta;           // RansTables::meta
+  const unsigned* lmeta;
+  int ntables;
+  int dec_total;               // entries in dec: total + 3 * ntables, padded to a multiple of 4
+  int lut_total;               // entries in lut, padded to a multiple of 8
+};
+
 // Staging.  A wave that codes one stream has nobody to hide memory latency behind, so nothing in the coding loops
 // touches global memory for input: table ids (and values / stream words) are fetched a CHUNK of 16 steps ahead into
 // registers and dropped into LDS rings when the chunk ends; the loops read LDS only, one to two steps ahead of use.
@@ -311,6 +327,152 @@ __global__ void __launch_bounds__(64) rans_decode_kernel(const unsigned short* _
   if (__ballot(!good) && lane == 0) atomicAdd(bad, 1);
 }
 
+// The same decoder with the RansDecTables in LDS.  A lone wave per stream is bound by its chain of dependent LDS round trips and
+// by its own instruction issue (nobody to interleave with), so a step is: start symbol from the start table (1 read), four
+// consecutive entries from there (independent reads; the symbol is among the first three in > 98 % of the slots of every table,
+// else the round repeats from the fourth), refill word (1 read) -- three round trips instead of the binary search's
+// log2(n) + 2 (11 + 2 on the widest scale table, and a wave waits for its slowest lane) -- and selects instead of divergent
+// branches.  Decoded values are those of rans_decode_kernel, bit for bit (tests/test_hip_bitstream.py).
+__global__ void __launch_bounds__(64) rans_decode_fast_kernel(const unsigned short* __restrict__ payload, const long long* __restrict__ offsets,
+                                                              const unsigned short* __restrict__ tid, int segs, int L, long long E,
+                                                              long long Eseg, RansDecTables T, int* __restrict__ values,
+                                                              int* __restrict__ bad) {
+  extern __shared__ unsigned char smem[];
+  unsigned short* tring = reinterpret_cast<unsigned short*>(smem);                   // [2][kChunk * 64]
+  unsigned short* wring = tring + 2 * kChunk * 64;                                   // [kWordRing]
+  uint4* m4 = reinterpret_cast<uint4*>(smem + kStagingBytes);                        // {entry offset, n | vmin, lut offset, 16 - bits}
+  unsigned* dec = reinterpret_cast<unsigned*>(m4 + T.ntables);
+  unsigned short* lut = reinterpret_cast<unsigned short*>(dec + T.dec_total);
+  const int lane = threadIdx.x;
+  for (int i = lane; i < T.ntables; i += 64) {
+    const uint2 a = T.meta[i];
+    const unsigned lm = T.lmeta[i];
+    m4[i] = make_uint4(a.x + 3u * (unsigned)i, a.y, lm >> 5, 16u - (lm & 31u));
+  }
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(T.dec);
+    uint4* dst = reinterpret_cast<uint4*>(dec);
+    for (int i = lane; i < T.dec_total / 4; i += 64) dst[i] = src[i];
+    src = reinterpret_cast<const uint4*>(T.lut);
+    dst = reinterpret_cast<uint4*>(lut);
+    for (int i = lane; i < T.lut_total / 8; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int s = blockIdx.x;
+  const int b = s / segs, sg = s - b * segs;
+  const long long e0 = (long long)b * E + (long long)sg * Eseg;
+  const long long e1 = std::min((long long)(b + 1) * E, e0 + Eseg);
+  const long long steps = e1 > e0 ? (e1 - e0 + L - 1) / L : 0;
+  const long long nchunks = (steps + kChunk - 1) / kChunk;
+  const unsigned short* w = payload + offsets[s];
+  const long long len = offsets[s + 1] - offsets[s];
+  if (len < 2 * L) {                                         // not even the lane states: malformed
+    if (lane == 0) atomicAdd(bad, 1);
+    return;
+  }
+  unsigned x = lane < L ? (((unsigned)w[2 * lane] << 16) | w[2 * lane + 1]) : (1u << 16);
+  bool ok = true;
+
+  int ptr = 2 * L, filled = 2 * L, wfrom = 2 * L, wto = 2 * L;  // as rans_decode_kernel: the ring holds [ptr, ptr + kWordRing)
+  const int len32 = (int)len;
+  unsigned short WR[kWordRegs];
+  auto word_fetch = [&](int target) {
+    wfrom = filled;
+    wto = std::min(target, len32);
+#pragma unroll
+    for (int i = 0; i < kWordRegs; ++i) {
+      const int q = wfrom + i * 64 + lane;
+      WR[i] = q < wto ? w[q] : (unsigned short)0;
+    }
+  };
+  auto word_spill = [&]() {
+#pragma unroll
+    for (int i = 0; i < kWordRegs; ++i) {
+      const int q = wfrom + i * 64 + lane;
+      if (q < wto) wring[q & (kWordRing - 1)] = WR[i];
+    }
+    filled = std::max(filled, wto);
+  };
+  unsigned short TR[kChunk];
+  auto tid_fetch = [&](long long k) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+      const long long e = e0 + (k * kChunk + i) * L + lane;
+      TR[i] = (k < nchunks && lane < L && e < e1) ? tid[e] : kNoTable;
+    }
+  };
+  auto tid_spill = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) tring[buf * kChunk * 64 + i * 64 + lane] = TR[i];
+  };
+  word_fetch(ptr + kWordRing / 2);
+  word_spill();
+  word_fetch(ptr + kWordRing);
+  word_spill();
+  tid_fetch(0);
+  tid_spill(0);
+
+  for (long long k = 0; k < nchunks; ++k) {
+    tid_fetch(k + 1);
+    word_fetch(ptr + kWordRing);
+    const unsigned short* tb = tring + (int)(k & 1) * kChunk * 64 + lane;
+    const int cnt = (int)std::min<long long>(kChunk, steps - k * kChunk);
+    int* vout = values + e0 + k * kChunk * L + lane;
+    int t1 = tb[0];
+    uint4 m1 = m4[t1 == kNoTable ? 0 : t1];
+    int t2 = cnt > 1 ? (int)tb[64] : (int)kNoTable;
+    for (int i = 0; i < cnt; ++i) {
+      const bool active = t1 != kNoTable;
+      const uint4 m = m1;
+      t1 = t2;
+      m1 = m4[t1 == kNoTable ? 0 : t1];                      // descriptor of step i + 1
+      t2 = tb[std::min(i + 2, kChunk - 1) * 64];             // table id of step i + 2
+      if (i + 2 >= cnt) t2 = kNoTable;
+      const unsigned slot = x & 0xffffu, key = (x << 16) | 0xfffeu;
+      const unsigned* e = dec + m.x;
+      unsigned lo = lut[m.z + (slot >> m.w)];
+      unsigned esel;
+      for (;;) {
+        const unsigned c0 = e[lo], c1 = e[lo + 1], c2 = e[lo + 2], c3 = e[lo + 3];
+        asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));   // all four in registers here: issued together, none deferred into a branch
+        const bool g1 = key >= c1, g2 = key >= c2, g3 = key >= c3;
+        esel = g2 ? c2 : (g1 ? c1 : c0);
+        lo += (g1 ? 1u : 0u) + (g2 ? 1u : 0u);
+        if (!__ballot(g3)) break;                            // a lane that has its symbol finds it again: c0 = its entry, g1 false
+        lo += g3 ? 1u : 0u;
+      }
+      const unsigned xn = ((esel & 0xffffu) + 1u) * (x >> 16) + slot - (esel >> 16);
+      x = active ? xn : x;                                   // a lane without an element keeps its state (always >= 2^16)
+      const bool need = x < (1u << 16);
+      const unsigned long long mask = __ballot(need);        // one word each, in lane order, from the shared pointer
+      {
+        const int q = ptr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        const unsigned word = wring[q & (kWordRing - 1)];
+        ok &= !need || q < len32;
+        x = need ? ((x << 16) | word) : x;
+        ptr += __popcll(mask);
+      }
+      const int n = (int)(m.y >> 16), vmin = (int)(short)(m.y & 0xffffu);
+      int v = (int)lo + vmin;
+      const bool esc = active && (int)lo == n - 1;
+      const unsigned long long emask = __ballot(esc);
+      if (emask) {
+        const int q = ptr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(emask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emask, 0u));
+        const unsigned word = wring[q & (kWordRing - 1)];
+        ok &= !esc || q < len32;
+        v = esc ? (int)(x & 0xffffu) - 32768 : v;
+        x = esc ? ((x & 0xffff0000u) | word) : x;
+        ptr += __popcll(emask);
+      }
+      if (active) vout[i * L] = v;
+    }
+    word_spill();
+    tid_spill((int)((k + 1) & 1));
+  }
+  const bool good = ok && x == (1u << 16) && ptr == len32;
+  if (__ballot(!good) && lane == 0) atomicAdd(bad, 1);
+}
+
 // indexes = round(clamp(exp(raw), 0, 63)) as the table id of every y element (the integer scale table TFC's
 // compress() path uses); raw = hyper[..., C:]
 __global__ void scale_index_kernel(const float* __restrict__ hyper, long long npix, int c, unsigned short* __restrict__ tid) {
@@ -395,18 +557,42 @@ extern "C" int sntc_rans_compact(const uint16_t* scratch, int64_t cap_words, con
   return SNTC_OK;
 }
 
+// LDS the decoder's own tables may take: what is left of a CU's next to the staging rings and the descriptors
+extern "C" int64_t sntc_rans_lut_budget(int ntables, int total_entries) {
+  if (ntables < 1 || total_entries < 1) return -1;
+  const long long dec_bytes = 4LL * (((long long)total_entries + 3LL * ntables + 3) / 4 * 4);
+  const long long rest = (long long)kRansLdsLimit - (long long)ntables * (long long)sizeof(uint4) - dec_bytes;
+  return rest < 16 ? 0 : rest / 2 / 8 * 8;
+}
+
 extern "C" int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets, const uint16_t* table_ids, int nimages,
                                 int64_t elems_per_image, int segments, int lanes, const uint16_t* cdf, const uint32_t* meta,
-                                int ntables, int total_entries, int32_t* values, int32_t* bad_streams, void* stream) {
+                                int ntables, int total_entries, const uint32_t* dec, const uint16_t* lut, const uint32_t* lut_meta,
+                                int lut_entries, int32_t* values, int32_t* bad_streams, void* stream) {
   if (!payload || !offsets || !table_ids || !cdf || !meta || !values || !bad_streams)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: null argument");
   if (nimages < 1 || elems_per_image < 1 || segments < 1 || !lanes_ok(lanes) || ntables < 1 || total_entries < 1)
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: bad sizes");
-  const RansTables T{cdf, reinterpret_cast<const uint2*>(meta), ntables, total_entries};
+  const bool fast = dec != nullptr;
+  if (fast != (lut != nullptr) || fast != (lut_meta != nullptr) ||
+      (fast && (lut_entries < ntables || (lut_entries & 7) || lut_entries > sntc_rans_lut_budget(ntables, total_entries))))
+    return fail(SNTC_ERR_BAD_SHAPE, "sntc_rans_decode: dec / lut / lut_meta come together, lut_entries a multiple of 8 within sntc_rans_lut_budget()");
   const long long eseg = segment_elems(elems_per_image, segments);
-  const int ns = nimages * segments, tb = table_bytes(ntables, total_entries), lds = kStagingBytes + tb;
+  const int ns = nimages * segments;
   hipStream_t s = (hipStream_t)stream;
   SNTC_HIP(hipMemsetAsync(bad_streams, 0, sizeof(int32_t), s));
+  if (fast) {
+    const int dec_total = (total_entries + 3 * ntables + 3) / 4 * 4;
+    const RansDecTables D{dec, lut, reinterpret_cast<const uint2*>(meta), lut_meta, ntables, dec_total, lut_entries};
+    const int lds = kStagingBytes + ntables * (int)sizeof(uint4) + dec_total * 4 + lut_entries * 2;
+    SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(ns), dim3(64), lds, s, payload, reinterpret_cast<const long long*>(offsets), table_ids,
+                       segments, lanes, (long long)elems_per_image, eseg, D, values, bad_streams);
+    SNTC_HIP(hipGetLastError());
+    return SNTC_OK;
+  }
+  const RansTables T{cdf, reinterpret_cast<const uint2*>(meta), ntables, total_entries};
+  const int tb = table_bytes(ntables, total_entries), lds = kStagingBytes + tb;
   if (tb <= kRansLdsLimit) {
     SNTC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(rans_decode_kernel<true>, dim3(ns), dim3(64), lds, s, payload, reinterpret_cast<const long long*>(offsets),

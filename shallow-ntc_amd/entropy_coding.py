@@ -99,6 +99,39 @@ def factorized_tables(prior_weights, num_layers, tail_mass=2.0 ** -12, max_half_
     return tabs
 
 
+def decoder_entries(tabs):
+    """(cdf[s] << 16) | (freq[s] - 1) for every symbol of every table, three 0xffffffff after each table, padded to a multiple
+    of four entries."""
+    out = []
+    for _, f in tabs:
+        f = np.asarray(f, np.int64)
+        cdf = np.concatenate([[0], np.cumsum(f)[:-1]])
+        assert len(f) >= 2 and f.min() >= 1 and f.max() <= 65535
+        out.append(((cdf << 16) | (f - 1)).astype(np.uint32))
+        out.append(np.full(3, 0xFFFFFFFF, np.uint32))
+    flat = np.concatenate(out)
+    pad = -len(flat) % 4
+    return np.concatenate([flat, np.full(pad, 0xFFFFFFFF, np.uint32)]) if pad else flat
+
+
+def start_tables(cdfs, bits):
+    """Per table the decoder's start table: entry b of 2^bits = the largest symbol s with cdf[s] <= b << (16 - bits).
+    -> (uint16 entries of all tables, padded to a multiple of eight; uint32 (offset << 5) | bits per table)."""
+    luts, lmeta, pos = [], [], 0
+    for cdf, b in zip(cdfs, bits):
+        base = np.arange(1 << b, dtype=np.int64) << (16 - b)
+        lut = np.searchsorted(cdf.astype(np.int64), base, side="right") - 1
+        assert lut.min() >= 0 and lut.max() < len(cdf)
+        luts.append(lut.astype(np.uint16))
+        lmeta.append((pos << 5) | b)
+        pos += len(lut)
+    flat = np.concatenate(luts)
+    pad = -len(flat) % 8
+    if pad:
+        flat = np.concatenate([flat, np.zeros(pad, np.uint16)]).astype(np.uint16)
+    return flat, np.asarray(lmeta, np.uint32)
+
+
 class DeviceTables:
     """Concatenated uint16 CDFs (cdf[n] = 65536 implicit) + packed per-table descriptors on the device."""
 
@@ -119,11 +152,28 @@ class DeviceTables:
         self.ntables, self.total = len(tabs), pos
         self.cdf = torch.from_numpy(flat.view(np.int16).copy()).to(device)
         self.meta = torch.from_numpy(np.asarray(meta, np.uint32).view(np.int32).copy()).to(device)
+        # the decoder's own view of the tables (include/sntc.h, sntc_rans_decode): packed (start, frequency - 1) entries with
+        # three sentinels per table, and start tables of about one entry per symbol -- a table of n symbols gets 2^ceil(log2 n)
+        # buckets, one bit more where the CU's LDS has the room, fewer where it has not
+        budget = int(capi.load().sntc_rans_lut_budget(self.ntables, self.total))
+        self.dec, self.lut, self.lut_meta, self.lut_total, self.lut_bits = None, None, None, 0, None
+        for extra in (1, 0, -1, -2, -3, -4, -5, -6):
+            bits = [min(16, max(0, int(np.ceil(np.log2(max(len(f), 1)))) + extra)) for _, f in tabs]
+            if -(-sum(1 << b for b in bits) // 8) * 8 <= budget:
+                lut, lmeta = start_tables(cdfs, bits)
+                dec = decoder_entries(tabs)
+                self.lut_bits, self.lut_total = bits, len(lut)
+                self.dec = torch.from_numpy(dec.view(np.int32).copy()).to(device)
+                self.lut = torch.from_numpy(lut.view(np.int16).copy()).to(device)
+                self.lut_meta = torch.from_numpy(lmeta.view(np.int32).copy()).to(device)
+                break
 
 
 def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
+
+USE_START_TABLES = True         # decoder: its own tables in LDS, DeviceTables.dec / .lut (False: binary search of cdf; same values)
 
 ELEMS_PER_SEGMENT = 1 << 18     # one rANS stream (= one wave of coding parallelism, 256 bytes of flushed lane states) per
                                 # this many latent elements: ~0.008 bit / element of overhead; a Kodak image = 1 z + 2 y streams
@@ -181,8 +231,10 @@ def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segment
     deferred = bad is not None
     if not deferred:
         bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    fast = USE_START_TABLES and tables.dec is not None
     capi.call("sntc_rans_decode", _p(payload), _p(offsets), _p(table_ids), n, E, segments, lanes, _p(tables.cdf), _p(tables.meta),
-              tables.ntables, tables.total, _p(values), _p(bad), ops._stream())
+              tables.ntables, tables.total, _p(tables.dec if fast else None), _p(tables.lut if fast else None),
+              _p(tables.lut_meta if fast else None), tables.lut_total if fast else 0, _p(values), _p(bad), ops._stream())
     if not deferred:
         nbad = int(bad.item())
         if nbad:

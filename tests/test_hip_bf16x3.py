@@ -97,7 +97,7 @@ def test_presplit_kernel_against_float64(kind, k, s, cin, cout, n, h, w, act, ep
     xs = ops.split3(xd)
     e32 = rel_err(p32(xd, res=rd).cpu().numpy(), ref)
     outs = []
-    for variant in (11, 12):
+    for variant in (11, 12, 13):
         ps.set_tile(variant)
         for sk, halo in ((True, True), (False, True), (True, False), (False, False)):
             ps.set_stream_k(sk, force=sk, halo=halo)      # halo: one activation patch per channel slab where the geometry allows
@@ -142,7 +142,7 @@ def test_stream_k_chain_at_full_width(dev):
     xs = ops.split3(x)
     ref = ops.ConvPlan("convT", wk, b, 1, "relu")(x)
     outs = []
-    for variant in (11, 12):
+    for variant in (11, 12, 13):
         ps.set_tile(variant)
         for sk, halo in ((True, True), (False, True), (True, False), (False, False)):
             ps.set_stream_k(sk, force=sk, halo=halo)

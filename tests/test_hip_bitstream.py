@@ -59,6 +59,44 @@ def test_stream_words_match_python_restatement(dev):
         ec.rans_decode(bad, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt)
 
 
+def test_start_tables_do_not_change_a_decoded_value(dev, monkeypatch):
+    """The decoder's start tables (DeviceTables.lut) only shorten the symbol search: same values with and without them, on every
+    table incl. the thin tails of the widest ones (where a bucket spans dozens of symbols), on the per-channel tables of a
+    factorized prior, and the same refusal of a corrupt stream."""
+    from shallow_ntc_amd import _capi
+    from shallow_ntc_amd import entropy_coding as ec
+    rng = np.random.default_rng(5)
+    tabs = ec.normal_tables()
+    dt = ec.DeviceTables(tabs, dev)
+    assert dt.lut is not None and dt.lut_total <= int(_capi.load().sntc_rans_lut_budget(dt.ntables, dt.total))
+    n, P, c = 3, 700, 16
+    tids = rng.integers(0, 64, size=(n, P, c)).astype(np.int16)
+    tids[1] = 63                                               # one image entirely on the widest table
+    sig = np.array([0.11 * np.exp(ec.SCALE_FACTOR * k) for k in range(64)])
+    vals = np.rint(rng.standard_normal((n, P, c)) * sig[tids] * np.where(rng.random((n, P, c)) < 0.2, 3.5, 1.0)).astype(np.int32)
+    vals[2, :40, 0] = rng.integers(-30000, 30000, 40)         # escapes
+    payload, lens = ec.rans_encode(torch.from_numpy(vals).to(dev), torch.from_numpy(tids).to(dev), dt)
+    outs = []
+    for use in (True, False):
+        monkeypatch.setattr(ec, "USE_START_TABLES", use)
+        outs.append(ec.rans_decode(payload, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt))
+        bad = payload.clone()
+        bad[200] ^= 0x0440
+        with pytest.raises(_capi.SntcError, match="corrupt"):
+            ec.rans_decode(bad, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt)
+    np.testing.assert_array_equal(outs[0].cpu().numpy(), vals)
+    assert torch.equal(outs[0], outs[1])
+    # every slot of every table: the start symbol is at or below the slot's symbol, never above
+    for (lo, f), bits, lm in zip(tabs, dt.lut_bits, dt.lut_meta.cpu().numpy().view(np.uint32)):
+        cdf = np.concatenate([[0], np.cumsum(f)[:-1]])
+        assert lm & 31 == bits
+        lut = dt.lut.cpu().numpy().view(np.uint16)[(lm >> 5):(lm >> 5) + (1 << bits)]
+        slots = np.arange(0, 65536, 7)
+        sym = np.searchsorted(cdf, slots, side="right") - 1
+        start = lut[slots >> (16 - bits)]
+        assert (start <= sym).all() and (cdf[start] <= (slots >> (16 - bits) << (16 - bits))).all()
+
+
 def test_codec_round_trip_and_rate(dev):
     """compress -> bytes -> decompress == decode(encode(x)) bit for bit; the coded size is within a few percent
     of the estimated rate (integer scale table + 16-bit frequencies + escapes + per-stream headers)."""

@@ -93,7 +93,7 @@ if args.bf16x3:
               f"max |bf16x3 - fp32| / max |fp32| = {err:.2e}")
     ps = ops.ConvPlan(args.kind, wk, b, args.s, None, capi.PRO_NONE, capi.EPI_ADD if args.epi else capi.EPI_STORE, bf16x3="presplit")
     xs = ops.split3(x)
-    for v3 in (11, 12):
+    for v3 in (11, 12, 13):
         ps.set_tile(v3)
         for static, halo in ((False, True), (True, True), (False, False), (True, False)):
             ps.set_stream_k(not static, force=not static, halo=halo)
