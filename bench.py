@@ -537,7 +537,7 @@ def main():
         tune(comp_fn)
         st_c, st_d = {}, {}
         timed(comp_fn, 5, 2, st_c)
-        decomp_fn = lambda: [bs_model.decompress(b) for b in blobs]
+        decomp_fn = lambda: bs_model.decompress_many(blobs)
         timed(decomp_fn, 5, 2, st_d)
         file_bpp = 8.0 * sum(len(b) for b in blobs) / pixels_per_step
         for label, st, fn in (("compress", st_c, comp_fn), ("decompress", st_d, decomp_fn)):

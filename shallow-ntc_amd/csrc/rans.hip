@@ -18,6 +18,7 @@
 // Cost of the parallelism: 4 L bytes of flushed state per stream (the host uses fewer lanes on short streams).  Probability precision 16 bits; CDF tables are
 // uint16 (cdf[n] = 65536 implicit) and live in LDS next to a packed (offset, n, vmin) descriptor per table.
 #include <algorithm>
+#include <type_traits>
 #include "sntc_internal.h"
 
 namespace sntc {
@@ -371,7 +372,6 @@ __global__ void __launch_bounds__(64) rans_decode_fast_kernel(const unsigned sho
     return;
   }
   unsigned x = lane < L ? (((unsigned)w[2 * lane] << 16) | w[2 * lane + 1]) : (1u << 16);
-  bool ok = true;
 
   int ptr = 2 * L, filled = 2 * L, wfrom = 2 * L, wto = 2 * L;  // as rans_decode_kernel: the ring holds [ptr, ptr + kWordRing)
   const int len32 = (int)len;
@@ -412,6 +412,54 @@ __global__ void __launch_bounds__(64) rans_decode_fast_kernel(const unsigned sho
   tid_fetch(0);
   tid_spill(0);
 
+  // One step.  FULL: every lane has an element in every step of the chunk (all chunks but a stream's last, with 64 lanes) -- no
+  // per-lane "active" selects, no store predicate.  A word index at or past the stream's end is not checked here: the
+  // pointer only grows, so it ends past the length and the stream is counted as bad below; the ring read itself is masked.
+  auto step = [&](auto full_tag, const unsigned short* tb, int* vout, int i, int cnt, int& t1, int& t2, uint4& m1) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const bool active = FULL || t1 != kNoTable;
+    const uint4 m = m1;
+    t1 = t2;
+    m1 = m4[(!FULL && t1 == kNoTable) ? 0 : t1];             // descriptor of step i + 1
+    t2 = tb[std::min(i + 2, kChunk - 1) * 64];               // table id of step i + 2 (FULL: past the chunk a repeat, unused)
+    if (!FULL && i + 2 >= cnt) t2 = kNoTable;
+    const unsigned slot = x & 0xffffu, key = (x << 16) | 0xfffeu;
+    const unsigned* e = dec + m.x;
+    unsigned lo = lut[m.z + (slot >> m.w)];
+    unsigned esel;
+    for (;;) {
+      const unsigned c0 = e[lo], c1 = e[lo + 1], c2 = e[lo + 2], c3 = e[lo + 3];
+      asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));   // all four in registers here: issued together, none deferred into a branch
+      const bool g1 = key >= c1, g2 = key >= c2, g3 = key >= c3;
+      esel = g2 ? c2 : (g1 ? c1 : c0);
+      lo += (g1 ? 1u : 0u) + (g2 ? 1u : 0u);
+      if (!__ballot(g3)) break;                              // a lane that has its symbol finds it again: c0 = its entry, g1 false
+      lo += g3 ? 1u : 0u;
+    }
+    const unsigned xn = ((esel & 0xffffu) + 1u) * (x >> 16) + slot - (esel >> 16);
+    x = active ? xn : x;                                     // a lane without an element keeps its state (always >= 2^16)
+    const bool need = x < (1u << 16);
+    const unsigned long long mask = __ballot(need);          // one word each, in lane order, from the shared pointer
+    {
+      const int q = ptr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      const unsigned word = wring[q & (kWordRing - 1)];
+      x = need ? ((x << 16) | word) : x;
+      ptr += __popcll(mask);
+    }
+    const int n = (int)(m.y >> 16), vmin = (int)(short)(m.y & 0xffffu);
+    int v = (int)lo + vmin;
+    const bool esc = active && (int)lo == n - 1;
+    const unsigned long long emask = __ballot(esc);
+    if (emask) {
+      const int q = ptr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(emask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emask, 0u));
+      const unsigned word = wring[q & (kWordRing - 1)];
+      v = esc ? (int)(x & 0xffffu) - 32768 : v;
+      x = esc ? ((x & 0xffff0000u) | word) : x;
+      ptr += __popcll(emask);
+    }
+    if (active) vout[(long long)i * L] = v;
+  };
+
   for (long long k = 0; k < nchunks; ++k) {
     tid_fetch(k + 1);
     word_fetch(ptr + kWordRing);
@@ -421,55 +469,16 @@ __global__ void __launch_bounds__(64) rans_decode_fast_kernel(const unsigned sho
     int t1 = tb[0];
     uint4 m1 = m4[t1 == kNoTable ? 0 : t1];
     int t2 = cnt > 1 ? (int)tb[64] : (int)kNoTable;
-    for (int i = 0; i < cnt; ++i) {
-      const bool active = t1 != kNoTable;
-      const uint4 m = m1;
-      t1 = t2;
-      m1 = m4[t1 == kNoTable ? 0 : t1];                      // descriptor of step i + 1
-      t2 = tb[std::min(i + 2, kChunk - 1) * 64];             // table id of step i + 2
-      if (i + 2 >= cnt) t2 = kNoTable;
-      const unsigned slot = x & 0xffffu, key = (x << 16) | 0xfffeu;
-      const unsigned* e = dec + m.x;
-      unsigned lo = lut[m.z + (slot >> m.w)];
-      unsigned esel;
-      for (;;) {
-        const unsigned c0 = e[lo], c1 = e[lo + 1], c2 = e[lo + 2], c3 = e[lo + 3];
-        asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));   // all four in registers here: issued together, none deferred into a branch
-        const bool g1 = key >= c1, g2 = key >= c2, g3 = key >= c3;
-        esel = g2 ? c2 : (g1 ? c1 : c0);
-        lo += (g1 ? 1u : 0u) + (g2 ? 1u : 0u);
-        if (!__ballot(g3)) break;                            // a lane that has its symbol finds it again: c0 = its entry, g1 false
-        lo += g3 ? 1u : 0u;
-      }
-      const unsigned xn = ((esel & 0xffffu) + 1u) * (x >> 16) + slot - (esel >> 16);
-      x = active ? xn : x;                                   // a lane without an element keeps its state (always >= 2^16)
-      const bool need = x < (1u << 16);
-      const unsigned long long mask = __ballot(need);        // one word each, in lane order, from the shared pointer
-      {
-        const int q = ptr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        const unsigned word = wring[q & (kWordRing - 1)];
-        ok &= !need || q < len32;
-        x = need ? ((x << 16) | word) : x;
-        ptr += __popcll(mask);
-      }
-      const int n = (int)(m.y >> 16), vmin = (int)(short)(m.y & 0xffffu);
-      int v = (int)lo + vmin;
-      const bool esc = active && (int)lo == n - 1;
-      const unsigned long long emask = __ballot(esc);
-      if (emask) {
-        const int q = ptr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(emask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emask, 0u));
-        const unsigned word = wring[q & (kWordRing - 1)];
-        ok &= !esc || q < len32;
-        v = esc ? (int)(x & 0xffffu) - 32768 : v;
-        x = esc ? ((x & 0xffff0000u) | word) : x;
-        ptr += __popcll(emask);
-      }
-      if (active) vout[i * L] = v;
+    if (L == 64 && e0 + (k + 1) * kChunk * 64 <= e1) {
+#pragma unroll
+      for (int i = 0; i < kChunk; ++i) step(std::true_type{}, tb, vout, i, kChunk, t1, t2, m1);
+    } else {
+      for (int i = 0; i < cnt; ++i) step(std::false_type{}, tb, vout, i, cnt, t1, t2, m1);
     }
     word_spill();
     tid_spill((int)((k + 1) & 1));
   }
-  const bool good = ok && x == (1u << 16) && ptr == len32;
+  const bool good = x == (1u << 16) && ptr == len32;
   if (__ballot(!good) && lane == 0) atomicAdd(bad, 1);
 }
 

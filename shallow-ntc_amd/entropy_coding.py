@@ -313,7 +313,8 @@ class Codec:
                                    sz, sy, lz, ly)
         return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
 
-    def decompress(self, blob: bytes):
+    def _parse(self, blob: bytes):
+        """Header and stream lengths of one blob, checked against THIS model: nothing later trusts the header."""
         m = self.m
         if blob[:4] != MAGIC:
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "not an SNTC bitstream")
@@ -328,8 +329,8 @@ class Codec:
             names = {v: k for k, v in ARITH.items()}
             raise capi.SntcError(capi.ERR_UNSUPPORTED, f"bitstream was written by a {names.get(arith, arith)!r} model, this model "
                                  f"computes in {m._precision!r}: mu / sigma would not be reproduced bit for bit")
-        # Nothing below trusts the header: every dimension is recomputed from (H, W) and THIS model, so a corrupt or crafted
-        # blob cannot size an allocation or index a table-id tensor beyond what the model itself would produce.
+        # Every dimension is recomputed from (H, W) and THIS model, so a corrupt or crafted blob cannot size an allocation or
+        # index a table-id tensor beyond what the model itself would produce.
         if not (1 <= n <= self.MAX_IMAGES and 1 <= H <= self.MAX_SIDE and 1 <= W <= self.MAX_SIDE):
             raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream header: implausible batch / image size n={n} H={H} W={W}")
         want = self.latent_shapes(H, W)
@@ -348,26 +349,78 @@ class Codec:
         zw, yw = int(zl.sum()), int(yl.sum())
         if len(blob) != pos + 2 * (zw + yw):
             raise capi.SntcError(capi.ERR_BAD_SHAPE, "bitstream truncated")
+        return dict(n=n, H=H, W=W, c=c, cz=cz, hz=hz, wz=wz, h=h, w=w, sz=sz, sy=sy, lz=lz, ly=ly, zl=zl, yl=yl, pos=pos, zw=zw, yw=yw)
+
+    def decompress(self, blob: bytes):
+        return self.decompress_many([blob])[0]
+
+    def decompress_many(self, blobs):
+        """Several bitstreams (e.g. one per batch shape of a set) -> their pixel batches, in order.  An entropy-decoding launch
+        is a handful of lone waves whose time is a latency (one wave per stream, ~0.4 us per step of 64 symbols whatever the
+        batch), so the launches of ALL blobs run side by side on streams of their own: first every blob's hyper-latents, then --
+        after the hyper-syntheses, back on the caller's stream -- every blob's latents.  Only entropy decoding overlaps entropy
+        decoding: a decoding wave holds ~100 KB of tables in its CU's LDS and the stream-K convolutions need every one of their
+        workgroups resident, so a convolution launch that meets decoding waves simply waits for them (measured: groups of one
+        blob's images pipelined against each other's convolutions, 9.5 -> 10.9 / 12.7 / 17.6 ms with 2 / 3 / 4 groups)."""
+        m = self.m
+        heads = [self._parse(b) for b in blobs]
         dev = m.device
         with torch.cuda.device(dev):
-            zp = torch.from_numpy(np.frombuffer(blob, "<i2", zw, pos).copy()).to(dev)
-            yp = torch.from_numpy(np.frombuffer(blob, "<i2", yw, pos + 2 * zw).copy()).to(dev)
-            # one read-back of the corruption count for the whole blob instead of one per entropy-decoding launch: the chain
-            # z symbols -> hyper-synthesis -> y symbols -> synthesis is enqueued without the host waiting in between.
-            # (Groups of a blob's images on streams of their own, so that one group's entropy decoding runs under another's
-            # convolutions, were measured and dropped: 9.5 -> 10.9 / 12.7 / 17.6 ms with 2 / 3 / 4 groups.  A decoding wave holds
-            # ~100 KB of tables in its CU's LDS, the stream-K convolutions need every one of their workgroups resident, and so
-            # a convolution launch that meets decoding waves simply waits for them.)
-            bad = torch.zeros((1,), dtype=torch.int32, device=dev)
-            zi = rans_decode(zp, zl, channel_table_ids((n, hz, wz, cz), dev), (n, hz, wz, cz), self.z_tables, sz, lz, bad=bad)
-            hyper = m._hyper_synthesis(int_to_float(zi))
-            if tuple(hyper.shape) != (n, h, w, 2 * c):
-                raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents {(n, h, w, c)}")
-            sym = rans_decode(yp, yl, scale_table_ids(hyper), (n, h, w, c), self.y_tables, sy, ly, bad=bad)
-            y_hat = ops.dequant_split3(sym, hyper) if m._synthesis.takes_s3(h, w) else ops.dequant_scale_normal(sym, hyper)
-            px = m._pixels(y_hat, (H, W))
-            nbad = int(bad.item())                                # synchronises the stream
+            main = torch.cuda.current_stream()
+            side = self._side_streams(len(blobs)) if len(blobs) > 1 and not torch.cuda.is_current_stream_capturing() else [main] * len(blobs)
+            # one counter per entropy-decoding launch (the launch zeroes its own), ONE read-back for everything at the end: the
+            # chain z symbols -> hyper-synthesis -> y symbols -> synthesis is enqueued without the host waiting in between
+            bad = torch.zeros((2 * len(blobs),), dtype=torch.int32, device=dev)
+            pay = []
+            for b, hd in zip(blobs, heads):
+                zp = torch.from_numpy(np.frombuffer(b, "<i2", hd["zw"], hd["pos"]).copy()).to(dev)
+                yp = torch.from_numpy(np.frombuffer(b, "<i2", hd["yw"], hd["pos"] + 2 * hd["zw"]).copy()).to(dev)
+                pay.append((zp, yp))
+
+            def side_by_side(jobs):
+                outs = []
+                for st, job in zip(side, jobs):
+                    if st is not main:
+                        st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        outs.append(job())
+                for st, out in zip(side, outs):
+                    if st is not main:
+                        main.wait_stream(st)
+                        out.record_stream(main)
+                return outs
+
+            zis = side_by_side([
+                (lambda k=k, hd=hd: rans_decode(pay[k][0], hd["zl"], channel_table_ids((hd["n"], hd["hz"], hd["wz"], hd["cz"]), dev),
+                                                (hd["n"], hd["hz"], hd["wz"], hd["cz"]), self.z_tables, hd["sz"], hd["lz"], bad=bad[2 * k:2 * k + 1]))
+                for k, hd in enumerate(heads)])
+            hypers, tids = [], []
+            for zi, hd in zip(zis, heads):
+                hyper = m._hyper_synthesis(int_to_float(zi))
+                if tuple(hyper.shape) != (hd["n"], hd["h"], hd["w"], 2 * hd["c"]):
+                    raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents "
+                                         f"{(hd['n'], hd['h'], hd['w'], hd['c'])}")
+                hypers.append(hyper)
+                tids.append(scale_table_ids(hyper))
+            syms = side_by_side([
+                (lambda k=k, hd=hd: rans_decode(pay[k][1], hd["yl"], tids[k], (hd["n"], hd["h"], hd["w"], hd["c"]), self.y_tables, hd["sy"], hd["ly"],
+                                                bad=bad[2 * k + 1:2 * k + 2]))
+                for k, hd in enumerate(heads)])
+            out = []
+            for sym, hyper, hd in zip(syms, hypers, heads):
+                y_hat = ops.dequant_split3(sym, hyper) if m._synthesis.takes_s3(hd["h"], hd["w"]) else ops.dequant_scale_normal(sym, hyper)
+                out.append(m._pixels(y_hat, (hd["H"], hd["W"])))
+            nbad = int(bad.sum().item())                           # synchronises the stream
             if nbad:
-                raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream corrupt: {nbad} of {n * (sz + sy)} rANS streams did not terminate cleanly")
+                total = sum(hd["n"] * (hd["sz"] + hd["sy"]) for hd in heads)
+                raise capi.SntcError(capi.ERR_BAD_SHAPE, f"bitstream corrupt: {nbad} of {total} rANS streams did not terminate cleanly")
             ops.check_conv_status()       # wrong pixels never leave without an error
-            return px
+            return out
+
+    def _side_streams(self, count):
+        st = getattr(self, "_sides", None)
+        if st is None:
+            st = self._sides = []
+        while len(st) < count:
+            st.append(torch.cuda.Stream(device=self.m.device))
+        return st[:count]

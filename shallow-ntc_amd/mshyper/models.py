@@ -567,6 +567,11 @@ class Model:
         """Bitstream -> uint8 pixels [n, H, W, 3]; bit-identical to ``decode(encode(x))``."""
         return self._get_codec().decompress(blob)
 
+    def decompress_many(self, blobs):
+        """Several bitstreams -> their pixel batches; the entropy-decoding launches of all of them run side by side
+        (entropy_coding.Codec.decompress_many).  Same pixels as one ``decompress`` per blob."""
+        return self._get_codec().decompress_many(list(blobs))
+
     # -- training (reference :375-383) -----------------------------------------------------------------------
     def train_step(self, image_batch):
         """One optimizer step on ``image_batch`` (tape.gradient of end_to_end_frame_loss(training=True) + Adam,

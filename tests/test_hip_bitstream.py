@@ -121,8 +121,26 @@ def test_codec_round_trip_and_rate(dev):
     real_bits = 8.0 * len(blob)
     assert 0.97 * est_bits < real_bits < 1.08 * est_bits, (real_bits, est_bits)
     # single images decode identically from their own streams (batch invariance of the whole chain)
-    px0 = model.decompress(model.compress(x[:1].contiguous()))
+    blob0 = model.compress(x[:1].contiguous())
+    px0 = model.decompress(blob0)
     assert torch.equal(px0, px[:1])
+    # several blobs at once (their entropy-decoding launches side by side): the same pixels, in order
+    xp = torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(1, 384, 256, seed=9))).to(dev)
+    blobp = model.compress(xp)
+    many = model.decompress_many([blob, blobp, blob0])
+    assert torch.equal(many[0], px) and torch.equal(many[1], model.decompress(blobp)) and torch.equal(many[2], px0)
+    # a flipped payload word is refused whether it sits in the hyper-latents' streams or in the latents' (one counter per
+    # entropy-decoding launch, summed once)
+    import struct as _st
+    from shallow_ntc_amd.entropy_coding import Codec as _Codec
+    hd = model._get_codec()._parse(blob)
+    for word in (hd["pos"] // 2 + 300, hd["pos"] // 2 + hd["zw"] + 5000):
+        raw = bytearray(blob)
+        raw[2 * word] ^= 0x10
+        with pytest.raises(Exception, match="corrupt"):
+            model.decompress(bytes(raw))
+        with pytest.raises(Exception, match="corrupt"):
+            model.decompress_many([blob0, bytes(raw)])
     from shallow_ntc_amd import _capi
     with pytest.raises(_capi.SntcError):
         model.decompress(blob[:-10])
