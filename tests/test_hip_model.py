@@ -176,7 +176,7 @@ def test_mshyper_model_parity(synth, dev):
     solo = [mm.scalars_float for mm in model.evaluate(other, lookahead=1)]
     mixed = [x[0:1], other[0:1], x[1:2], x[0:1], other[1:2], x[1:2], x[0:1]]
     want = [serial[0], solo[0], serial[1], serial[0], solo[1], serial[1], serial[0]]
-    for look, group in ((2, 2), (4, 4), (3, 1)):
+    for look, group in ((2, 2), (4, 4), (3, 1), (3, 8)):
         out = list(model.evaluate(iter(mixed), lookahead=look, group=group))
         assert [mm.scalars_float for mm in out] == want, (look, group)
         rec = [mm.images["reconstruction"] for mm in out]
