@@ -571,6 +571,8 @@ def main():
                 shape = {8: "1, 1, 2, 2", 9: "2, 2, 2, 2", 10: "2, 4, 4, 1"}.get(e["variant"], f"1, {e['variant']}, 4, 1")
                 # <..., BF3, DMA, DEEP, FUSE2>: the default fp32 register-staged instance, or the fused ResidualBlock tail
                 name = f"gg_kernel<{shape}, {vec}, false, false, 0, {'true' if '+1x1' in e['kind'] else 'false'}>"
+                if e.get("colm"):                                           # the column-major stream-K twin (template argument COLM)
+                    name = name[:-1] + ", true>"
                 if e["variant"] >= 11:                                      # the pre-split bf16 x 3 kernel (csrc/bf3_gemm.hip)
                     name = f"bf3_kernel<4, 2, 2, {4 if e['variant'] == 11 else 2}>"
                 if e["kind"] == "resblock":                                 # the whole ResidualBlock in one launch (csrc/rb_fused.hip)

@@ -182,7 +182,9 @@ int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);
 /* Schedule switches of THIS plan (tests / profiling).  flags bit 0: 1 (default) lets large launches run on the persistent
  * stream-K workers, 0 forces the static schedule (one workgroup per tile); bit 2 set: bit 1 selects the stage path --
  * 1 direct-to-LDS (buffer_load ... lds), 0 register staging; bit 2 clear: the library default; bit 3: stream-K also for launches of
- * short tiles (< 64 K stages on average), which by default run one workgroup per tile because that is faster.  Every combination
+ * short tiles (< 64 K stages on average), which by default run one workgroup per tile because that is faster; bit 5 set: bit 6
+ * selects the stream-K unit order -- 1 column tile outermost (where that twin of the kernel exists), 0 row strip outermost; bit 5
+ * clear: column-major where one group's packed weights exceed an XCD's L2.  Every combination
  * produces bit-identical outputs (each element is the same k-ordered fma chain); the switches exist so that a test can
  * assert exactly that. */
 int sntc_conv_plan_set_schedule(sntc_conv_plan* plan, int flags);
@@ -214,6 +216,10 @@ int sntc_conv_set_stream_k(int enabled);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);
+/* 1 if that launch walks its stream-K units column tile outermost (the weights of a few column tiles stay in an XCD's L2 while
+ * the row strips stream past: single-group layers whose packed weights exceed 4 MB), 0 for the row-strip-major order.  Profiling
+ * only: the kernel's name differs, the bits do not. */
+int sntc_conv_launch_order(const sntc_conv_plan* plan, int n, int h, int w, int* column_major);
 /* Measured schedule.  Every (tile variant, stream-K / one-workgroup-per-tile) candidate of a plan computes the same k-ordered
  * chains, so the choice is a question of speed only; sntc_conv_plan_tune times them on the caller's buffers for one (n, h, w)
  * (`reps` launches each, HIP events on `stream`, synchronises it) and records the winner in the plan: later calls of that shape

@@ -71,6 +71,7 @@ SIGNATURES = {
     "sntc_conv_status_inject": (C.c_int, [C.c_int, _P]),
     "sntc_conv_set_stream_k": (C.c_int, [C.c_int]),
     "sntc_conv_launch_info": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sntc_conv_launch_order": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "sntc_conv_tune_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_conv_plan_tune": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), _P]),

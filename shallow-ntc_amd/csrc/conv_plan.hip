@@ -153,6 +153,8 @@ struct sntc_conv_plan {
   int dma = -1;             // direct-to-LDS staging: -1 default (kDefaultDma), 0 off, 1 on (sntc_conv_plan_set_schedule bit 1)
   bool no_stream_k = false; // force the static one-workgroup-per-tile schedule (tests: both schedules give identical bits)
   bool force_stream_k = false;  // ignore the short-tile rule: stream-K wherever the launch is large enough (tests)
+  int colm = -1;            // fp32 stream-K unit order: -1 rule (column tile outermost where one group's packed weights exceed an
+                            // XCD's 4 MB L2), 0 strip-major, 1 column-major wherever the twin exists (sntc_conv_plan_set_schedule bits 5, 6)
   bool no_halo = false;     // pre-split plans: stage every tap's activation rows separately even where one patch per slab would do (A/B)
   float* w2f = nullptr;     // this 1x1 plan's weights in the fused ResidualBlock tail's fragment order (fusable_second plans only)
   // sntc_conv_plan_tune: (n, h, w) -> measured best (tile variant, schedule).  Every candidate computes the same k-ordered chains,
@@ -185,6 +187,7 @@ extern "C" int sntc_conv_plan_set_schedule(sntc_conv_plan* p, int flags) {
   p->no_stream_k = (flags & 1) == 0;
   p->force_stream_k = (flags & 8) != 0;
   p->no_halo = (flags & 16) != 0;
+  p->colm = (flags & 32) ? ((flags & 64) ? 1 : 0) : -1;   // bit 5: "bit 6 is meaningful"; bit 6: column-major stream-K unit order on / off
   p->dma = (flags & 4) ? ((flags & 2) ? 1 : 0) : -1;      // bit 2: "bit 1 is meaningful"; bit 1: direct-to-LDS staging on / off
   return SNTC_OK;
 }
@@ -741,6 +744,23 @@ extern "C" int64_t sntc_conv_workspace_bytes(const sntc_conv_plan* p, int n, int
   return 4 * workspace_floats(p, (int64_t)n * g.Qh * g.Qw, plan_schedule(p, g, n, h, w));
 }
 
+// fp32 stream-K unit order of a launch: column tile outermost for single-group plans whose packed weights do not fit an XCD's
+// 4 MB L2, where the twin of the kernel exists (csrc/gather_gemm.hip, COLM)
+static bool column_major(const sntc_conv_plan* p, const Sched& sc, int dma) {
+  return !p->s3 && !p->bf3 && sc.sk && p->ngroups == 1 && p->colm != 0 && gg_colm_available(sc.variant, p->vec, p->d.prologue, dma) &&
+         (p->colm == 1 || (size_t)p->g[0].Ncol * p->g[0].K * sizeof(float) > ((size_t)4 << 20));
+}
+
+extern "C" int sntc_conv_launch_order(const sntc_conv_plan* p, int n, int h, int w, int* column_major_out) {
+  if (!p || !column_major_out) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_launch_order: null argument");
+  Geo g;
+  int rc = geometry(p, h, w, &g);
+  if (rc) return rc;
+  const Sched s = plan_schedule(p, g, n, h, w);
+  *column_major_out = column_major(p, s, s.deep ? 2 : plan_dma(p) ? 1 : 0) ? 1 : 0;
+  return SNTC_OK;
+}
+
 extern "C" int sntc_conv_launch_info(const sntc_conv_plan* p, int n, int h, int w, int* variant, int* nblocks) {
   if (!p || !variant || !nblocks) return fail(SNTC_ERR_BAD_SHAPE, "sntc_conv_launch_info: null argument");
   Geo g;
@@ -841,6 +861,9 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
     a.halo = halo ? 1 : 0;
     return bf3p_launch(v, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
   }
+  // stream-K unit order of the fp32 kernel: column tile outermost (GGArgs::order == 0) for single-group plans whose packed
+  // weights do not fit an XCD's 4 MB L2 -- the 3x3 hyper-synthesis layer (11 MB): HBM-side reads of the launch 1667 -> 857 MB
+  a.order = (!p2 && column_major(p, sc, a.dma)) ? 0 : 1;
   rc = gg_launch(v, p->vec, a, sc.sk ? sc.workers : nb, (hipStream_t)stream);
   if (rc || sc.sk || sc.ksplit <= 1) return rc;
   return gg_reduce_launch(a, (hipStream_t)stream);

@@ -159,7 +159,8 @@ __device__ __forceinline__ void split3(float x, __bf16* hi, __bf16* mid, __bf16*
 // (64 lanes x 16 B = 16 rows), so the XOR swizzle is applied to the SOURCE chunk each lane fetches.  Four ring slots: stage
 // j+3 is issued in step j, stage j+2 is waited for (counted vmcnt) before the barrier of step j, and its first fragments are
 // prefetched in step j+1.
-template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false, int DEEP = 0, bool FUSE2 = false>
+template <int TM, int TN, int WM, int WN, bool VEC, bool PRO, bool BF3 = false, bool DMA = false, int DEEP = 0, bool FUSE2 = false,
+          bool COLM = false>
 __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(const GGArgs a) {
   static_assert(!BF3 || (VEC && !PRO), "the bf16 x 3 experiment covers the vector path without prologue");
   static_assert(!DMA || (VEC && !PRO && !BF3), "direct-to-LDS staging: vector path, no prologue (nothing can touch the data on the way)");
@@ -209,18 +210,35 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
     // tile order: row strip major, then group, then column tile -- every worker's share mixes the groups (their tiles
     // differ in length, so a group-major order would hand some workers only short, epilogue-heavy tiles) and one strip's
     // input rows serve all groups while they are hot in L2
+    // COLM (a compile-time twin of the kernel, single-group plans only: round 3 had this as a run-time branch and the branch
+    // moved the whole kernel's register allocation): COLUMN tile outermost, row strips inside (u = nt * ntm * steps + mt * steps
+    // + k, tile id = nt * ntm + mt).  The workers of one XCD own a contiguous eighth of the range, i.e. less than one column
+    // tile of a five-column layer, whose weight rows then stay in that XCD's 4 MB L2 while the strips stream past -- for
+    // layers whose packed weights exceed the L2 (hyper-synthesis 480 -> 640: 11 MB), where the strip-major order streams the
+    // whole matrix through every XCD once per strip.
     auto locate = [&](int u, int* t, int* k, int* steps) {
-      const int mt = u / a.ups;
-      const int r = u - mt * a.ups;
-      int gi = 0;
+      if constexpr (COLM) {
+        const int st = a.g[0].steps;
+        const int per = a.ntm * st;
+        const int nt = u / per;
+        const int r2 = u - nt * per;
+        const int mt = r2 / st;
+        *t = nt * a.ntm + mt;
+        *k = r2 - mt * st;
+        *steps = st;
+      } else {
+        const int mt = u / a.ups;
+        const int r = u - mt * a.ups;
+        int gi = 0;
 #pragma unroll
-      for (int i = 1; i < kMaxGroups; ++i)
-        if (i < a.ngroups && r >= (int)a.g[i].unit0) gi = i;
-      const int r2 = r - (int)a.g[gi].unit0;
-      const int nt = r2 / a.g[gi].steps;
-      *t = mt * a.tps + a.g[gi].tile0 + nt;
-      *k = r2 - nt * a.g[gi].steps;
-      *steps = a.g[gi].steps;
+        for (int i = 1; i < kMaxGroups; ++i)
+          if (i < a.ngroups && r >= (int)a.g[i].unit0) gi = i;
+        const int r2 = r - (int)a.g[gi].unit0;
+        const int nt = r2 / a.g[gi].steps;
+        *t = mt * a.tps + a.g[gi].tile0 + nt;
+        *k = r2 - nt * a.g[gi].steps;
+        *steps = a.g[gi].steps;
+      }
     };
     if (u_hi > u_lo) {
       int tF, kF, sF, tL, kL, sL;
@@ -238,15 +256,22 @@ __global__ void __launch_bounds__(256, FUSE2 ? 2 : gg_waves(TM * TN)) gg_kernel(
 
   auto tile_of = [&](int t, Piece* p) {          // global tile id -> (group, row strip, column tile): column fastest
     KArgs& a = fresh_args();
-    const int mt = t / a.tps;
-    const int r = t - mt * a.tps;
-    int gi = 0;
+    if constexpr (COLM) {                        // one group; tile id = nt * ntm + mt
+      const int nt = t / a.ntm;
+      p->gi = 0;
+      p->mt = t - nt * a.ntm;
+      p->nt = nt;
+    } else {
+      const int mt = t / a.tps;
+      const int r = t - mt * a.tps;
+      int gi = 0;
 #pragma unroll
-    for (int i = 1; i < kMaxGroups; ++i)
-      if (i < a.ngroups && r >= a.g[i].tile0) gi = i;
-    p->gi = gi;
-    p->mt = mt;
-    p->nt = r - a.g[gi].tile0;
+      for (int i = 1; i < kMaxGroups; ++i)
+        if (i < a.ngroups && r >= a.g[i].tile0) gi = i;
+      p->gi = gi;
+      p->mt = mt;
+      p->nt = r - a.g[gi].tile0;
+    }
   };
 
   auto next_piece = [&](Piece* p) -> bool {
@@ -1136,6 +1161,12 @@ static const void* kernel_fused() {
   return reinterpret_cast<const void*>(&gg_kernel<1, 3, 4, 1, true, false, false, false, 0, true>);
 }
 
+// the column-tile-outermost twin of the 128 x 128 stream-K instance (GGArgs::order == 0; single-group plans)
+static const void* kernel_colm() {
+  return reinterpret_cast<const void*>(&gg_kernel<2, 2, 2, 2, true, false, false, false, 0, false, true>);
+}
+static bool colm_shape(int variant, bool vec, int pro, int dma) { return variant == 9 && vec && pro == SNTC_PRO_NONE && dma == 0; }
+
 static const void* variant_kernel_bf3(int v) {
   switch (v) {
     case 2: return reinterpret_cast<const void*>(&gg_kernel<1, 2, 4, 1, true, false, true>);
@@ -1176,6 +1207,7 @@ struct DeviceTables {
   int resident_dma[kNumVariants + 1] = {};
   int resident_deep[kNumVariants + 1] = {};
   int resident_fused = 0;
+  bool colm_ok = false;                        // the column-major twin of variant 9 is as resident as variant 9 itself
   int* status = nullptr;                       // sticky status word (device memory)
 };
 static DeviceTables g_dev[kMaxDevices];
@@ -1216,6 +1248,14 @@ static int fill_tables(DeviceTables& T, int dev) {
     int per_cu = 0;
     SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes(3)));
     T.resident_fused = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(3))})) * T.num_cus;
+  }
+  {
+    const void* fn = kernel_colm();
+    SNTC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(9)));
+    int per_cu = 0;
+    SNTC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds_bytes(9)));
+    // stream-K sizes its worker count from the strip-major instance's residency: the twin must hold as many
+    T.colm_ok = std::max(1, std::min({per_cu, 8, (int)(163840 / lds_bytes(9))})) * T.num_cus >= T.resident[9][0];
   }
   for (int v : {2, 4}) {
     const void* fn = variant_kernel_bf3(v);
@@ -1277,6 +1317,12 @@ int gg_resident_blocks_fused() {
   return T ? T->resident_fused : 0;
 }
 
+// the column-major stream-K twin exists for this launch shape on the current device
+bool gg_colm_available(int variant, bool vec, int pro, int dma) {
+  const DeviceTables* T = current_tables();
+  return T && T->colm_ok && colm_shape(variant, vec, pro, dma);
+}
+
 int gg_resident_blocks_bf3(int variant) {
   const DeviceTables* T = current_tables();
   return (variant == 2 || variant == 4) && T ? T->resident_bf3[variant] : 0;
@@ -1289,8 +1335,11 @@ int gg_launch(int variant, bool vec, const GGArgs& args, int nblocks, hipStream_
   const bool fused = args.w2f != nullptr;
   if (fused && (variant != 3 || !vec || pro || args.bf3 || args.ksplit != 1))
     return fail(SNTC_ERR_UNSUPPORTED, "fused ResidualBlock tail: 128 x 96 vector instance, no prologue, no split-K");
+  const bool colm = !fused && !args.bf3 && args.sk && args.order == 0 && args.ngroups == 1 && colm_shape(variant, vec, args.pro, args.dma);
+  if (!fused && !args.bf3 && args.sk && args.order == 0 && !colm)
+    return fail(SNTC_ERR_UNSUPPORTED, "column-major stream-K order: single-group plans on the 128 x 128 register-staged vector instance only");
   const void* fn = fused ? kernel_fused() : args.bf3 ? variant_kernel_bf3(variant) : deep ? variant_kernel_deep(variant)
-                   : dma ? variant_kernel_dma(variant) : variant_kernel(variant, vec, pro || !vec);
+                   : dma ? variant_kernel_dma(variant) : colm ? kernel_colm() : variant_kernel(variant, vec, pro || !vec);
   if (!fn) return fail(SNTC_ERR_UNSUPPORTED, "unknown gather-GEMM tile variant");
   if (args.bf3 && (pro || !vec)) return fail(SNTC_ERR_UNSUPPORTED, "bf16 x 3 mode: vector path without prologue only");
   GGArgs a = args;

@@ -88,7 +88,8 @@ struct GGArgs {
   int bf3;             // 1: bf16 x 3 split-precision experiment (weights packed as three bf16 planes)
   int halo;            // bf3_gemm.hip: 1 = patch staging (one activation patch per channel slab shared by its taps); needs sA == 1
                        // and every group's patch within bf3p_patch_rows_max()
-  int order;           // bf3_gemm.hip stream-K unit order: 1 strip-major (default, as gather_gemm.hip), 0 column tile outermost (A/B)
+  int order;           // stream-K unit order: 1 strip-major (default), 0 column tile outermost (bf3_gemm.hip: A/B switch;
+                       // gather_gemm.hip: the COLM twin of the 128 x 128 instance, single-group plans whose weights exceed an XCD's L2)
   int dbg;             // -DSNTC_DIAG builds only (SNTC_GG_DBG): 1 skip global loads, 2 skip LDS writes, 4 skip barriers,
                        // 8 skip fragment reads, 16 skip the epilogue's stores, 32 its residual loads, 64 the MFMAs, 128 the fused
                        // ResidualBlock tail's second contraction -- to see what a launch waits on; results are meaningless with any bit set
@@ -109,7 +110,8 @@ int gg_resident_blocks_deep(int variant);                   // same for the deep
 int gg_num_cus();
 int* gg_status_word();                                      // device pointer of the current device's sticky status word
 int gg_resident_blocks_dma(int variant);                    // same for the direct-to-LDS instantiations
-int gg_resident_blocks_fused();                             // the FUSE2 instance (variant 3)
+int gg_resident_blocks_fused();
+bool gg_colm_available(int variant, bool vec, int pro, int dma);                             // the FUSE2 instance (variant 3)
 int gg_resident_blocks_bf3(int variant);                    // same for the bf16 x 3 instantiations (variants 2 and 4)
 size_t gg_sk_slab_floats(int variant);                     // per-worker accumulator slab of the stream-K hand-off
 

@@ -256,12 +256,13 @@ class ConvPlan:
         """Force this plan's gather-GEMM tile variant (0 = heuristic); profiling / tests."""
         capi.call("sntc_conv_plan_set_tile", self._h, int(variant))
 
-    def set_stream_k(self, enabled, dma=None, force=False, halo=True):
+    def set_stream_k(self, enabled, dma=None, force=False, halo=True, colm=None):
         """``enabled`` False forces the static one-workgroup-per-tile schedule for this plan; ``dma`` True / False forces the
         direct-to-LDS / register stage path (None: library default); ``force``: stream-K even where the default picks one
         workgroup per tile because the tiles are short; ``halo`` False (pre-split plans): stage every tap's activation rows
         separately instead of one patch per channel slab.  Tests: identical bits every way."""
         flags = int(bool(enabled)) | (0 if dma is None else (4 | (2 if dma else 0))) | (8 if force else 0) | (0 if halo else 16)
+        flags |= 0 if colm is None else (32 | (64 if colm else 0))   # stream-K unit order: column tile / row strip outermost (None: rule)
         capi.call("sntc_conv_plan_set_schedule", self._h, flags)
 
     def fusable_with(self, second):
@@ -377,8 +378,10 @@ class ConvPlan:
         if prof is not None:
             e1.record()
             v, nb = self.launch_info(n, h, w)
+            colm = C.c_int()
+            capi.call("sntc_conv_launch_order", self._h, n, h, w, C.byref(colm))
             prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=v, nblocks=nb, vec=self.cin % 16 == 0 or self.rowpack,
-                             kind=self.kind, k=self.k[0], s=self.stride, cin=self.cin, cout=self.cout, n=n, h=h, w=w))
+                             kind=self.kind, k=self.k[0], s=self.stride, cin=self.cin, cout=self.cout, n=n, h=h, w=w, colm=bool(colm.value)))
         return y
 
 

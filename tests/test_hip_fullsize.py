@@ -1,5 +1,7 @@
 """Full-size (BASELINE.json configs 2-4 shapes) property tests on the GPU, where the float64 oracle
 would take minutes: size-independent identities instead of element-wise comparison (-m gpu)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -304,6 +306,18 @@ def test_stream_k_is_bit_identical_to_the_static_schedule(kind, k, s, cin, cout,
             assert torch.equal(plan(x, res=res), y_static), (variant, sk, "dma")
             plan.set_stream_k(sk, dma=False, force=sk)
             assert torch.equal(plan(x, res=res), y_static), (variant, sk, "registers")
+    # the stream-K unit order: column tile outermost (the COLM twin of the 128 x 128 instance; single-group plans) against
+    # row strip outermost -- other K ranges per worker, the same chains
+    plan.set_tile(9)
+    orders = set()
+    for colm in (True, False):
+        plan.set_stream_k(True, force=True, colm=colm)
+        order = C.c_int(-1)
+        capi.call("sntc_conv_launch_order", plan._h, n, h, w, C.byref(order))
+        orders.add(order.value)
+        assert torch.equal(plan(x, res=res), y_static), ("column-major", colm)
+    if (kind, k, cin) == ("convT", 3, 480):  # one phase group on the vector path: the twin exists and was really launched
+        assert orders == {0, 1}, orders
     plan.set_stream_k(True)
     plan.set_tile(0)
     one = plan(x[2:3].contiguous(), res=None if res is None else res[2:3].contiguous())
