@@ -28,6 +28,12 @@ python3 tools/profile_layers.py --reps 5 --batch 64 --hw 256 256 --autotune > $O
 python3 tools/rb_block.py > $O/resblock_vs_layers.txt 2>&1
 python3 tools/stream_kernels.py > $O/stream_kernels.txt 2>&1
 python3 tools/time_evaluate.py > $O/evaluate_b1.txt 2>&1
+python3 tools/profile_layers.py --reps 5 --precision bf16x3 > $O/layer_table_bf16x3.txt 2>&1
+python3 tools/rans_steps.py > $O/rans_steps.txt 2>&1
+python3 tools/rans_steps.py --no-lut >> $O/rans_steps.txt 2>&1
+python3 tools/decompress_phases.py > $O/decompress_phases.txt 2>&1
+python3 tools/decompress_phases.py --one-by-one >> $O/decompress_phases.txt 2>&1
+python3 tools/ab_order.py > $O/ab_order.txt 2>&1
 python3 tools/summarize_pmc.py ${TAG}_pmc_summary $(find $O/dec_stats -name "*kernel_stats.csv" | head -1) $O/dec_pmc_sq $O/dec_pmc_fetch $O/dec_pmc_write > $O/summary_dec.txt 2>&1
 python3 tools/summarize_pmc.py ${TAG}_encode_pmc_summary $(find $O/enc_stats -name "*kernel_stats.csv" | head -1) $O/enc_pmc_sq $O/enc_pmc_fetch $O/enc_pmc_write > $O/summary_enc.txt 2>&1
 # (the summaries above carry the hashes of the kernel sources they were measured on: the bench line below reads them, traffic_stale false)
