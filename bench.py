@@ -609,6 +609,10 @@ def main():
                         traffic_source=traffic_src, traffic_stale=traffic_stale,
                         avg_launch_ms=round(k["ms"] / k["launches"], 4), launches_per_step=k["launches"] // 3,
                         precision="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                        note=("dominant kernel by GPU time of the decode step; since round 4 the 480->640 hyper-synthesis launch runs on the "
+                              "column-major twin of the 128x128 instance (template argument COLM), a kernel of its own in rocprof's tables, so this "
+                              "object describes that ONE exact-fit launch; the strip-major instance (the synthesis launches) is in all_kernels, the "
+                              "whole step's fraction in regions.decode.roofline"),
                         all_kernels={n: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                              ms_per_step=round(v["ms"] / 3, 4)) for n, v in per_kernel.items()})
 
