@@ -215,7 +215,7 @@ def rans_encode(values, table_ids, tables: DeviceTables, segments=None, lanes=No
     return payload, lens_h
 
 
-def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segments=None, lanes=None, bad=None):
+def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segments=None, lanes=None, bad=None, offsets=None):
     """-> int32 values of ``shape`` [n, ...]; raises on a malformed stream.  ``bad`` (an int32 device tensor [1]): count the
     streams that did not terminate cleanly there instead of reading the count back here -- the caller checks it where it
     synchronises anyway (a decoder that keeps several batches in flight)."""
@@ -226,7 +226,8 @@ def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segment
     if len(lens_h) != n * segments:
         raise capi.SntcError(capi.ERR_BAD_SHAPE, "stream count does not match the image / segment counts")
     dev = payload.device
-    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)).to(dev)
+    if offsets is None:        # ``offsets``: the exclusive prefix sum of lens_h already on the device (int64 [streams + 1])
+        offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)).to(dev)
     values = torch.empty(tuple(shape), dtype=torch.int32, device=dev)
     deferred = bad is not None
     if not deferred:
@@ -371,11 +372,23 @@ class Codec:
             # one counter per entropy-decoding launch (the launch zeroes its own), ONE read-back for everything at the end: the
             # chain z symbols -> hyper-synthesis -> y symbols -> synthesis is enqueued without the host waiting in between
             bad = torch.zeros((2 * len(blobs),), dtype=torch.int32, device=dev)
-            pay = []
-            for b, hd in zip(blobs, heads):
-                zp = torch.from_numpy(np.frombuffer(b, "<i2", hd["zw"], hd["pos"]).copy()).to(dev)
-                yp = torch.from_numpy(np.frombuffer(b, "<i2", hd["yw"], hd["pos"] + 2 * hd["zw"]).copy()).to(dev)
-                pay.append((zp, yp))
+            # ONE upload for every blob's words and stream offsets (int64 offsets first, then the 16-bit words: both aligned)
+            offs = [np.concatenate([[0], np.cumsum(hd[k])]).astype(np.int64) for hd in heads for k in ("zl", "yl")]
+            words = [np.frombuffer(b, "<i2", hd["zw"] + hd["yw"], hd["pos"]) for b, hd in zip(blobs, heads)]
+            noff = sum(len(o) for o in offs)
+            host = np.empty(8 * noff + 2 * sum(len(w) for w in words), np.uint8)
+            host[:8 * noff].view(np.int64)[:] = np.concatenate(offs)
+            host[8 * noff:].view(np.int16)[:] = np.concatenate(words)
+            up = torch.from_numpy(host).to(dev)
+            off_d, word_d = up[:8 * noff].view(torch.int64), up[8 * noff:].view(torch.int16)
+            pay, offd = [], []
+            o = wpos = 0
+            for hd in heads:
+                nz, ny = len(hd["zl"]) + 1, len(hd["yl"]) + 1
+                offd.append((off_d[o:o + nz], off_d[o + nz:o + nz + ny]))
+                o += nz + ny
+                pay.append((word_d[wpos:wpos + hd["zw"]], word_d[wpos + hd["zw"]:wpos + hd["zw"] + hd["yw"]]))
+                wpos += hd["zw"] + hd["yw"]
 
             def side_by_side(jobs):
                 outs = []
@@ -392,7 +405,8 @@ class Codec:
 
             zis = side_by_side([
                 (lambda k=k, hd=hd: rans_decode(pay[k][0], hd["zl"], channel_table_ids((hd["n"], hd["hz"], hd["wz"], hd["cz"]), dev),
-                                                (hd["n"], hd["hz"], hd["wz"], hd["cz"]), self.z_tables, hd["sz"], hd["lz"], bad=bad[2 * k:2 * k + 1]))
+                                                (hd["n"], hd["hz"], hd["wz"], hd["cz"]), self.z_tables, hd["sz"], hd["lz"], bad=bad[2 * k:2 * k + 1],
+                                                offsets=offd[k][0]))
                 for k, hd in enumerate(heads)])
             hypers, tids = [], []
             for zi, hd in zip(zis, heads):
@@ -404,7 +418,7 @@ class Codec:
                 tids.append(scale_table_ids(hyper))
             syms = side_by_side([
                 (lambda k=k, hd=hd: rans_decode(pay[k][1], hd["yl"], tids[k], (hd["n"], hd["h"], hd["w"], hd["c"]), self.y_tables, hd["sy"], hd["ly"],
-                                                bad=bad[2 * k + 1:2 * k + 2]))
+                                                bad=bad[2 * k + 1:2 * k + 2], offsets=offd[k][1]))
                 for k, hd in enumerate(heads)])
             out = []
             for sym, hyper, hd in zip(syms, hypers, heads):
