@@ -364,6 +364,8 @@ class Codec:
         workgroups resident, so a convolution launch that meets decoding waves simply waits for them (measured: groups of one
         blob's images pipelined against each other's convolutions, 9.5 -> 10.9 / 12.7 / 17.6 ms with 2 / 3 / 4 groups)."""
         m = self.m
+        if not blobs:
+            return []
         heads = [self._parse(b) for b in blobs]
         dev = m.device
         with torch.cuda.device(dev):
