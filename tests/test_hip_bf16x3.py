@@ -221,8 +221,11 @@ def test_model_in_bf16x3_meets_the_baseline_bars(synth, dev, monkeypatch):
     px = m3.decompress(blob)
     z_hat, symbols, _, _ = m3.encode(x)
     assert torch.equal(px, m3.decode(z_hat, symbols, (256, 320)))
-    one = m3.decompress(m3.compress(x[:1]))
+    blob1 = m3.compress(x[:1])
+    one = m3.decompress(blob1)
     assert torch.equal(one, px[:1])                                                  # batch-invariant arithmetic
+    many = m3.decompress_many([blob1, blob])                                         # decoding launches side by side: same pixels
+    assert torch.equal(many[0], one) and torch.equal(many[1], px)
     with pytest.raises(capi.SntcError, match="bf16x3"):
         m32.decompress(blob)
     # and it is close to, but not the same arithmetic as, the fp32 model

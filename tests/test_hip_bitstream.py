@@ -86,6 +86,16 @@ def test_start_tables_do_not_change_a_decoded_value(dev, monkeypatch):
             ec.rans_decode(bad, lens, torch.from_numpy(tids).to(dev), (n, P, c), dt)
     np.testing.assert_array_equal(outs[0].cpu().numpy(), vals)
     assert torch.equal(outs[0], outs[1])
+    # the three decoder-table arguments come together, and within the LDS budget
+    import ctypes as C
+    P = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(dev)
+    out, badc = torch.empty((n, 700, 16), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)
+    common = (P(payload), P(offs), P(torch.from_numpy(tids).to(dev)), n, 700 * 16, 1, 64, P(dt.cdf), P(dt.meta), dt.ntables, dt.total)
+    for dec, lut, lmeta, entries in ((dt.dec, None, dt.lut_meta, dt.lut_total), (None, dt.lut, dt.lut_meta, dt.lut_total),
+                                     (dt.dec, dt.lut, dt.lut_meta, dt.lut_total + 8 * 8192), (dt.dec, dt.lut, dt.lut_meta, dt.lut_total - 1)):
+        with pytest.raises(_capi.SntcError):
+            _capi.call("sntc_rans_decode", *common, P(dec), P(lut), P(lmeta), entries, P(out), P(badc), None)
     # every slot of every table: the start symbol is at or below the slot's symbol, never above
     for (lo, f), bits, lm in zip(tabs, dt.lut_bits, dt.lut_meta.cpu().numpy().view(np.uint32)):
         cdf = np.concatenate([[0], np.cumsum(f)[:-1]])
