@@ -176,6 +176,49 @@ int64_t sntc_resblock_flops(const sntc_resblock_plan* plan, int n, int h, int w)
 int sntc_resblock_forward(const sntc_resblock_plan* plan, const float* x, int n, int h, int w, float* y, void* stream);
 /* Cap the persistent workgroups of THIS plan's launches (0 = one per CU): tests assert that results do not depend on it. */
 int sntc_resblock_plan_set_workgroups(sntc_resblock_plan* plan, int max_workgroups);
+/* ------------------------------------------------------------------------------------------
+ * The first layer of the two-layer syntheses (reference common/transforms.py:298-317 TwoLayerSynthesis, :320-361
+ * TwoLayerResSynthesis) in ONE launch:  hidden = act(base_conv(y_hat)) [+ res(y_hat)]  -- the tensor the reference hands to
+ * its output convolution (:315, :359).  base_conv / res = Conv2DTranspose k x k / stride, SAME (:307-313, :331-338, :351-357);
+ * act_kind as in sntc_two_layer_tail (0 none, 1 IGDN1, 2 GDN1, 3 relu, 4 leaky relu) is base_conv's `activation`.
+ *   w1 [k, k, (1 + has_res) ch, cin]: the Keras transposed kernel(s), the residual branch's concatenated behind the base
+ *   convolution's along the output-channel axis; b1 [(1 + has_res) ch] or NULL; beta [ch], gamma [ch, ch] for act_kind 1 / 2.
+ * Indexed by the output-aligned macro pixel a tap is one of nine whole-pixel shifts of the input: a workgroup walks
+ * (tile of 256 latent pixels) x (unit of 96 output columns) items -- weights through an LDS-DMA ring, the 16-channel
+ * patch slab staged once per slab, every shift a shifted fragment read of it -- dealt dynamically over one workgroup per CU;
+ * the activation and the residual add are applied to the accumulators.  Every output is the same k-ordered fp32 fma chain
+ * (and the same activation arithmetic) as sntc_conv_forward + stage 1 of sntc_two_layer_tail: bit-identical to them, for any
+ * batching.  sntc_syn_supported: 1 where the kernel exists (13 x 13 / 8, 5 x 5 / 2, 3 x 3 / 1 ...: taps within one pixel of
+ * the output-aligned source; (1 + has_res) ch in {12, 24, 48}; cin % 16 == 0), else 0 -- callers then run the layers.
+ * One call takes up to four batches of DIFFERENT image sizes (sntc_syn_batch: y_hat [n, h, w, cin] -> hidden
+ * [n, stride h, stride w, ch]; w <= 127; one image's tensors < 2 GiB): they share the launch's work queue.
+ * workspace >= sntc_syn_workspace_bytes(), private to the call until it has run. */
+typedef struct sntc_syn_plan sntc_syn_plan;
+typedef struct sntc_syn_batch {
+  const float* y_hat;
+  float* hidden;
+  int32_t n, h, w;
+  int32_t reserved;
+} sntc_syn_batch;
+int sntc_syn_supported(int k, int stride, int cin, int ch, int has_res);
+int sntc_syn_plan_create(int k, int stride, int cin, int ch, int has_res, int act_kind, const float* w1, const float* b1,
+                         const float* beta, const float* gamma, void* stream, sntc_syn_plan** plan);
+int sntc_syn_plan_update(sntc_syn_plan* plan, const float* w1, const float* b1, const float* beta, const float* gamma, void* stream);
+void sntc_syn_plan_destroy(sntc_syn_plan* plan);
+/* Algorithmic 2*MAC FLOPs of `latent_pixels` input pixels (all batches of a call): 2 k^2 cin (1 + has_res) ch each. */
+int64_t sntc_syn_flops(const sntc_syn_plan* plan, int64_t latent_pixels);
+int64_t sntc_syn_workspace_bytes(const sntc_syn_plan* plan);
+int sntc_syn_forward(const sntc_syn_plan* plan, const sntc_syn_batch* batches, int nbatches, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* Cap the persistent workgroups of THIS plan's launches (0 = one per CU): tests assert that results do not depend on it. */
+int sntc_syn_plan_set_workgroups(sntc_syn_plan* plan, int max_workgroups);
+/* The plan's units (tests, tools): up to `capacity` records of four ints (shifts per channel slab; phases held | 32-row tile
+ * steps per slab << 8 | mask of the steps that leave the third tile out << 16; the shift list packed four bits per step:
+ * low word, high word); returns the number of units. */
+int sntc_syn_plan_units(const sntc_syn_plan* plan, int* out, int capacity);
+/* Host-only check of the decomposition (no device): units + packed weights driven through the kernel's loop nest on the CPU
+ * against the scatter form of Conv2DTranspose(SAME) on a random h x w input; *max_err = largest absolute difference. */
+int sntc_syn_selfcheck(int k, int stride, int cin, int ch, int has_res, int h, int w, unsigned seed, double* max_err);
 /* Force the gather-GEMM tile variant of THIS plan (0 = back to the heuristic): profiling and the
  * every-variant parity test only; tile choice never changes results beyond fp32 summation order. */
 int sntc_conv_plan_set_tile(sntc_conv_plan* plan, int variant);

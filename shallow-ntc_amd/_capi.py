@@ -36,6 +36,12 @@ class ConvDesc(C.Structure):
                 ("epilogue", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
+class SynBatch(C.Structure):
+    """sntc_syn_batch: one group of same-sized images of a sntc_syn_forward call."""
+    _fields_ = [("y_hat", C.c_void_p), ("hidden", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/sntc.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -63,6 +69,16 @@ SIGNATURES = {
     "sntc_resblock_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_resblock_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_resblock_plan_set_workgroups": (C.c_int, [_P, C.c_int]),
+    "sntc_syn_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sntc_syn_plan_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(_P)]),
+    "sntc_syn_plan_update": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "sntc_syn_plan_destroy": (None, [_P]),
+    "sntc_syn_flops": (C.c_int64, [_P, C.c_int64]),
+    "sntc_syn_workspace_bytes": (C.c_int64, [_P]),
+    "sntc_syn_forward": (C.c_int, [_P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "sntc_syn_plan_set_workgroups": (C.c_int, [_P, C.c_int]),
+    "sntc_syn_plan_units": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
+    "sntc_syn_selfcheck": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double)]),
     "sntc_conv_plan_set_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "sntc_conv_plan_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "sntc_split3": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),

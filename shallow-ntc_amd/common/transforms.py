@@ -406,6 +406,13 @@ class _TwoLayerBase(Transform):
         self._gamma = dv(w["act/gamma"]) if "act/gamma" in w else None
         self._w2 = dv(w[f"{n2}/kernel"])
         self._b2 = dv(w[f"{n2}/bias"])
+        # the first layer, its activation and the residual add in ONE launch (csrc/syn_fused.hip) where the kernel exists:
+        # [base | res] never goes to HBM, the tail kernel then only runs the output layer on the hidden tensor.  fp32 only
+        # (the split-precision mode keeps the pre-split gather GEMM); same bits as the layers.
+        self._syn = None
+        if merged and self._precision == "fp32" and ops.SynPlan.supported(self._k[0], self._s[0], self._cin, self._ch, self._has_res):
+            with torch.cuda.device(device):
+                self._syn = ops.SynPlan(dv(k1), dv(b1), self._s[0], self._ch, self._has_res, self._act_kind, self._beta, self._gamma)
         self.output_channels = self._out_ch
         self._built_on = device
         return self
@@ -437,7 +444,23 @@ class _TwoLayerBase(Transform):
             return self._up(x)
         return ops.concat_channels(self._up(x), self._res_d2s(x))
 
+    def _use_syn(self, x):
+        return self._syn is not None and ops.FUSED_SYNTHESIS and x.dim() == 4 and self._syn.fits(x)
+
+    def hidden_many(self, xs):
+        """act(base_conv(y_hat)) + res(y_hat) for a LIST of batches of different image sizes in one launch (None where the
+        fused kernel does not apply: the caller then takes ``forward_pixels`` per batch)."""
+        if not all(self._use_syn(x) for x in xs) or not 1 <= len(xs) <= 4:
+            return None
+        return self._syn(list(xs))
+
+    def pixels_from_hidden(self, hid, h, w, reference=None):
+        """The output layer on the hidden tensor (+ crop + uint8 + SSE): the tail kernel without activation and residual."""
+        return ops.two_layer_tail_pixels(hid, self._ch, False, 0, None, None, self._w2, self._b2, h, w, reference, self._k[1], self._s[1])
+
     def _forward(self, x):
+        if self._fused and self._use_syn(x):
+            return ops.two_layer_tail(self._syn(x), self._ch, False, 0, None, None, self._w2, self._b2, self._k[1], self._s[1])
         if self._fused:
             return ops.two_layer_tail(self._tail_input(x), self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
                                       self._w2, self._b2, self._k[1], self._s[1])
@@ -448,6 +471,8 @@ class _TwoLayerBase(Transform):
         for the fused shapes in the same launch as the activation and the output layer -- no float image round trip."""
         if self._built_on != x.device:
             self.build(x.shape[-1] if x.dim() == 4 else x.shape[3] * 16, x.device)
+        if self._fused and self._use_syn(x):
+            return self.pixels_from_hidden(self._syn(x), h, w, reference)
         if self._fused:
             return ops.two_layer_tail_pixels(self._tail_input(x), self._ch, self._has_res, self._act_kind, self._beta, self._gamma,
                                              self._w2, self._b2, h, w, reference, self._k[1], self._s[1])

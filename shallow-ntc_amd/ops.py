@@ -193,6 +193,101 @@ class ResBlockPlan:
         return y
 
 
+FUSED_SYNTHESIS = not os.environ.get("SNTC_NO_SYN_FUSE")   # two-layer syntheses: first layer + activation + residual in ONE launch (csrc/syn_fused.hip;
+                                                           # bit-identical; False: phase-grouped gather GEMM + the tail kernel's stage 1)
+
+
+class SynPlan:
+    """The first layer of a two-layer synthesis (reference common/transforms.py:298-361) as one launch: sntc_syn_plan
+    (csrc/syn_fused.hip).  ``w1`` [k, k, (1 + has_res) ch, cin]: the Keras transposed kernel, the convolutional residual
+    branch's concatenated behind the base convolution's on the output-channel axis; ``b1`` likewise or None; ``beta`` [ch],
+    ``gamma`` [ch, ch] for the (I)GDN1 activations (``act_kind`` as ops.TAIL_ACTS)."""
+
+    @staticmethod
+    def supported(k, stride, cin, ch, has_res):
+        return FUSED_SYNTHESIS and bool(capi.load().sntc_syn_supported(int(k), int(stride), int(cin), int(ch), int(bool(has_res))))
+
+    def __init__(self, w1, b1, stride, ch, has_res, act_kind, beta=None, gamma=None):
+        capi.require_gpu()
+        self.k, self.stride, self.ch, self.has_res, self.act_kind = int(w1.shape[0]), int(stride), int(ch), bool(has_res), int(act_kind)
+        self.cin = int(w1.shape[3])
+        if tuple(w1.shape) != (self.k, self.k, ch * (2 if has_res else 1), self.cin):
+            raise ValueError(f"synthesis kernel {tuple(w1.shape)} does not match ch = {ch}, has_res = {has_res}")
+        ts = [None if t is None else t.contiguous() for t in (w1, b1, beta, gamma)]
+        self._h = C.c_void_p()
+        capi.call("sntc_syn_plan_create", self.k, self.stride, self.cin, self.ch, int(self.has_res), self.act_kind,
+                  *[_ptr(t) for t in ts], _stream(), C.byref(self._h))
+        torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
+        self._ws = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_syn_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def update(self, w1, b1, beta=None, gamma=None):
+        capi.call("sntc_syn_plan_update", self._h, *[_ptr(t) for t in (w1, b1, beta, gamma)], _stream())
+
+    def set_workgroups(self, n):
+        """Cap the persistent workgroups of this plan's launches (0: one per CU); tests: identical bits for any value."""
+        capi.call("sntc_syn_plan_set_workgroups", self._h, int(n))
+
+    def units(self):
+        """[(shifts per channel slab, phases held, 32-row tile steps per slab, partial-step mask, [shift indices])] of the plan's
+        units, in processing order."""
+        buf = (C.c_int * (4 * 128))()
+        n = int(capi.load().sntc_syn_plan_units(self._h, buf, 128))
+        out = []
+        for i in range(n):
+            ns, word, lo, hi = buf[4 * i], buf[4 * i + 1], buf[4 * i + 2] & 0xffffffff, buf[4 * i + 3] & 0xffffffff
+            out.append((ns, word & 255, (word >> 8) & 255, (word >> 16) & 0xffff,
+                        [((lo >> (4 * j)) if j < 8 else (hi >> (4 * (j - 8)))) & 15 for j in range(ns)]))
+        return out
+
+    def flops(self, latent_pixels):
+        return int(capi.load().sntc_syn_flops(self._h, int(latent_pixels)))
+
+    def fits(self, x):
+        """Whether this call shape is inside the kernel's limits (latent rows of at most 127 pixels, one image < 2 GiB)."""
+        n, h, w, c = x.shape
+        return w <= 127 and h * w * max(c, self.stride * self.stride * self.ch) * 4 < (1 << 31)
+
+    def __call__(self, xs):
+        """``xs``: one y_hat tensor [n, h, w, cin] or a list of up to four of DIFFERENT image sizes (one launch for all of
+        them) -> the hidden tensor(s) [n, stride h, stride w, ch]."""
+        single = torch.is_tensor(xs)
+        xs = [xs] if single else list(xs)
+        if not 1 <= len(xs) <= 4:
+            raise ValueError("1 .. 4 batches per call")
+        outs = []
+        arr = (capi.SynBatch * len(xs))()
+        px = 0
+        for i, x in enumerate(xs):
+            _check_nhwc(x, self.cin)
+            n, h, w, _ = x.shape
+            y = torch.empty((n, h * self.stride, w * self.stride, self.ch), dtype=torch.float32, device=x.device)
+            outs.append(y)
+            arr[i].y_hat, arr[i].hidden, arr[i].n, arr[i].h, arr[i].w = x.data_ptr(), y.data_ptr(), n, h, w
+            px += n * h * w
+        dev = xs[0].device
+        ws = torch.empty((64,), dtype=torch.int32, device=dev)     # the launch's work queue: private to this call
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        capi.call("sntc_syn_forward", self._h, arr, len(xs), _ptr(ws), 256, _stream())
+        if prof is not None:
+            e1.record()
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(px), variant=0, nblocks=0, vec=True, kind="synthesis", k=self.k,
+                             s=self.stride, cin=self.cin, cout=self.ch * (2 if self.has_res else 1), n=sum(x.shape[0] for x in xs),
+                             h=xs[0].shape[1], w=xs[0].shape[2]))
+        return outs[0] if single else outs
+
+
 def to_device(a, device):
     """Host array -> float32 device tensor (weights, images)."""
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)

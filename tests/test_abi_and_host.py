@@ -231,3 +231,28 @@ def test_parity_prose_is_rendered_from_the_committed_reports():
     import subprocess
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "parity_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("k,s,cin,ch,res,h,w", [
+    (13, 8, 32, 12, 1, 5, 7), (13, 8, 16, 24, 0, 6, 4), (13, 8, 16, 12, 0, 4, 9), (13, 8, 16, 48, 0, 3, 5), (13, 8, 16, 24, 1, 7, 3),
+    (5, 2, 32, 12, 1, 6, 5), (3, 1, 16, 24, 0, 5, 6), (6, 4, 16, 12, 0, 4, 4), (16, 16, 16, 12, 0, 3, 2), (13, 8, 32, 12, 1, 20, 19)])
+def test_fused_synthesis_decomposition_on_the_host(k, s, cin, ch, res, h, w):
+    """csrc/syn_fused.hip's units, shift lists, slot -> phase map and packed weights, driven through the kernel's loop nest on the
+    CPU (sntc_syn_selfcheck: no device involved), reproduce Conv2DTranspose(SAME) (reference common/transforms.py:307-313,
+    :331-338): every output pixel is produced by exactly one (unit, slot), and the values agree exactly."""
+    import ctypes as C
+    from shallow_ntc_amd import _capi as capi
+    lib = capi.load()
+    assert lib.sntc_syn_supported(k, s, cin, ch, res) == 1
+    err = C.c_double(-1.0)
+    capi.check(lib.sntc_syn_selfcheck(k, s, cin, ch, res, h, w, 1234, C.byref(err)))
+    assert 0.0 <= err.value < 1e-9
+
+
+def test_fused_synthesis_refuses_what_it_does_not_cover():
+    from shallow_ntc_amd import _capi as capi
+    lib = capi.load()
+    assert lib.sntc_syn_supported(18, 16, 320, 3, 0) == 0       # JPEG-like synthesis: 3 columns per phase
+    assert lib.sntc_syn_supported(13, 8, 24, 12, 1) == 0        # input channels not a multiple of 16
+    assert lib.sntc_syn_supported(29, 8, 32, 12, 1) == 0        # taps further than one pixel from the aligned source
+    assert lib.sntc_syn_supported(13, 8, 320, 12, 1) == 1 and lib.sntc_syn_supported(13, 8, 320, 24, 0) == 1
