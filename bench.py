@@ -160,6 +160,10 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="decode the batches of the set on this many HIP streams at once (0 = one per batch shape): the tail of "
                          "one batch's kernels is filled by the other's blocks; 1 = serial on the current stream")
+    ap.add_argument("--set-decode", action="store_true",
+                    help="A/B: Model.decode_set (the hyper-syntheses of the batch shapes side by side, then ONE synthesis launch for all "
+                         "of them) instead of one Model.decode per batch shape on its own stream (measured: the join in front of the "
+                         "shared launch costs more overlap than the launch saves: 3.39 against 3.16 ms per step)")
     ap.add_argument("--chunk", type=int, default=0, help="split every batch shape into sub-batches of at most this many images (0 = no split)")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
@@ -277,7 +281,15 @@ def main():
             cur.wait_stream(st)
         return outs
 
-    if not args.graph:
+    def decode_set_step():
+        """All batches of the set through Model.decode_set: hyper-syntheses side by side on one stream per batch, the synthesis of
+        every batch in ONE launch (per-image geometry in the kernel), output layers per batch."""
+        return model.decode_set([(z_hat, sym, hw) for z_hat, sym, hw, _x in codes], check=False)
+
+    set_decode = args.set_decode and args.streams == 0 and 2 <= len(codes) <= 4
+    if set_decode:
+        decode_step = decode_set_step
+    elif not args.graph:
         decode_step = decode_streams if nstreams > 1 and len(codes) > 1 else decode_eager
     else:                                  # one captured HIP graph per batch shape, replayed every step
         from shallow_ntc_amd.graphs import DecodeGraph
@@ -575,6 +587,8 @@ def main():
                     name = name[:-1] + ", true>"
                 if e["variant"] >= 11:                                      # the pre-split bf16 x 3 kernel (csrc/bf3_gemm.hip)
                     name = f"bf3_kernel<4, 2, 2, {4 if e['variant'] == 11 else 2}>"
+                if e["kind"] == "synthesis":                                # the fused two-layer synthesis (csrc/syn_fused.hip)
+                    name = f"syn_kernel<{e['cout']}, {'true' if e['cout'] > 12 and e['cout'] % 24 == 0 and model._synthesis._has_res else 'false'}>"
                 if e["kind"] == "resblock":                                 # the whole ResidualBlock in one launch (csrc/rb_fused.hip)
                     name = f"rb_kernel<{e['cin']}>"
                 if e["kind"] == "resblock3":                                # ... in bf16 x 3 (csrc/rb_fused_bf3.hip)
@@ -701,7 +715,8 @@ def main():
                                  "random-init weights", images_per_gpu=len(shapes), parallelism=f"dp{world}",
                         timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels",
                         launch="hipGraph replay (one graph per batch shape)" if args.graph else
-                        (f"eager, {min(nstreams, len(codes))} concurrent streams (one per batch)" if nstreams > 1 and len(codes) > 1 else "eager"),
+                        ("eager, Model.decode_set: hyper-syntheses of the batch shapes on concurrent streams, one synthesis launch for all" if set_decode else
+                         f"eager, {min(nstreams, len(codes))} concurrent streams (one per batch)" if nstreams > 1 and len(codes) > 1 else "eager"),
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))",
                         launch_schedule="cost model" if args.no_autotune else
                         f"measured once per layer shape before the timed regions (sntc_conv_plan_tune, {tune_seconds[0]:.1f} s untimed; "

@@ -444,13 +444,15 @@ class _TwoLayerBase(Transform):
             return self._up(x)
         return ops.concat_channels(self._up(x), self._res_d2s(x))
 
-    def _use_syn(self, x):
-        return self._syn is not None and ops.FUSED_SYNTHESIS and x.dim() == 4 and self._syn.fits(x)
+    def _use_syn(self, x, alone=True):
+        ok = self._syn is not None and ops.FUSED_SYNTHESIS and x.dim() == 4 and self._syn.fits(x)
+        return ok and (not alone or self._syn.items([x]) >= ops.FUSED_SYNTHESIS_MIN_ITEMS)
 
     def hidden_many(self, xs):
         """act(base_conv(y_hat)) + res(y_hat) for a LIST of batches of different image sizes in one launch (None where the
         fused kernel does not apply: the caller then takes ``forward_pixels`` per batch)."""
-        if not all(self._use_syn(x) for x in xs) or not 1 <= len(xs) <= 4:
+        if not 1 <= len(xs) <= 4 or not all(self._use_syn(x, alone=False) for x in xs) \
+                or self._syn.items(xs) < ops.FUSED_SYNTHESIS_MIN_ITEMS:
             return None
         return self._syn(list(xs))
 

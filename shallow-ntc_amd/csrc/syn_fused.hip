@@ -517,49 +517,65 @@ __global__ void __launch_bounds__(512, 2) syn_kernel(const SynArgs a) {
       const float* bias = tab;
       const float* beta = tab + CP;
       const float* gamma = tab + CP + CH;
-      // Two phases at a time where the lane half holds an even number (the two-element vector operations are the same
-      // IEEE multiply and add per element as the scalar ones, half the instructions: the epilogue is VALU-issue bound).
-      constexpr int PW = SPH % 2 == 0 ? 2 : 1;
-      typedef float fpw __attribute__((ext_vector_type(PW == 2 ? 2 : 1)));
+      // One phase at a time, the norm pool two output channels at a time: nrm[j], nrm[j + 1] += |t_i| * (gamma[i][j], gamma[i][j + 1])
+      // -- the gamma pair is one LDS read (a broadcast: every lane reads the same address), the two-element multiply and add are
+      // the same IEEE operations per element as the scalar ones (separately rounded: this file is built -ffp-contract=off), in
+      // the order of pixel.hip's tail (i ascending for every j).  The epilogue is VALU-issue bound (two waves per SIMD are in it
+      // at once), so instructions are what counts.
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const int act = a.act_kind;
 #pragma unroll
-      for (int sl = 0; sl < SPH; sl += PW) {
-        fpw tv[CP];
+      for (int sl = 0; sl < SPH; ++sl) {
+        float tv[CP];
 #pragma unroll
-        for (int c = 0; c < CP; ++c)
-#pragma unroll
-          for (int q = 0; q < PW; ++q) {
-            const int vi = (sl + q) * CP + c;
-            tv[c][q] = acc[vi >> 4][vi & 15] + bias[c];
-          }
-        fpw o[CH];
-#pragma unroll
-        for (int jc = 0; jc < CH; ++jc) {
-          fpw r = tv[jc];
-          if (a.act_kind == 1 || a.act_kind == 2) {
-            fpw nrm = beta[jc];
-#pragma unroll
-            for (int ic = 0; ic < CH; ++ic) nrm += __builtin_elementwise_abs(tv[ic]) * gamma[ic * CH + jc];
-            r = a.act_kind == 1 ? tv[jc] * nrm : tv[jc] / nrm;
-          } else if (a.act_kind == 3) {
-#pragma unroll
-            for (int q = 0; q < PW; ++q) r[q] = fmaxf(r[q], 0.0f);
-          } else if (a.act_kind == 4) {
-#pragma unroll
-            for (int q = 0; q < PW; ++q) r[q] = r[q] >= 0.0f ? r[q] : 0.2f * r[q];
-          }
-          if (RES) r = r + tv[CH + jc];
-          o[jc] = r;
+        for (int c = 0; c < CP; ++c) {
+          const int vi = sl * CP + c;
+          tv[c] = acc[vi >> 4][vi & 15] + bias[c];
         }
+        float o[CH];
+        if (act == 1 || act == 2) {
+          float av[CH];
 #pragma unroll
-        for (int q = 0; q < PW; ++q) {
-          const unsigned ph0 = up->ph[sl + q], ph1 = up->ph[SPH + sl + q];
-          const unsigned ph = h ? ph1 : ph0;
-          const int ry = (int)(ph >> 8), rx = (int)(ph & 255u);
-          const bool ok = pvalid && ph != 0xffffffffu;
-          const unsigned off = ok ? (unsigned)(((qy * a.s + ry) * Wo + qx * a.s + rx) * (CH * 4)) : kOOB;
+          for (int ic = 0; ic < CH; ++ic) av[ic] = fabsf(tv[ic]);
+          f32x2 nrm[CH / 2];
 #pragma unroll
-          for (int c4 = 0; c4 < CH; c4 += 4) buf_store(vs, f32x4{o[c4][q], o[c4 + 1][q], o[c4 + 2][q], o[c4 + 3][q]}, off, c4 * 4);
+          for (int jp = 0; jp < CH / 2; ++jp) nrm[jp] = *reinterpret_cast<const f32x2*>(beta + 2 * jp);
+#pragma unroll
+          for (int ic = 0; ic < CH; ++ic)
+#pragma unroll
+            for (int jp = 0; jp < CH / 2; ++jp) {
+              const f32x2 g = *reinterpret_cast<const f32x2*>(gamma + ic * CH + 2 * jp);
+              const f32x2 pr = g * av[ic];
+              nrm[jp] = nrm[jp] + pr;
+            }
+          if (act == 1) {
+#pragma unroll
+            for (int jc = 0; jc < CH; ++jc) o[jc] = tv[jc] * nrm[jc >> 1][jc & 1];
+          } else {
+#pragma unroll
+            for (int jc = 0; jc < CH; ++jc) o[jc] = tv[jc] / nrm[jc >> 1][jc & 1];
+          }
+        } else if (act == 3) {
+#pragma unroll
+          for (int jc = 0; jc < CH; ++jc) o[jc] = fmaxf(tv[jc], 0.0f);
+        } else if (act == 4) {
+#pragma unroll
+          for (int jc = 0; jc < CH; ++jc) o[jc] = tv[jc] >= 0.0f ? tv[jc] : 0.2f * tv[jc];
+        } else {
+#pragma unroll
+          for (int jc = 0; jc < CH; ++jc) o[jc] = tv[jc];
         }
+        if (RES) {
+#pragma unroll
+          for (int jc = 0; jc < CH; ++jc) o[jc] = o[jc] + tv[CH + jc];
+        }
+        const unsigned ph0 = up->ph[sl], ph1 = up->ph[SPH + sl];
+        const unsigned ph = h ? ph1 : ph0;
+        const int ry = (int)(ph >> 8), rx = (int)(ph & 255u);
+        const bool ok = pvalid && ph != 0xffffffffu;
+        const unsigned off = ok ? (unsigned)(((qy * a.s + ry) * Wo + qx * a.s + rx) * (CH * 4)) : kOOB;
+#pragma unroll
+        for (int c4 = 0; c4 < CH; c4 += 4) buf_store(vs, f32x4{o[c4], o[c4 + 1], o[c4 + 2], o[c4 + 3]}, off, c4 * 4);
       }
     }
     if (!more) break;

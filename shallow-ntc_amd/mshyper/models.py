@@ -541,6 +541,50 @@ class Model:
                 ops.check_conv_status()
             return out
 
+    def decode_set(self, codes, check=True):
+        """``decode`` for a SET of batches of different image sizes (the Kodak set's two orientations): ``codes`` =
+        [(z_hat, symbols, image_hw[, reference])] -> the list of what ``decode`` returns for each.  The hyper-syntheses and
+        dequantisations of the batches run side by side on one stream per batch; a two-layer synthesis then takes ALL batches
+        in ONE launch (common/transforms.py ``hidden_many``: per-image geometry inside the kernel), and the output layers
+        follow per batch.  Same pixels as one ``decode`` per batch."""
+        codes = [tuple(c) + (None,) * (4 - len(c)) for c in codes]
+        syn = self._synthesis
+        if len(codes) < 2 or len(codes) > 4 or not hasattr(syn, "hidden_many") or self._synthesis.takes_s3(*codes[0][1].shape[1:3]):
+            return [self.decode(z, s, hw, reference=r, check=check) for z, s, hw, r in codes]
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_set_streams", None) is None or len(self._set_streams) < len(codes):
+                self._set_streams = [torch.cuda.Stream(device=self.device) for _ in codes]
+            y_hats = []
+            for st, (z_hat, sym, _hw, _r) in zip(self._set_streams, codes):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    y_hat = ops.dequant_scale_normal(sym, self._hyper_synthesis(z_hat))
+                y_hat.record_stream(cur)
+                y_hats.append(y_hat)
+            for st in self._set_streams[:len(codes)]:
+                cur.wait_stream(st)
+            hidden = syn.hidden_many(y_hats)
+            outs = []
+            if hidden is None:
+                for y_hat, (_z, _s, hw, ref) in zip(y_hats, codes):
+                    outs.append(self._pixels(y_hat, hw, ref))
+            else:
+                for st, hid, (_z, _s, hw, ref) in zip(self._set_streams, hidden, codes):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        px, sse = syn.pixels_from_hidden(hid, hw[0], hw[1], ref)
+                    hid.record_stream(st)
+                    px.record_stream(cur)
+                    if sse is not None:
+                        sse.record_stream(cur)
+                    outs.append(px if ref is None else (px, sse))
+                for st in self._set_streams[:len(codes)]:
+                    cur.wait_stream(st)
+            if check:
+                ops.check_conv_status()
+            return outs
+
     def _pixels(self, y_hat, image_hw, reference=None):
         """synthesis -> unpad -> floats_to_pixels -> quantize_image (reference :297-317) as uint8 [n, H, W, 3], plus the
         per-image integer SSE when ``reference`` is given.  The two-layer syntheses emit the pixels from their last

@@ -193,6 +193,7 @@ class ResBlockPlan:
         return y
 
 
+FUSED_SYNTHESIS_MIN_ITEMS = 512   # ... where the launch offers about two items per CU (speed only: the same bits either way)
 FUSED_SYNTHESIS = not os.environ.get("SNTC_NO_SYN_FUSE")   # two-layer syntheses: first layer + activation + residual in ONE launch (csrc/syn_fused.hip;
                                                            # bit-identical; False: phase-grouped gather GEMM + the tail kernel's stage 1)
 
@@ -218,7 +219,7 @@ class SynPlan:
         capi.call("sntc_syn_plan_create", self.k, self.stride, self.cin, self.ch, int(self.has_res), self.act_kind,
                   *[_ptr(t) for t in ts], _stream(), C.byref(self._h))
         torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
-        self._ws = {}
+        self._nunits = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -255,6 +256,13 @@ class SynPlan:
         """Whether this call shape is inside the kernel's limits (latent rows of at most 127 pixels, one image < 2 GiB)."""
         n, h, w, c = x.shape
         return w <= 127 and h * w * max(c, self.stride * self.stride * self.ch) * 4 < (1 << 31)
+
+    def items(self, xs):
+        """Work items (256-pixel tiles x units) of a call on these batches: below FUSED_SYNTHESIS_MIN_ITEMS the launch cannot
+        fill the device (one workgroup per CU, an item is 25 - 100 us) and the layers' small tiles are faster."""
+        if self._nunits is None:
+            self._nunits = len(self.units())
+        return sum(int(x.shape[0]) * (-(-int(x.shape[1]) * int(x.shape[2]) // 256)) for x in xs) * self._nunits
 
     def __call__(self, xs):
         """``xs``: one y_hat tensor [n, h, w, cin] or a list of up to four of DIFFERENT image sizes (one launch for all of

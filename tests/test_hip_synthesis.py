@@ -130,3 +130,31 @@ def test_decoded_pixels_do_not_change(cfg_name, hw, dev):
     finally:
         ops.FUSED_SYNTHESIS = True
     assert torch.equal(px, px0) and torch.equal(sse, sse0)
+
+
+def test_decode_set_equals_one_decode_per_batch(dev):
+    """Model.decode_set (hyper-syntheses side by side, ONE synthesis launch for batches of different sizes, output layers per
+    batch) returns exactly what Model.decode returns for each batch -- pixels and SSE; repeated calls included."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.01))
+    rng = np.random.default_rng(8)
+    codes = []
+    for n, hw in ((3, (256, 384)), (2, (384, 256)), (1, (200, 120))):
+        x = dev_t(rng.uniform(-0.5, 0.5, (n,) + hw + (3,)), dev)
+        z_hat, sym, _, _ = model.encode(x)
+        codes.append((z_hat, sym, hw, x))
+    want = [model.decode(z, s, hw, reference=x) for z, s, hw, x in codes]
+    old_min = ops.FUSED_SYNTHESIS_MIN_ITEMS
+    ops.FUSED_SYNTHESIS_MIN_ITEMS = 1                     # small images: take the fused launch anyway
+    try:
+        for _ in range(3):
+            got = model.decode_set(codes)
+            for (px, sse), (px0, sse0) in zip(got, want):
+                assert torch.equal(px, px0) and torch.equal(sse, sse0)
+        plain = model.decode_set([c[:3] for c in codes])
+        for px, (px0, _) in zip(plain, want):
+            assert torch.equal(px, px0)
+    finally:
+        ops.FUSED_SYNTHESIS_MIN_ITEMS = old_min
