@@ -34,6 +34,9 @@ def itinf_on_data_batch(train_eval_config, train_writer, val_writer, model, data
         step += 1
         if eval_every > 0 and step % eval_every == 0 and step < num_steps:
             evaluate_fn(step)
+    # the reference's step runs check_numerics every step (mshyper/models.py:308-309,356); here the unlogged steps leave their
+    # scalars on the device, so the last step's loss and the launch status are checked once more before anything is returned
+    model.itinf_last_metrics()
     if eval_every > 0:                                         # :86-90
         evaluate_fn(step)
     lat = model.latent_rvs                                     # :92 the optimised variables as arrays

@@ -599,11 +599,15 @@ def import_tuning(entries):
     """Apply another rank's ``export_tuning()``; a plan whose (kind, cin, cout) does not match the entry's is a job whose ranks
     built different models: refused loudly."""
     for idx, kind, cin, cout, n, h, w, v, sk in entries:
-        p = _PLAN_REGISTRY[idx]() if idx < len(_PLAN_REGISTRY) else None
-        if p is None or (p.kind, p.cin, p.cout) != (kind, cin, cout):
-            raise capi.SntcError(capi.ERR_BAD_SHAPE, f"import_tuning: plan {idx} here is "
-                                 f"{None if p is None else (p.kind, p.cin, p.cout)}, the entry was measured on {(kind, cin, cout)}: "
-                                 "the ranks did not build the same plans in the same order")
+        if idx >= len(_PLAN_REGISTRY):
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, f"import_tuning: plan {idx} does not exist here ({len(_PLAN_REGISTRY)} plans "
+                                 "were built): the ranks did not build the same plans in the same order")
+        p = _PLAN_REGISTRY[idx]()
+        if p is None:
+            continue        # collected here already (the cyclic collector runs at different times on different ranks): nothing to tune
+        if (p.kind, p.cin, p.cout) != (kind, cin, cout):
+            raise capi.SntcError(capi.ERR_BAD_SHAPE, f"import_tuning: plan {idx} here is {(p.kind, p.cin, p.cout)}, the entry was "
+                                 f"measured on {(kind, cin, cout)}: the ranks did not build the same plans in the same order")
         p.set_choice(n, h, w, v, sk)
 
 

@@ -392,6 +392,16 @@ def gdn_effective(raw, minimum):
     return (np.maximum(np.asarray(raw, np.float64), math.sqrt(minimum + pedestal)) ** 2 - pedestal).astype(np.float32)
 
 
+def checkpoints_to_keep(age, current, max_to_keep):
+    """tf.train.CheckpointManager(max_to_keep=N) retention (reference common/train_lib.py:124-126): the checkpoint just written
+    (step ``current``) always stays, next to the N - 1 most RECENT others.  ``age``: {step: modification time} of the bundles in
+    the directory (``current`` may or may not be among them).  Returns the surviving steps, oldest first, ``current`` last."""
+    others = sorted((k for k in age if k != current), key=lambda k: (age[k], k))
+    nkeep = max(1, int(max_to_keep)) - 1                       # survivors besides the checkpoint just written
+    keep = others[max(0, len(others) - nkeep):] if nkeep > 0 else []      # (a negative slice start would count from the end)
+    return keep + [current]
+
+
 class Trainer:
     """Owns the training state of a mean-scale hyperprior ``Model`` and runs ``train_step``."""
 
@@ -779,9 +789,7 @@ class Trainer:
         age = {}
         for f, k in files:
             age[k] = max(age.get(k, 0.0), f.stat().st_mtime)
-        others = sorted((k for k in age if k != self.step_count), key=lambda k: (age[k], k))
-        keep = others[len(others) - (max(1, int(max_to_keep)) - 1):] if max_to_keep > 1 else []
-        keep = keep + [self.step_count]
+        keep = checkpoints_to_keep(age, self.step_count, max_to_keep)
         state = f'model_checkpoint_path: "{name}"\n' + "".join(f'all_model_checkpoint_paths: "ckpt-{k}"\n' for k in keep)
         tmp = ckdir / "checkpoint.tmp"
         tmp.write_text(state)

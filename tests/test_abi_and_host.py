@@ -256,3 +256,21 @@ def test_fused_synthesis_refuses_what_it_does_not_cover():
     assert lib.sntc_syn_supported(13, 8, 24, 12, 1) == 0        # input channels not a multiple of 16
     assert lib.sntc_syn_supported(29, 8, 32, 12, 1) == 0        # taps further than one pixel from the aligned source
     assert lib.sntc_syn_supported(13, 8, 320, 12, 1) == 1 and lib.sntc_syn_supported(13, 8, 320, 24, 0) == 1
+
+
+@pytest.mark.parametrize("n_keep", [1, 2, 4, 5])
+def test_checkpoint_retention_keeps_the_newest_n(n_keep):
+    """tf.train.CheckpointManager(max_to_keep=N) (reference common/train_lib.py:124-126) over a run of saves: after every save the
+    newest min(N, saves so far) checkpoints exist, the one just written among them (N >= 4 used to drop checkpoints early: a
+    negative slice start)."""
+    from shallow_ntc_amd.train import checkpoints_to_keep
+    on_disk = {}
+    for i, step in enumerate(range(3, 33, 3)):
+        keep = checkpoints_to_keep(dict(on_disk), step, n_keep)
+        on_disk[step] = float(i)
+        on_disk = {k: v for k, v in on_disk.items() if k in keep}
+        want = list(range(3, step + 1, 3))[-n_keep:]
+        assert keep == want and sorted(on_disk) == want
+    # recency, not step number: a stale bundle with a higher step goes first
+    assert checkpoints_to_keep({99: 0.0, 6: 5.0, 9: 6.0}, 12, 3) == [6, 9, 12]
+    assert checkpoints_to_keep({99: 0.0}, 12, 1) == [12]

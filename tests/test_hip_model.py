@@ -268,3 +268,26 @@ def test_smoke_entry_point_runs(dev):
     MS-SSIM pyramid does not fit, the metric is skipped rather than raised)."""
     import __graft_entry__ as graft
     graft.smoke()
+
+
+@pytest.mark.parametrize("hw", [(128, 192), (512, 768)])
+def test_attention_branches_on_two_streams_do_not_change_a_bit(hw, dev):
+    """SimpleAttention (reference common/elic.py:85-100) runs trunk and branch on two streams where the launches are small
+    (ops.CONCURRENT_BRANCHES: one image at 1/4 and 1/16 resolution).  Same kernels, same bits as the one-stream order, and no
+    stream-K hand-off of the two launches in flight at once ever times out -- over many repetitions."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.common import transforms as T
+    t = T.class_builder.build("ElicAnalysis", channels=(192, 192, 192, 320))
+    t.build(3, dev)
+    rng = np.random.default_rng(21)
+    x = torch.from_numpy(rng.uniform(-0.5, 0.5, (1,) + hw + (3,)).astype(np.float32)).to(dev)
+    assert ops.CONCURRENT_BRANCHES
+    ops.CONCURRENT_BRANCHES = False
+    try:
+        want = t(x)
+    finally:
+        ops.CONCURRENT_BRANCHES = True
+    ops.check_conv_status()
+    for _ in range(25):
+        assert torch.equal(t(x), want)
+    ops.check_conv_status()                    # raises if a hand-off timed out (and would switch stream-K off for the process)
