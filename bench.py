@@ -339,6 +339,8 @@ def main():
     def e2e_step():
         return on_streams(e2e_one)
 
+    rank_walls = []
+
     def timed(fn, steps, warmup, stats=None):
         """The contract's timing: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
         torch.cuda.synchronize() on both sides, MAX over ranks of the wall time.  ``stats`` (a dict) additionally receives
@@ -358,7 +360,10 @@ def main():
                 evs[i + 1].record()
         torch.cuda.synchronize()
         D.barrier()
-        wall = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        mine = time.perf_counter() - t0
+        wall = D.max_over_ranks(mine, device=dev)
+        if stats is None:                      # the headline region: every rank's own time travels with the maximum
+            rank_walls[:] = D.all_ranks(mine, device=dev)
         ops.check_conv_status()         # the timed steps deferred their stream-K health check (check=False): raise here, not a wrong number
         if evs:
             per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
@@ -422,6 +427,7 @@ def main():
         tune(w1_step)
     t_dec = timed(decode_step, args.steps, args.warmup)                 # the headline: exactly --steps steps after --warmup
     ms_per_step = 1e3 * t_dec / args.steps
+    ms_by_rank = [round(1e3 * w / args.steps, 4) for w in rank_walls]   # each rank's own clock over the same K steps (value uses the max)
     value = world * pixels_per_step * args.steps / t_dec / 1e6
     e2e_value, table = None, None
 
@@ -621,6 +627,9 @@ def main():
         roofline = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         traffic_source=traffic_src, traffic_stale=traffic_stale,
+                        frac_step=regions["decode"]["roofline"]["frac_of_fp32_mfma_peak"],
+                        frac_step_note="the whole decode step against the same peak: all convolution FLOPs of a step / the step's measured time "
+                                       "(regions.decode.roofline) -- `frac` describes the dominant kernel's launches only",
                         avg_launch_ms=round(k["ms"] / k["launches"], 4), launches_per_step=k["launches"] // 3,
                         precision="fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                         note=("dominant kernel by GPU time of the decode step; since round 4 the 480->640 hyper-synthesis launch runs on the "
@@ -706,7 +715,7 @@ def main():
         line = dict(
             metric="decode Mpixels/s + (bpp, PSNR) on Kodak, two_layer_syn",
             value=round(value, 2), unit="Mpixel/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-            ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+            ms_per_step=round(ms_per_step, 4), ms_per_step_by_rank=ms_by_rank, higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype="f32", data="synthetic",
             config=dict(workload=f"mshyper/configs/two_layer_syn.py (ElicAnalysis 192,192,192,320 + TwoLayerResSynthesis 12,3), "
                                  + (f"W1 synthetic batch per GPU ({len(shapes)} x 256x256), " if args.workload == "w1" else

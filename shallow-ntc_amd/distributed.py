@@ -94,6 +94,18 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def all_ranks(value, device="cpu"):
+    """Every rank's ``value`` as a list in rank order, on every rank (one all_gather of a float64): the per-rank step times an
+    N-GPU bench line carries so that a skewed rank is visible next to the maximum."""
+    if not dist.is_initialized():
+        return [float(value)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def share_from_rank0(obj):
     """Rank 0's ``obj`` on every rank (one ``all_gather_object``; the payloads here are a few KB of schedule choices)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -408,7 +408,11 @@ class ConvPlan:
         return ho.value, wo.value
 
     def flops(self, n, h, w):
-        return int(capi.load().sntc_conv_flops(self._h, n, h, w))
+        """Algorithmic 2 * MAC FLOPs of a call.  A plan whose input channels were zero-padded by its owner (the SGA adjoint of the
+        two-layer synthesis pads 24 gradient channels to 32 for the vector loader) counts the REAL channels only."""
+        f = int(capi.load().sntc_conv_flops(self._h, n, h, w))
+        alg = getattr(self, "algorithmic_cin", None)
+        return f if alg is None else f * int(alg) // self.cin
 
     def launch_info(self, n, h, w):
         v, nb = C.c_int(), C.c_int()

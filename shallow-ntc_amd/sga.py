@@ -105,6 +105,7 @@ class TwoLayerBackward:
         k1p = np.zeros(k1.shape[:2] + (self.cp, k1.shape[3]), np.float32)
         k1p[:, :, :c2] = k1
         self.up_adj = ops.ConvPlan("conv", ops.to_device(k1p, dev), None, t._s[0])
+        self.up_adj.algorithmic_cin = c2                  # the zero-padded gradient channels are not work (ConvPlan.flops)
 
     def forward(self, x):
         t = self.t

@@ -29,6 +29,7 @@ def _worker(rank, world, port, num_items, q):
     rows = np.array([[i + 0.25, 30.0 + i, 100.0 - i] for i in idx], np.float64).reshape(len(idx), 3)
     table = D.gather_rows(rows, idx, num_items)
     t = D.max_over_ranks(1.0 + rank)
+    assert D.all_ranks(1.0 + rank) == [1.0 + r for r in range(world)]      # every rank's own step time, in rank order, on every rank
     D.barrier()
     q.put((rank, table, t, idx))
     import torch.distributed as dist

@@ -447,3 +447,29 @@ def test_tuned_schedule_is_a_speed_choice_only(dev):
     assert v in (11, 12) and torch.equal(ps(xs), before)
     torch.cuda.synchronize()
     ops.check_conv_status()
+
+
+def test_counted_flops_are_the_reference_tables(kodak_model, dev):
+    """What bench.py divides by the measured time (ops.PROFILE: the algorithmic 2 * MAC count of every convolution launch) is
+    the reference's own FLOPs per pixel (results/all_fpp.csv:3-4, tests/golden/published_rows.json) times the pixels: decode
+    g_h + g = 41,031.7 (the TF profiler's figure includes bias / activation adds: within 1 %), encode f + f_h + g_h =
+    510,564 + 13,452 + 30,355; and the SGA adjoint of the synthesis counts its 24 real gradient channels, not the 32 it pads to."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.common import data_lib
+    m = kodak_model
+    x = t(data_lib.normalize_image(data_lib.synthetic_images(2, 512, 768, seed=5)), dev)
+    px = 2 * 512 * 768
+    ops.PROFILE = []
+    try:
+        z_hat, sym, _, _ = m.encode(x)
+        enc = sum(e["flops"] for e in ops.PROFILE)
+        ops.PROFILE = []
+        m.decode(z_hat, sym, (512, 768))
+        dec = sum(e["flops"] for e in ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+    assert abs(dec / px / 41031.69 - 1) < 0.01
+    assert abs(enc / px / (510563.75 + 13451.64 + 30354.69) - 1) < 0.01
+    from shallow_ntc_amd.sga import TwoLayerBackward
+    bw = TwoLayerBackward(m._synthesis)
+    assert bw.up_adj.cin == 32 and bw.up_adj.flops(1, 256, 384) == 2 * 32 * 48 * 169 * 24 * 320
