@@ -593,6 +593,8 @@ def main():
                     name = name[:-1] + ", true>"
                 if e["variant"] >= 11:                                      # the pre-split bf16 x 3 kernel (csrc/bf3_gemm.hip)
                     name = f"bf3_kernel<4, 2, 2, {4 if e['variant'] == 11 else 2}>"
+                if e["kind"] == "tail":                                     # the two-layer syntheses' output layer (csrc/pixel.hip; VALU, not MFMA)
+                    name = f"two_layer_tail_kernel<{e['cin']}>"
                 if e["kind"] == "synthesis":                                # the fused two-layer synthesis (csrc/syn_fused.hip)
                     name = f"syn_kernel<{e['cout']}, {'true' if e['cout'] > 12 and e['cout'] % 24 == 0 and model._synthesis._has_res else 'false'}>"
                 if e["kind"] == "resblock":                                 # the whole ResidualBlock in one launch (csrc/rb_fused.hip)

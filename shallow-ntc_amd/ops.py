@@ -634,13 +634,33 @@ TAIL_CHANNELS = (12, 24, 48)
 TAIL_ACTS = {None: 0, "none": 0, "igdn": 1, "igdn1": 1, "gdn": 2, "gdn1": 2, "relu": 3, "leaky_relu": 4, "lrelu": 4}
 
 
+def _tail_profile(n, hh, wh, ch, cout, k2, s2):
+    """bench.py's launch record of the tail kernel: the output layer's algorithmic FLOPs (Conv2DTranspose k2 x k2 / s2,
+    ch -> cout: 2 * MACs of its input pixels, as sntc_conv_flops counts a transposed layer) between two events."""
+    prof = PROFILE
+    if prof is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return prof, dict(e0=e0, e1=e1, flops=2 * n * hh * wh * k2 * k2 * ch * cout, variant=0, nblocks=0, vec=True, kind="tail",
+                      k=k2, s=s2, cin=ch, cout=cout, n=n, h=hh, w=wh)
+
+
+def _tail_profile_done(rec):
+    if rec is not None:
+        rec[1]["e1"].record()
+        rec[0].append(rec[1])
+
+
 def two_layer_tail(t, ch, has_res, act_kind, beta, gamma, w2, b2, k2=5, s2=2):
     _check_nhwc(t, ch * (2 if has_res else 1))
     n, hh, wh, _ = t.shape
     cout = int(w2.shape[2])
     y = torch.empty((n, hh * s2, wh * s2, cout), dtype=torch.float32, device=t.device)
+    rec = _tail_profile(n, hh, wh, ch, cout, k2, s2)
     capi.call("sntc_two_layer_tail", _ptr(t), n, hh, wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma),
               _ptr(w2), _ptr(b2), k2, s2, cout, _ptr(y), _stream())
+    _tail_profile_done(rec)
     return y
 
 
@@ -657,8 +677,10 @@ def two_layer_tail_pixels(t, ch, has_res, act_kind, beta, gamma, w2, b2, h, w, r
         if tuple(reference.shape) != (n, h, w, cout):
             raise ValueError(f"reference {tuple(reference.shape)} does not match the decoded size {(n, h, w, cout)}")
         sse = torch.empty((n,), dtype=torch.int64, device=t.device)
+    rec = _tail_profile(n, hh, wh, ch, cout, k2, s2)
     capi.call("sntc_two_layer_tail_pixels", _ptr(t), n, hh, wh, ch, int(has_res), act_kind, _ptr(beta), _ptr(gamma), _ptr(w2),
               _ptr(b2), k2, s2, cout, h, w, _ptr(reference), _ptr(px), _ptr(sse), _stream())
+    _tail_profile_done(rec)
     return px, sse
 
 
