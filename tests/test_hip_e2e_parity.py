@@ -1,14 +1,25 @@
 """image -> (bpp, PSNR) of the HIP path against the float64 oracle, END TO END FROM PIXELS, at full width and at
-Kodak size, with the BASELINE.json tolerance asserted unconditionally (-m gpu).
+Kodak size, with the BASELINE.json tolerance written into every assertion (-m gpu).
 
 Everything upstream of round(y - mu) runs in float32 on the GPU and in float64 in the oracle, so a symbol whose
-y - mu lies within ~1e-5 of a rounding boundary can come out one step away.  This test measures how often that happens
-on a 393,216-pixel image (491,520 symbols) and what it does to the rate and to the PSNR -- no `if flips == 0` escape:
-|d bpp| <= 1e-4 and |d PSNR| <= 1e-3 dB are asserted on whatever the GPU produced (reference
-mshyper/models.py:300-317).  The oracle's transforms run on oracle/train_ref (library convolutions in float64; it
-equals the NumPy tap-loop oracle to 1e-12, tests/test_oracle_cross.py), the entropy models and pixel maths on ops_np.
+y - mu lies within ~1e-5 of a rounding boundary can come out one step away.  These tests measure how often that happens
+on a 393,216-pixel image (491,520 symbols) and what it does to the rate and to the PSNR (reference
+mshyper/models.py:300-317).  What is asserted, exactly:
 
-The measured counts are also written to gpurun_out/e2e_parity.json (when that directory exists) for DESIGN.md.
+  * single-image cases and every set in the reference's PUBLISHED operating range (0.115 ... 1.31 bpp): the RAW
+    comparison -- |d bpp| <= 1e-4 and |d PSNR| <= 1e-3 dB on whatever the GPU produced, no condition on the flips;
+  * the one set far above that range (~2.3 bpp): an image whose hyper-latent z the float64 oracle ITSELF puts within
+    2e-5 of a rounding tie (at most two per image) is compared a second time with z pinned to the GPU's value
+    (oracle/model_np.py `force_z`), and THAT comparison is held to the bars -- an escape, counted and reported: the raw
+    numbers of those images (|d bpp| up to 2e-4) are in the report, and `raw_images_within_bars` says how many images
+    of each set meet the bars without it.
+
+The oracle's transforms run on oracle/train_ref (library convolutions in float64; it equals the NumPy tap-loop oracle
+to 1e-12, tests/test_oracle_cross.py), the entropy models and pixel maths on ops_np.  The oracle is this repository's
+restatement of the reference (parity unpinned: the reference has no tests, tensors or weights).
+
+The measured counts are also written to gpurun_out/e2e_parity*.json (when that directory exists); tools/parity_tables.py
+renders DESIGN.md's and README.md's parity tables from the committed copies under profiles/.
 """
 import json
 from pathlib import Path
@@ -341,33 +352,51 @@ def test_bf16x3_image_to_bpp_psnr_at_full_width(name, hw, dev):
 # (max / median |d bpp|, |d PSNR|, symbol flips, hyper-latent flips) is written out for DESIGN.md / README.md
 # (tools/parity_tables.py renders those tables from the committed JSON -- no hand-typed parity number).
 # ---------------------------------------------------------------------------------------------------------------------------
-KODAK_POINTS = {"2.3bpp": "high_rate", "0.25bpp": 0.25}
+KODAK_SHAPES = [(768, 512) if i in (3, 8, 9, 16, 17, 18) else (512, 768) for i in range(24)]
+SETS = {
+    "2.3bpp": dict(config="two_layer_syn", point="high_rate", precision="fp32", shapes=KODAK_SHAPES),
+    "0.25bpp": dict(config="two_layer_syn", point=0.25, precision="fp32", shapes=KODAK_SHAPES),
+    "jpegl/0.25bpp": dict(config="jpegl", point=0.25, precision="fp32", shapes=KODAK_SHAPES),
+    "bf16x3/0.25bpp": dict(config="two_layer_syn", point=0.25, precision="bf16x3", shapes=KODAK_SHAPES),
+    "two_layer_syn2/5x1200x1200/0.25bpp": dict(config="two_layer_syn2", point=0.25, precision="fp32", shapes=[(1200, 1200)] * 5),
+}
+_ORACLE_CACHE = {}      # (config, point) -> per-image float64 results: the bf16x3 set runs the fp32 set's weights and images
 
 
-@pytest.mark.parametrize("label", list(KODAK_POINTS))
+@pytest.mark.parametrize("label", list(SETS))
 def test_kodak_set_margin_distribution(label, dev):
     from shallow_ntc_amd.common import data_lib
     from shallow_ntc_amd.mshyper import configs
-    shapes = [(768, 512) if i in (3, 8, 9, 16, 17, 18) else (512, 768) for i in range(24)]
+    spec = SETS[label]
+    name, point, shapes = spec["config"], spec["point"], spec["shapes"]
     images = [data_lib.normalize_image(data_lib.synthetic_images(1, h, w, seed=700 + i)) for i, (h, w) in enumerate(shapes)]
-    point = KODAK_POINTS[label]
     if isinstance(point, str):
-        model, w = _model("two_layer_syn", dev, **OPERATING_POINTS[point])
+        model, w = _model(name, dev, **OPERATING_POINTS[point])
     else:
-        model, w = _model_at_bpp("two_layer_syn", dev, images[0], point)
-    ref_model = model_np.Model(configs.CONFIGS["two_layer_syn"]()["transform_config"], rd_lambda=0.02)
-    # the float64 oracle on each orientation's images as ONE batch (its library convolutions thread better that way: the two
-    # operating points together are 48 full-width 512 x 768 evaluations); every image is then read out by itself
-    oracle = {}
-    for shape in sorted(set(shapes)):
-        ids = [i for i, s in enumerate(shapes) if s == shape]
-        xb = np.concatenate([images[i] for i in ids])
-        rl = ref_model.infer_latents(w, xb, be=train_ref)
-        rf = ref_model.frame_loss(w, xb, rl, be=train_ref)
-        npix = float(shape[0] * shape[1])
-        for k, i in enumerate(ids):
-            oracle[i] = dict(lat=tuple(t[k:k + 1] for t in rl), symbols_y=rf["symbols_y"][k:k + 1], z_hat=rf["z_hat"][k:k + 1],
-                             bpp=float((rf["bits_z"][k] + rf["bits_y"][k]) / npix), psnr=float(rf["psnrs"][k]))
+        model, w = _model_at_bpp(name, dev, images[0], point)
+    if spec["precision"] != "fp32":          # the same weights in split precision: the same bars
+        from shallow_ntc_amd.mshyper.models import Model
+        model = Model(device=dev, quality_metrics=False, precision=spec["precision"], **configs.CONFIGS[name](rd_lambda=0.02))
+        model._step = 10 ** 9
+        model.set_weights(w)
+    ref_model = model_np.Model(configs.CONFIGS[name]()["transform_config"], rd_lambda=0.02)
+    # the float64 oracle on each image size's images as ONE batch (its library convolutions thread better that way);
+    # every image is then read out by itself
+    key = (name, point)
+    if key not in _ORACLE_CACHE:
+        oracle = {}
+        for shape in sorted(set(shapes)):
+            ids = [i for i, sh in enumerate(shapes) if sh == shape]
+            xb = np.concatenate([images[i] for i in ids])
+            rl = ref_model.infer_latents(w, xb, be=train_ref)
+            rf = ref_model.frame_loss(w, xb, rl, be=train_ref)
+            npix = float(shape[0] * shape[1])
+            for k, i in enumerate(ids):
+                oracle[i] = dict(lat=tuple(t[k:k + 1] for t in rl), symbols_y=rf["symbols_y"][k:k + 1], z_hat=rf["z_hat"][k:k + 1],
+                                 bpp=float((rf["bits_z"][k] + rf["bits_y"][k]) / npix), psnr=float(rf["psnrs"][k]))
+        _ORACLE_CACHE[key] = oracle
+    oracle = _ORACLE_CACHE[key]
+    pinned_allowed = isinstance(point, str)        # only the set far above the published range may pin a tied hyper-latent
     rows = []
     for i, x in enumerate(images):
         lat = model.infer_latent_rvs(x)
@@ -380,7 +409,8 @@ def test_kodak_set_margin_distribution(label, dev):
         row = dict(image=i, shape=list(shapes[i]), symbols=int(sym.size), symbol_flips=int((sym != ref["symbols_y"]).sum()),
                    z_flips=int(zdiff.sum()), bpp_f64=float(ref["bpp"]), d_bpp=m["bpp"] - float(ref["bpp"]),
                    psnr_f64=float(ref["psnr"]), d_psnr=m["psnr"] - float(ref["psnr"]))
-        if row["z_flips"]:
+        row["raw_within_bars"] = bool(abs(row["d_bpp"]) <= 1e-4 and abs(row["d_psnr"]) <= 1e-3 and row["symbol_flips"] <= sym.size * 1e-4)
+        if row["z_flips"] and pinned_allowed:
             # a hyper-latent the ORACLE itself puts on a rounding tie (any float32 implementation, the reference's included, can
             # land on either side) moves mu / sigma over its receptive field: it must really be a tie, there may be at most two,
             # and with the hyper-latents pinned to the GPU's the image is held to the bars like every other
@@ -393,15 +423,17 @@ def test_kodak_set_margin_distribution(label, dev):
         else:
             held = (row["d_bpp"], row["d_psnr"], row["symbol_flips"])
         rows.append(row)
-        # the BASELINE.json bars, per image, no escape
+        # the BASELINE.json bars, per image (raw everywhere but on the tied images of the ~2.3 bpp set: module docstring)
         assert abs(held[0]) <= 1e-4, row
         assert abs(held[1]) <= 1e-3, row
         assert held[2] <= sym.size * 1e-4, row
     ab = lambda k: np.abs(np.array([r[k] for r in rows], np.float64))
-    clean = [r for r in rows if not r["z_flips"]]
-    tied = [r for r in rows if r["z_flips"]]
+    tied = [r for r in rows if "d_bpp_at_gpu_z" in r]          # compared a second time with z pinned (the ~2.3 bpp set only)
+    clean = [r for r in rows if "d_bpp_at_gpu_z" not in r]     # held to the bars raw
     abc = lambda k, rs: np.abs(np.array([r[k] for r in rs], np.float64)) if rs else np.zeros(1)
-    summary = dict(images=len(rows), bpp_f64_range=[min(r["bpp_f64"] for r in rows), max(r["bpp_f64"] for r in rows)],
+    summary = dict(images=len(rows), config=name, precision=spec["precision"], image_sizes=sorted({f"{h}x{w}" for h, w in shapes}),
+                   symbols_per_image=int(rows[0]["symbols"]), raw_images_within_bars=sum(r["raw_within_bars"] for r in rows),
+                   bpp_f64_range=[min(r["bpp_f64"] for r in rows), max(r["bpp_f64"] for r in rows)],
                    images_without_z_flips=len(clean),
                    max_abs_d_bpp=float(abc("d_bpp", clean).max()), median_abs_d_bpp=float(np.median(abc("d_bpp", clean))),
                    max_abs_d_psnr=float(abc("d_psnr", clean).max()), median_abs_d_psnr=float(np.median(abc("d_psnr", clean))),
@@ -423,5 +455,5 @@ def test_kodak_set_margin_distribution(label, dev):
         rep[label] = dict(summary=summary, per_image=rows)
         f.write_text(json.dumps(rep, indent=1))
     print(json.dumps({label: summary}))
-    if isinstance(point, float):                      # the set really sits around the published operating point
+    if not pinned_allowed:                            # the set really sits around the published operating point
         assert 0.3 * point <= summary["bpp_f64_range"][0] and summary["bpp_f64_range"][1] <= 3.0 * point, summary
