@@ -164,6 +164,8 @@ def main():
                     help="A/B: Model.decode_set (the hyper-syntheses of the batch shapes side by side, then ONE synthesis launch for all "
                          "of them) instead of one Model.decode per batch shape on its own stream (measured: the join in front of the "
                          "shared launch costs more overlap than the launch saves: 3.39 against 3.16 ms per step)")
+    ap.add_argument("--stream-map", type=str, default="",
+                    help="A/B: comma-separated stream index per batch of the set (default: batch i on stream i %% streams)")
     ap.add_argument("--chunk", type=int, default=0, help="split every batch shape into sub-batches of at most this many images (0 = no split)")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
@@ -268,12 +270,14 @@ def main():
     nstreams = len(codes) if args.streams == 0 else args.streams
     side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
 
+    smap = [int(v) for v in args.stream_map.split(",")] if args.stream_map else None
+
     def decode_streams():
         """Independent batches on independent streams (joined back into the current stream before returning)."""
         cur = torch.cuda.current_stream()
         outs = []
         for i, (z_hat, sym, hw, _x) in enumerate(codes):
-            st = side[i % nstreams]
+            st = side[smap[i] if smap else i % nstreams]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 outs.append(model.decode(z_hat, sym, hw, check=False))

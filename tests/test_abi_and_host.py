@@ -274,3 +274,14 @@ def test_checkpoint_retention_keeps_the_newest_n(n_keep):
     # recency, not step number: a stale bundle with a higher step goes first
     assert checkpoints_to_keep({99: 0.0, 6: 5.0, 9: 6.0}, 12, 3) == [6, 9, 12]
     assert checkpoints_to_keep({99: 0.0}, 12, 1) == [12]
+
+
+@pytest.mark.skipif(not os.environ.get("SNTC_SLOW_TESTS"), reason="recompiles three kernel sources (about four minutes): "
+                    "SNTC_SLOW_TESTS=1, or python tools/kernel_resources.py --check, when a kernel source changes")
+def test_hot_kernel_register_allocation_is_the_committed_one():
+    """The fp32 gather-GEMM instances that carry the decode, the ResidualBlock kernel and the synthesis kernel compile to the
+    register / scratch figures committed in profiles/kernel_resources.json: a new mode of the 11-parameter template (or a
+    compiler update) that moves them shows up here, not as an unexplained 8 % on the GPU."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "kernel_resources.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
