@@ -3,6 +3,7 @@ host logic (registry, configs, metrics, schedules) mirrors the reference, and th
 refuses to run without a GPU instead of falling back."""
 import json
 import math
+import os
 import re
 import sys
 from pathlib import Path
