@@ -1,9 +1,9 @@
-# rocprofv3 evidence for profiles/ (round 4): kernel stats + PMC passes of the decode-only bench AND of the encode-side layer
+# rocprofv3 evidence for profiles/ (round 5): kernel stats + PMC passes of the decode-only bench AND of the encode-side layer
 # table, the layer tables (Kodak batch and W1), the whole-ResidualBlock kernel alone, the stream kernels, the default bench line.
 # Program directly after `--`.  bash tools/profile_round.sh [round tag, default r04]
 # NOTE: gpurun MERGES what this writes into the local gpurun_out/prof_<tag> -- delete that directory locally before a re-run, or
 # stale *_kernel_stats.csv / *_counter_collection.csv of the previous run are averaged into tools/summarize_pmc.py's output.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 SQ="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"
@@ -26,6 +26,10 @@ python3 tools/profile_layers.py --reps 5 > $O/layer_table.txt 2>&1
 python3 tools/profile_layers.py --reps 5 --autotune > $O/layer_table_tuned.txt 2>&1
 python3 tools/profile_layers.py --reps 5 --batch 64 --hw 256 256 --autotune > $O/layer_table_w1.txt 2>&1
 python3 tools/rb_block.py > $O/resblock_vs_layers.txt 2>&1
+python3 tools/syn_block.py > $O/synthesis_vs_layers.txt 2>&1
+python3 tools/syn_block.py --ch 24 --res 0 5 76 76 >> $O/synthesis_vs_layers.txt 2>&1
+python3 bench.py --decode-only --steps 50 --warmup 10 --set-decode > $O/decode_only_set_decode.json 2> /dev/null
+python3 bench.py --decode-only --steps 50 --warmup 10 --streams 1 > $O/decode_only_one_stream.json 2> /dev/null
 python3 tools/stream_kernels.py > $O/stream_kernels.txt 2>&1
 python3 tools/time_evaluate.py > $O/evaluate_b1.txt 2>&1
 python3 tools/profile_layers.py --reps 5 --precision bf16x3 > $O/layer_table_bf16x3.txt 2>&1
