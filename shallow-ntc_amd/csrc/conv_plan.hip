@@ -822,7 +822,7 @@ static int conv_forward_impl(const sntc_conv_plan* p, const sntc_conv_plan* p2, 
     a.sk_slab = static_cast<float*>(workspace);
     a.sk_flags = reinterpret_cast<int*>(a.sk_slab + (size_t)sc.workers * (v > kNumVariants ? bf3p_sk_slab_floats(v) : gg_sk_slab_floats(v)));
     a.slab = nullptr;
-    SNTC_HIP(hipMemsetAsync(a.sk_flags, 0, sizeof(int) * sc.workers, (hipStream_t)stream));
+    if (int zrc = zero_async(a.sk_flags, sizeof(int) * sc.workers, (hipStream_t)stream)) return zrc;
   }
   int nb = 0, tile0 = 0;
   long long unit0 = 0;

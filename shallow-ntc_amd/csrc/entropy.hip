@@ -207,7 +207,7 @@ extern "C" int sntc_entropy_factorized(const sntc_prior* prior, const float* z, 
   if (!prior || !z || !bits || (!values_only && !z_hat)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_factorized: null argument");
   if (n < 1 || hw < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_factorized: empty input");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   const int64_t per = hw * prior->channels;
   hipLaunchKernelGGL(factorized_kernel, dim3(grid_for(per), n), dim3(256), 0, s, prior->rec, prior->d, z, hw,
                      prior->channels, z_hat, bits, values_only);
@@ -221,7 +221,7 @@ extern "C" int sntc_entropy_scale_normal(const float* y, const float* hyper, int
   if (n < 1 || hw < 1 || c < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_entropy_scale_normal: empty input");
   if (c % 4) return fail(SNTC_ERR_UNSUPPORTED, "sntc_entropy_scale_normal: channels must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   hipLaunchKernelGGL(scale_normal_kernel, dim3(grid_for(hw * c / 4), n), dim3(256), 0, s, y, hyper, hw, c, y_hat,
                      symbols, bits, values_only);
   SNTC_HIP(hipGetLastError());

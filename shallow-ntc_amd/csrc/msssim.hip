@@ -143,8 +143,8 @@ extern "C" int sntc_ssim_scale(const float* a, const float* b, int n, int h, int
   for (int i = 0; i < kWin; ++i) win.w[i] = (float)(g[i] / s);
   const float c1 = (0.01f * max_val) * (0.01f * max_val), c2 = (0.03f * max_val) * (0.03f * max_val);
   hipStream_t st = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(ssim_sum, 0, sizeof(double) * n * c, st));
-  SNTC_HIP(hipMemsetAsync(cs_sum, 0, sizeof(double) * n * c, st));
+  if (int zrc = zero_async(ssim_sum, sizeof(double) * n * c, st)) return zrc;
+  if (int zrc = zero_async(cs_sum, sizeof(double) * n * c, st)) return zrc;
   const int ho = h - kWin + 1, wo = w - kWin + 1;
   dim3 grid((wo + kTile - 1) / kTile, (ho + kTile - 1) / kTile, n);
   switch (c) {

@@ -416,7 +416,7 @@ extern "C" int sntc_pixels_sse(const float* x, const float* x_hat, int n, int h,
   if (!x_hat || (x && !sse_out) || (!x && !pixels_out)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_pixels_sse: null argument");
   if (n < 1 || h < 1 || w < 1 || c < 1 || hs < h || ws < w) return fail(SNTC_ERR_BAD_SHAPE, "sntc_pixels_sse: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  if (x) SNTC_HIP(hipMemsetAsync(sse_out, 0, sizeof(unsigned long long) * n, s));
+  if (x) if (int zrc = zero_async(sse_out, sizeof(unsigned long long) * n, s)) return zrc;
   const int64_t per = (int64_t)h * w * c;
   const bool vec = (w * c) % 4 == 0 && (ws * c) % 4 == 0 && per < (1LL << 33) && ((int64_t)hs * ws * c) % 4 == 0 &&
                    (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x_hat)) % 16 == 0 &&
@@ -444,7 +444,7 @@ extern "C" int sntc_float_sse(const float* x, const float* x_hat, int n, int h, 
   if (!x || !x_hat || !sse_out) return fail(SNTC_ERR_BAD_SHAPE, "sntc_float_sse: null argument");
   if (n < 1 || h < 1 || w < 1 || c < 1 || hs < h || ws < w) return fail(SNTC_ERR_BAD_SHAPE, "sntc_float_sse: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(sse_out, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(sse_out, sizeof(double) * n, s)) return zrc;
   const int64_t per = (int64_t)h * w * c;
   int b = blocks_for(per);
   if (b > 512) b = 512;
@@ -493,7 +493,7 @@ static int launch_tail(const float* t, int n, int hh, int wh, int has_res, int a
     attr_dev = dev;
   }
   dim3 grid((wh + 1 + 15) / 16, (hh + 1 + 15) / 16, n);
-  if (px && ref && sse) SNTC_HIP(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * n, s));
+  if (px && ref && sse) if (int zrc = zero_async(sse, sizeof(unsigned long long) * n, s)) return zrc;
   hipLaunchKernelGGL((two_layer_tail_kernel<CH>), grid, dim3(256), lds, s, t, hh, wh, has_res, act_kind, beta, gamma, w2,
                      b2, x_hat, oh, ow, ref, px, sse);
   SNTC_HIP(hipGetLastError());

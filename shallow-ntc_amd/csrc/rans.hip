@@ -589,7 +589,7 @@ extern "C" int sntc_rans_decode(const uint16_t* payload, const int64_t* offsets,
   const long long eseg = segment_elems(elems_per_image, segments);
   const int ns = nimages * segments;
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bad_streams, 0, sizeof(int32_t), s));
+  if (int zrc = zero_async(bad_streams, sizeof(int32_t), s)) return zrc;
   if (fast) {
     const int dec_total = (total_entries + 3 * ntables + 3) / 4 * 4;
     const RansDecTables D{dec, lut, reinterpret_cast<const uint2*>(meta), lut_meta, ntables, dec_total, lut_entries};

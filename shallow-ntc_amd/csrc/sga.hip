@@ -626,7 +626,7 @@ extern "C" int sntc_sga_normal_fwd(const float* y_loc, const float* hyper, int n
     return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_normal_fwd: null argument");
   if (n < 1 || hw < 1 || c < 1 || !(tau > 0.0f)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_normal_fwd: bad sizes / tau");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   hipLaunchKernelGGL(sga_normal_fwd_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, y_loc, hyper, hw, c, tau, noise,
                      (unsigned long long)seed, (unsigned long long)step, y_tilde, sprime, dbits_dv, dbits_draw, bits);
   SNTC_HIP(hipGetLastError());
@@ -651,7 +651,7 @@ extern "C" int sntc_sga_factorized_fwd(const sntc_prior* prior, const float* z_l
   if (n < 1 || hw < 1 || !(tau > 0.0f)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_sga_factorized_fwd: bad sizes / tau");
   const int c = prior->channels;
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   hipLaunchKernelGGL(sga_factorized_fwd_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, prior->rec,
                      prior->d, z_loc, hw, c, tau, noise, (unsigned long long)seed,
                      (unsigned long long)step, z_tilde, sprime, dbits_dz, bits);
@@ -686,7 +686,7 @@ extern "C" int sntc_distortion_grad(const float* x, const float* x_hat, int n, i
   if (!x || !x_hat || !g_xhat || !sse) return fail(SNTC_ERR_BAD_SHAPE, "sntc_distortion_grad: null argument");
   if (n < 1 || h < 1 || w < 1 || c < 1 || hs < h || ws < w) return fail(SNTC_ERR_BAD_SHAPE, "sntc_distortion_grad: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(sse, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(sse, sizeof(double) * n, s)) return zrc;
   int b = grid_for((int64_t)hs * ws * c);
   if (b > 512) b = 512;
   hipLaunchKernelGGL(distortion_grad_kernel, dim3(b, n), dim3(256), 0, s, x, x_hat, h, w, c, hs, ws, scale, g_xhat, sse);
@@ -736,7 +736,7 @@ extern "C" int sntc_noisy_normal(const float* y_tilde, const float* hyper, int n
   if (!y_tilde || !hyper || !dbits_dv || !dbits_draw || !bits) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_normal: null argument");
   if (n < 1 || hw < 1 || c < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_normal: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   hipLaunchKernelGGL(noisy_normal_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, y_tilde, hyper, hw, c, dbits_dv, dbits_draw, bits);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;
@@ -750,12 +750,12 @@ extern "C" int sntc_noisy_factorized(const sntc_prior* prior, const float* z_til
   if (n < 1 || hw < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_noisy_factorized: bad sizes");
   const int c = prior->channels;
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(bits, 0, sizeof(double) * n, s));
+  if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   hipLaunchKernelGGL(noisy_factorized_kernel, dim3(grid_for(hw * c), n), dim3(256), 0, s, prior->rec, prior->d, z_tilde, hw, c,
                      dbits_dz, bits);
   SNTC_HIP(hipGetLastError());
   if (grad_record) {                         // sum over ALL elements of d bits / d record (caller applies the loss weight)
-    SNTC_HIP(hipMemsetAsync(grad_record, 0, sizeof(float) * (size_t)c * prior->d.stride, s));
+    if (int zrc = zero_async(grad_record, sizeof(float) * (size_t)c * prior->d.stride, s)) return zrc;
     const int64_t npix = (int64_t)n * hw;
     const int64_t slabs = std::min<int64_t>(256, (npix + 3) / 4);       // few elements, heavy threads: spread them wide
     const int64_t pslab = (npix + slabs - 1) / slabs;

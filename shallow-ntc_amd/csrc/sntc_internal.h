@@ -10,6 +10,7 @@ namespace sntc {
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
+int zero_async(void* p, size_t bytes, hipStream_t stream);   // zero a 4-byte-aligned range on the stream with a kernel (graph-replay safe)
 
 #define SNTC_HIP(expr)                                         \
   do {                                                         \

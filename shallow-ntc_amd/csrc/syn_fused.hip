@@ -903,7 +903,7 @@ extern "C" int sntc_syn_forward(const sntc_syn_plan* p, const sntc_syn_batch* ba
   if (const char* e = getenv("SNTC_SYN_DBG")) a.dbg = atoi(e);     // diagnostic builds only (make DIAG=1): results are WRONG with it
 #endif
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(workspace, 0, 64, s));
+  if (int zrc = zero_async(workspace, 64, s)) return zrc;
   const int grid = std::min<int64_t>(a.nitems, p->max_workgroups > 0 ? p->max_workgroups : cus);
   const void* fn = nullptr;
   size_t lds = 0;

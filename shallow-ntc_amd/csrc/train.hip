@@ -240,7 +240,7 @@ extern "C" int sntc_noise_add(const float* x, int64_t total, const float* noise,
 extern "C" int sntc_sumsq(const float* x, int64_t total, double* out, void* stream) {
   if (!x || !out || total < 1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_sumsq: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  SNTC_HIP(hipMemsetAsync(out, 0, sizeof(double), s));
+  if (int zrc = zero_async(out, sizeof(double), s)) return zrc;
   hipLaunchKernelGGL(sumsq_kernel, dim3(std::min(tr_grid(total), 1024)), dim3(256), 0, s, x, total, out);
   SNTC_HIP(hipGetLastError());
   return SNTC_OK;

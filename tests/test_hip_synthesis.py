@@ -158,3 +158,25 @@ def test_decode_set_equals_one_decode_per_batch(dev):
             assert torch.equal(px, px0)
     finally:
         ops.FUSED_SYNTHESIS_MIN_ITEMS = old_min
+
+
+def test_decode_replays_from_a_hip_graph(dev):
+    """The decode sequence captured once (graphs.DecodeGraph) and replayed: EVERY replay returns the eager pixels.  The stream-K
+    hand-off flags and the synthesis launch's work queue are re-armed by kernels in front of the launches that use them -- as
+    memsets they were not re-armed on replay (the second replay differed, with or without the fused synthesis)."""
+    from shallow_ntc_amd.graphs import DecodeGraph
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.01))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    n, hw = 6, (768, 512)
+    z_hat = torch.round(3.0 * torch.randn((n, hw[0] // 64, hw[1] // 64, 320), device=dev, generator=g)).contiguous()
+    sym = torch.round(2.0 * torch.randn((n, hw[0] // 16, hw[1] // 16, 320), device=dev, generator=g)).to(torch.int32).contiguous()
+    want = model.decode(z_hat, sym, hw)
+    graph = DecodeGraph(model, z_hat, sym, hw)
+    for _ in range(4):
+        assert torch.equal(graph(), want)
+    sym2 = -sym                                            # new codes through the same graph
+    want2 = model.decode(z_hat, sym2, hw)
+    assert torch.equal(graph(z_hat, sym2), want2) and not torch.equal(want2, want)
