@@ -216,6 +216,8 @@ int sntc_syn_plan_set_workgroups(sntc_syn_plan* plan, int max_workgroups);
  * steps per slab << 8 | mask of the steps that leave the third tile out << 16; the shift list packed four bits per step:
  * low word, high word); returns the number of units. */
 int sntc_syn_plan_units(const sntc_syn_plan* plan, int* out, int capacity);
+/* The units a layer would get, without a device or a plan (same records as sntc_syn_plan_units; -1 where unsupported). */
+int sntc_syn_describe(int k, int stride, int cin, int ch, int has_res, int* out, int capacity);
 /* Host-only check of the decomposition (no device): units + packed weights driven through the kernel's loop nest on the CPU
  * against the scatter form of Conv2DTranspose(SAME) on a random h x w input; *max_err = largest absolute difference. */
 int sntc_syn_selfcheck(int k, int stride, int cin, int ch, int has_res, int h, int w, unsigned seed, double* max_err);

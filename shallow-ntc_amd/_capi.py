@@ -78,6 +78,7 @@ SIGNATURES = {
     "sntc_syn_forward": (C.c_int, [_P, _P, C.c_int, _P, C.c_size_t, _P]),
     "sntc_syn_plan_set_workgroups": (C.c_int, [_P, C.c_int]),
     "sntc_syn_plan_units": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
+    "sntc_syn_describe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "sntc_syn_selfcheck": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double)]),
     "sntc_conv_plan_set_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "sntc_conv_plan_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),

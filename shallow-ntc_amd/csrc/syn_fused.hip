@@ -18,13 +18,16 @@
 // the nine phase classes are grouped so that shift sets nest; a column whose phase does not use a step's shift carries a
 // zero weight there).  The workgroup (512 threads = 8 waves, one per CU) walks the unit's K loop -- channel slab outermost,
 // the unit's shifts inside, 16 channels per step -- with
-//   * the weights as MFMA A operand: one 6-KB ring unit per step (96 rows x 16 k, the LDS image as packed), LDS-DMA, 4 slots;
+//   * the weights as MFMA A operand: one 6-KB ring unit per step (96 rows x 16 k, the LDS image as packed), LDS-DMA into an
+//     eight-slot ring, five units ahead of the step that reads them (a counted vmcnt leaves the youngest in flight);
 //   * the pixels as B operand: wave w owns pixels 32 w .. 32 w + 31 of the tile; the 16-channel slab of the tile's PATCH
 //     (the tile's 256 pixels + one image row + one pixel either side, flat) is staged once per slab by LDS-DMA (3 slots) and
 //     every shift is a shifted fragment read of it ([pixel][16] with the 16-B chunks XOR-swizzled by (pixel >> 2) & 3:
-//     conflict-free under any shift); a source outside the image reads a zero row instead (one select on the address);
-//   * 24 MFMAs per wave and step, fragments double-buffered under them, one barrier per step (rb_fused.hip's 3x3 loop).
-// Items are dealt dynamically (one atomic per item, fetched an item ahead), most expensive units first, unit-major so that
+//     conflict-free under any shift); a source outside the image reads the slot's zero row instead (one select on the address);
+//   * 24 MFMAs per wave and step (16 where the unit's third tile is empty for the step's shift), fragments double-buffered
+//     under them; the loop is compiled per shift count (1 / 2 / 4 per slab) with one barrier per PAIR of steps, and in a
+//     generic form (run-time shift, one barrier per step) for everything else.
+// Items are dealt dynamically (one atomic per item, fetched two items ahead), most expensive units first, unit-major so that
 // the workgroups of an XCD stream the same weights at about the same time; the next item's first patch slabs and ring
 // units are in flight while the current item's epilogue runs.  Per-image geometry comes with the item: batches of
 // different shapes (the Kodak set's two orientations) share one launch.
@@ -991,6 +994,21 @@ extern "C" int sntc_syn_selfcheck(int k, int stride, int cin, int ch, int has_re
     if (v != 1) e = 1e30;          // every output pixel is produced by exactly one (unit, slot)
   *max_err = e;
   return SNTC_OK;
+}
+
+// the units a layer would get, without a device (tests, tools): same records as sntc_syn_plan_units
+extern "C" int sntc_syn_describe(int k, int stride, int cin, int ch, int has_res, int* out, int capacity) {
+  HostPlan P;
+  if (k < 1 || stride < 1 || ch < 1 || (!out && capacity > 0)) return -1;
+  if (build_host_plan(k, stride, cin, ch, has_res ? 1 : 0, &P) != SNTC_OK) return -1;
+  const int n = (int)P.units.size();
+  for (int i = 0; i < n && i < capacity; ++i) {
+    const SynUnit& U = P.units[i];
+    int nph = 0;
+    for (int q = 0; q < kMaxSlots; ++q) nph += U.ph[q] != 0xffffffffu;
+    out[4 * i] = U.ns; out[4 * i + 1] = nph | (U.cost << 8) | ((int)U.pm << 16); out[4 * i + 2] = (int)U.sl0; out[4 * i + 3] = (int)U.sl1;
+  }
+  return n;
 }
 
 // the plan's units for tests and tools: writes up to `capacity` records of 4 ints (steps per slab, phases, packed shifts lo, hi)
