@@ -101,7 +101,8 @@ class TwoLayerBackward:
         if nr:
             k1 = np.concatenate([k1, w[f"{nr}/kernel"]], axis=2)
         c2 = k1.shape[2]
-        self.cp = -(-c2 // 32) * 32                       # pad the gradient channels to a 32 multiple (vector gather path)
+        self.cp = -(-c2 // 16) * 16                       # pad the gradient channels to a multiple of the 16-deep K stage (the vector
+                                                          # gather path; 12 -> 16: half the adjoint's MFMAs of the 32 it used to pad to)
         k1p = np.zeros(k1.shape[:2] + (self.cp, k1.shape[3]), np.float32)
         k1p[:, :, :c2] = k1
         self.up_adj = ops.ConvPlan("conv", ops.to_device(k1p, dev), None, t._s[0])

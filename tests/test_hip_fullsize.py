@@ -472,4 +472,4 @@ def test_counted_flops_are_the_reference_tables(kodak_model, dev):
     assert abs(enc / px / (510563.75 + 13451.64 + 30354.69) - 1) < 0.01
     from shallow_ntc_amd.sga import TwoLayerBackward
     bw = TwoLayerBackward(m._synthesis)
-    assert bw.up_adj.cin == 32 and bw.up_adj.flops(1, 256, 384) == 2 * 32 * 48 * 169 * 24 * 320
+    assert bw.up_adj.cin == 32 and bw.up_adj.flops(1, 256, 384) == 2 * 32 * 48 * 169 * 24 * 320      # 24 real channels, padded to 32
