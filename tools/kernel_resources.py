@@ -7,7 +7,7 @@ code size of the fp32 instances that carry the decode (round 3 lost 8 % to exact
     python tools/kernel_resources.py --write    # ... and rewrite profiles/kernel_resources.json (commit it with the change)
     python tools/kernel_resources.py --check    # exit 1 if an instance differs from the committed table (tests/test_abi_and_host.py)
 
-No GPU needed (hipcc cross-compiles).  One compile of gather_gemm.hip takes about a minute."""
+No GPU needed (hipcc cross-compiles); the four sources take about three minutes."""
 import json
 import re
 import subprocess
@@ -21,14 +21,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-c", "-o", "/dev/null"]
 # source -> the instances (demangled-name fragments) whose numbers are pinned
 WATCH = {
-    "gather_gemm.hip": {
+    "gg_inst_vec.hip": {
         "gg 128x128 stream-K (HS3 twin, column-major)": "gg_kernelILi2ELi2ELi2ELi2ELb1ELb0ELb0ELb0ELi0ELb0ELb1EE",
         "gg 128x128 (strip-major)": "gg_kernelILi2ELi2ELi2ELi2ELb1ELb0ELb0ELb0ELi0ELb0ELb0EE",
         "gg 128x96 (HS2, 5x5/2 layers)": "gg_kernelILi1ELi3ELi4ELi1ELb1ELb0ELb0ELb0ELi0ELb0ELb0EE",
         "gg 128x64": "gg_kernelILi1ELi2ELi4ELi1ELb1ELb0ELb0ELb0ELi0ELb0ELb0EE",
         "gg 64x64": "gg_kernelILi1ELi1ELi2ELi2ELb1ELb0ELb0ELb0ELi0ELb0ELb0EE",
-        "gg fused ResidualBlock tail": "gg_kernelILi1ELi3ELi4ELi1ELb1ELb0ELb0ELb0ELi0ELb1ELb0EE",
     },
+    "gg_inst_fuse.hip": {"gg fused ResidualBlock tail": "gg_kernelILi1ELi3ELi4ELi1ELb1ELb0ELb0ELb0ELi0ELb1ELb0EE"},
     "rb_fused.hip": {"rb_kernel<192>": "rb_kernelILi192EE"},
     "syn_fused.hip": {"syn_kernel<24, true>": "syn_kernelILi24ELb1EE", "syn_kernel<12, false>": "syn_kernelILi12ELb0EE",
                       "syn_kernel<24, false>": "syn_kernelILi24ELb0EE"},
