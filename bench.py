@@ -625,7 +625,7 @@ def main():
         # records the hash of the kernel source it was measured on, so a number from an older kernel is marked stale
         import hashlib
         traffic, traffic_src, traffic_stale = None, None, None
-        cur_sha = hashlib.sha256((ROOT / "shallow-ntc_amd/csrc/gather_gemm.hip").read_bytes()).hexdigest()[:16]
+        cur_sha = hashlib.sha256((ROOT / "shallow-ntc_amd/csrc/gather_gemm_kernel.h").read_bytes()).hexdigest()[:16]
         import re as _re
         for f in sorted(f for f in (ROOT / "profiles").glob("*_pmc_summary.json") if _re.fullmatch(r"r\d+_pmc_summary\.json", f.name))[::-1]:
             summ = json.loads(f.read_text())

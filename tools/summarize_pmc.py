@@ -46,7 +46,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -share.get(kv[0], 0.0)):
 root = Path(__file__).resolve().parent.parent
 sha = lambda f: hashlib.sha256((root / f).read_bytes()).hexdigest()[:16]
 # which kernel source these counters belong to: bench.py marks roofline.traffic stale when the source has changed since
-out["_meta"] = dict(gather_gemm_sha16=sha("shallow-ntc_amd/csrc/gather_gemm.hip"), conv_plan_sha16=sha("shallow-ntc_amd/csrc/conv_plan.hip"),
+out["_meta"] = dict(gather_gemm_sha16=sha("shallow-ntc_amd/csrc/gather_gemm_kernel.h"), conv_plan_sha16=sha("shallow-ntc_amd/csrc/conv_plan.hip"),
                     bf3_gemm_sha16=sha("shallow-ntc_amd/csrc/bf3_gemm.hip"), rb_fused_sha16=sha("shallow-ntc_amd/csrc/rb_fused.hip"),
                     syn_fused_sha16=sha("shallow-ntc_amd/csrc/syn_fused.hip"))
 p = root / "profiles" / f"{name}.json"
