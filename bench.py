@@ -169,7 +169,8 @@ def main():
                     help="A/B: comma-separated stream index per batch of the set (default: batch i on stream i %% streams)")
     ap.add_argument("--chunk", type=int, default=0, help="split every batch shape into sub-batches of at most this many images (0 = no split)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay one captured HIP graph per batch shape instead of eager launches (measured: no gain, "
+                    help="replay a captured HIP graph instead of eager launches: one graph for the set with a branch per batch "
+                         "(graphs.DecodeSetGraph), or one per batch shape with --streams 1 (measured, round 5: 3.14 ms either way -- "
                          "the host already runs ahead of the GPU)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="A/B: run the ResidualBlock tails as two launches instead of the fused one (same bits)")
@@ -301,14 +302,21 @@ def main():
     elif not args.graph:
         decode_step = decode_streams if nstreams > 1 and len(codes) > 1 else decode_eager
     else:                                  # one captured HIP graph per batch shape, replayed every step
-        from shallow_ntc_amd.graphs import DecodeGraph
-        graphs = [DecodeGraph(model, z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
-        # the graph output must equal the eager output bit for bit
-        for g, ref in zip(graphs, decode_eager()):
-            assert torch.equal(g(), ref), "HIP-graph replay differs from eager decode"
+        from shallow_ntc_amd.graphs import DecodeGraph, DecodeSetGraph
+        if nstreams > 1 and len(codes) > 1:      # one graph for the set, one branch per batch
+            set_graph = DecodeSetGraph(model, codes)
+            for _ in range(3):
+                for got, ref in zip(set_graph(), decode_eager()):
+                    assert torch.equal(got, ref), "HIP-graph replay differs from eager decode"
+            decode_step = set_graph
+        else:
+            graphs = [DecodeGraph(model, z_hat, sym, hw) for z_hat, sym, hw, _x in codes]
+            # the graph output must equal the eager output bit for bit
+            for g, ref in zip(graphs, decode_eager()):
+                assert torch.equal(g(), ref), "HIP-graph replay differs from eager decode"
 
-        def decode_step():
-            return [g() for g in graphs]
+            def decode_step():
+                return [g() for g in graphs]
 
     def on_streams(fn_per_batch):
         """Run fn(batch) for every batch of the set, independent batches on independent streams."""

@@ -36,3 +36,42 @@ class DecodeGraph:
         self.graph.replay()
         return self.out
 
+
+
+class DecodeSetGraph:
+    """ONE graph for a set of batches of different image sizes: every batch's decode sequence is a branch of its own (captured on
+    a stream forked from the capturing stream and joined back), so the branches run side by side as the eager two-stream decode
+    does, without its host launches.  graph(codes=None) -> [uint8 pixels per batch] (static buffers)."""
+
+    def __init__(self, model, codes, warmup=2):
+        self.model = model
+        self.codes = [(z.clone(), s.clone(), tuple(hw)) for z, s, hw, *_ in codes]
+        with torch.cuda.device(model.device):
+            self.streams = [torch.cuda.Stream() for _ in self.codes]
+            for _ in range(warmup):
+                self._launch()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._launch()
+
+    def _launch(self):
+        cur = torch.cuda.current_stream()
+        outs = []
+        for st, (z_hat, sym, hw) in zip(self.streams, self.codes):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self.model.decode(z_hat, sym, hw, check=False))
+        for st in self.streams:
+            cur.wait_stream(st)
+        return outs
+
+    def __call__(self, codes=None):
+        if codes is not None:
+            for (z0, s0, _hw), (z, s, *_r) in zip(self.codes, codes):
+                if z.data_ptr() != z0.data_ptr():
+                    z0.copy_(z)
+                if s.data_ptr() != s0.data_ptr():
+                    s0.copy_(s)
+        self.graph.replay()
+        return self.out

@@ -180,3 +180,27 @@ def test_decode_replays_from_a_hip_graph(dev):
     sym2 = -sym                                            # new codes through the same graph
     want2 = model.decode(z_hat, sym2, hw)
     assert torch.equal(graph(z_hat, sym2), want2) and not torch.equal(want2, want)
+
+
+def test_a_set_of_batches_replays_from_one_graph(dev):
+    """graphs.DecodeSetGraph: both orientations as branches of ONE captured graph -- every replay equals the eager decodes."""
+    from shallow_ntc_amd.graphs import DecodeSetGraph
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.01))
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    codes = []
+    for n, hw in ((4, (512, 768)), (2, (768, 512))):
+        z_hat = torch.round(3.0 * torch.randn((n, hw[0] // 64, hw[1] // 64, 320), device=dev, generator=g)).contiguous()
+        sym = torch.round(2.0 * torch.randn((n, hw[0] // 16, hw[1] // 16, 320), device=dev, generator=g)).to(torch.int32).contiguous()
+        codes.append((z_hat, sym, hw))
+    want = [model.decode(z, s, hw) for z, s, hw in codes]
+    graph = DecodeSetGraph(model, codes)
+    for _ in range(4):
+        for got, ref in zip(graph(), want):
+            assert torch.equal(got, ref)
+    flipped = [(z, -s, hw) for z, s, hw in codes]
+    want2 = [model.decode(z, s, hw) for z, s, hw in flipped]
+    for got, ref in zip(graph(flipped), want2):
+        assert torch.equal(got, ref)
