@@ -112,6 +112,46 @@ def test_weight_update_in_place(dev):
     assert torch.equal(got, want) and not torch.equal(got, first)
 
 
+OTHER_FRAMES = [  # k, s, cin, ch, has_res, act, (n, h, w): every kernel / stride pair the nine-shift frame admits takes the run-time-shift loop
+    (5, 2, 64, 12, True, "igdn", (2, 9, 14)),
+    (5, 2, 32, 24, False, "relu", (1, 33, 5)),
+    (3, 1, 48, 12, True, "igdn", (1, 21, 19)),
+    (3, 1, 16, 48, False, None, (2, 8, 8)),
+    (9, 4, 64, 12, True, "igdn", (1, 12, 17)),
+    (9, 4, 32, 24, True, "lrelu", (3, 5, 6)),
+    (4, 2, 32, 12, False, "igdn", (1, 10, 10)),
+    (6, 4, 32, 12, True, "gdn", (1, 7, 13)),
+    (16, 8, 32, 12, True, "igdn", (1, 6, 9)),
+    (8, 8, 32, 24, False, "igdn", (1, 5, 8)),
+    (2, 2, 16, 12, True, None, (2, 6, 7)),
+    (1, 1, 32, 24, False, "relu", (1, 11, 13)),
+    (18, 16, 32, 12, True, "igdn", (1, 4, 5)),
+    (10, 8, 16, 48, False, "igdn", (1, 9, 4)),
+]
+
+
+@pytest.mark.parametrize("case", OTHER_FRAMES, ids=lambda c: f"k{c[0]}s{c[1]}-cin{c[2]}-ch{c[3]}-res{int(c[4])}-{c[5]}")
+def test_other_kernel_and_stride_pairs(case, dev):
+    """What ``SynPlan.supported`` accepts, a two-layer synthesis built with other ``kernel_sizes`` / ``strides`` runs: each such
+    pair against the layers it replaces, bit for bit (pairs outside the frame are refused and keep the layers)."""
+    from shallow_ntc_amd import ops
+    k, s, cin, ch, has_res, act, (n, h, w) = case
+    if not ops.SynPlan.supported(k, s, cin, ch, has_res):
+        pytest.skip("outside the nine-shift frame: the layers stay")
+    rng = np.random.default_rng(100 * k + s + cin)
+    w1, b1, beta, gamma = make_layer(rng, cin, ch, has_res, k=k)
+    kind = ops.TAIL_ACTS[act]
+    w1d, b1d, bd, gd = (dev_t(a, dev) for a in (w1, b1, beta, gamma))
+    syn = ops.SynPlan(w1d, b1d, s, ch, has_res, kind, bd, gd)
+    up = ops.ConvPlan("convT", w1d, b1d, s)
+    x = dev_t(rng.standard_normal((n, h, w, cin)), dev)
+    want = layered_hidden(ops, up, x, ch, has_res, kind, bd, gd)
+    got = syn(x)
+    assert got.shape == want.shape == (n, h * s, w * s, ch)
+    assert torch.equal(got, want), f"{int((got != want).sum())} of {got.numel()} values differ"
+    ops.check_conv_status()
+
+
 @pytest.mark.parametrize("cfg_name,hw", [("two_layer_syn", (96, 128)), ("two_layer_syn2", (70, 100))])
 def test_decoded_pixels_do_not_change(cfg_name, hw, dev):
     """Model.decode with the fused synthesis == with the layered path: uint8 pixels and integer SSE, incl. a padded size."""
