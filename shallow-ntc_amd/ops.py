@@ -530,12 +530,16 @@ class autotune:
         return False
 
 
-def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None):
+def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst=1, passes=1):
     """Choose the schedules of a whole step by the step's own clock: ``step_fn`` (which may use several streams and must join
     them back into the current stream) is run once to find its convolution launches; then, launch by launch (longest
-    contraction first), every (tile, schedule) candidate is tried and kept if the median time of ``reps`` steps improves by
-    more than ``min_gain``.  For steps whose launches overlap on the device -- where a schedule measured with the device to
-    itself (``autotune``) can be the wrong one.  All candidates give identical bits.  Returns (ms before, ms after)."""
+    contraction first), every (tile, schedule) candidate is tried and kept if the median time of ``reps`` samples improves by
+    more than ``min_gain`` (otherwise the launch keeps what it had: a measured choice or the cost model's).  For steps whose
+    launches overlap on the device -- where a schedule measured with the device to itself (``autotune``) can be the wrong
+    one.  ``burst`` steps are launched back to back between the two events of one sample (a loop of steps overlaps the tail of
+    one with the head of the next; a lone step does not); ``passes`` > 1 walks the launches again while the previous walk
+    changed something (a launch's best schedule depends on what its neighbours run).  All candidates give identical bits.
+    Returns (ms per step before, after)."""
     global LAUNCH_LOG
 
     def clock():
@@ -543,10 +547,11 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None):
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            step_fn()
+            for _ in range(burst):
+                step_fn()
             e1.record()
             e1.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            ts.append(e0.elapsed_time(e1) / burst)
         ts.sort()
         return ts[len(ts) // 2]
 
@@ -561,27 +566,46 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None):
     for _ in range(3):
         step_fn()
     base = best = clock()
-    for plan, n, h, w in launches[:max_launches]:
-        if plan.rowpack:
-            continue
-        start = plan.launch_info(n, h, w)
-        chosen = None
-        for v, sk in plan.candidates(n, h, w):
-            plan.set_choice(n, h, w, v, sk)
-            t = clock()
-            if t < best * (1.0 - min_gain):
-                best, chosen = t, (v, sk)
-        if chosen is None:
-            plan._tuned.pop((n, h, w), None)
-            capi.call("sntc_conv_plan_clear_tuning", plan._h)    # back to the cost model for every shape of this plan ...
-            for (nn, hh, ww), (vv, ss) in list(plan._tuned.items()):
-                capi.call("sntc_conv_plan_set_choice", plan._h, nn, hh, ww, vv, ss)      # ... but the ones already chosen
-        else:
-            plan.set_choice(n, h, w, *chosen)
-        if log is not None:
-            log.append(dict(layer=f"{plan.kind} k{plan.k[0]} s{plan.stride} {plan.cin}->{plan.cout}", shape=[n, h, w], model=list(start),
-                            chosen=None if chosen is None else list(chosen), step_ms=round(best, 4)))
-    return base, best
+    for walk in range(max(1, int(passes))):
+        changed = False
+        for plan, n, h, w in launches[:max_launches]:
+            if plan.rowpack:
+                continue
+            start = plan.launch_info(n, h, w)
+            had = plan._tuned.get((n, h, w))
+
+            def restore():
+                if had is not None:
+                    plan.set_choice(n, h, w, *had)
+                else:
+                    plan._tuned.pop((n, h, w), None)
+                    capi.call("sntc_conv_plan_clear_tuning", plan._h)    # back to the cost model for every shape of this plan ...
+                    for (nn, hh, ww), (vv, ss) in list(plan._tuned.items()):
+                        capi.call("sntc_conv_plan_set_choice", plan._h, nn, hh, ww, vv, ss)      # ... but the ones already chosen
+
+            ref = clock()                        # what the launch runs now, measured next to its candidates (the clock drifts)
+            chosen, t_chosen = None, ref
+            for v, sk in plan.candidates(n, h, w):
+                plan.set_choice(n, h, w, v, sk)
+                if plan.launch_info(n, h, w) == start and (had is None or (v, sk) == tuple(had)):
+                    continue                                     # the launch `ref` was measured with
+                t = clock()
+                if t < t_chosen * (1.0 - min_gain):
+                    t = max(t, clock())                          # a winner has to win twice
+                    if t < t_chosen * (1.0 - min_gain):
+                        chosen, t_chosen = (v, sk), t
+            if chosen is not None:
+                plan.set_choice(n, h, w, *chosen)
+                changed = True
+            else:
+                restore()
+            best = t_chosen
+            if log is not None:
+                log.append(dict(layer=f"{plan.kind} k{plan.k[0]} s{plan.stride} {plan.cin}->{plan.cout}", shape=[n, h, w], start=list(start),
+                                chosen=None if chosen is None else list(chosen), ref_ms=round(ref, 4), step_ms=round(t_chosen, 4), walk=walk))
+        if not changed:
+            break
+    return base, best                # best: the last launch's sample of what the step now runs
 
 
 def export_tuning():
