@@ -647,6 +647,7 @@ static int build_host_plan(int k, int s, int cin, int ch, int has_res, HostPlan*
   const int cp = ch * (has_res ? 2 : 1);
   if (k < s || !dim_ok(k, s, (k - s) / 2)) return fail(SNTC_ERR_UNSUPPORTED, "sntc_syn: kernel / stride outside the nine-shift frame");
   if (cp != 12 && cp != 24 && cp != 48) return fail(SNTC_ERR_UNSUPPORTED, "sntc_syn: 12, 24 or 48 output columns per phase");
+  if (has_res && cp == 12) return fail(SNTC_ERR_UNSUPPORTED, "sntc_syn: 6 + 6 residual channels have no kernel instance");
   if (cin < 16 || cin % 16) return fail(SNTC_ERR_UNSUPPORTED, "sntc_syn: input channels must be a multiple of 16");
   if (s > 255) return fail(SNTC_ERR_UNSUPPORTED, "sntc_syn: stride");
   P->G = SynGeom{k, s, (k - s) / 2, cin, cp};

@@ -256,6 +256,8 @@ def test_fused_synthesis_refuses_what_it_does_not_cover():
     assert lib.sntc_syn_supported(18, 16, 320, 3, 0) == 0       # JPEG-like synthesis: 3 columns per phase
     assert lib.sntc_syn_supported(13, 8, 24, 12, 1) == 0        # input channels not a multiple of 16
     assert lib.sntc_syn_supported(29, 8, 32, 12, 1) == 0        # taps further than one pixel from the aligned source
+    assert lib.sntc_syn_supported(13, 8, 320, 6, 1) == 0        # 6 + 6 channels: no kernel instance (6 without residual neither)
+    assert lib.sntc_syn_supported(13, 8, 320, 6, 0) == 0
     assert lib.sntc_syn_supported(13, 8, 320, 12, 1) == 1 and lib.sntc_syn_supported(13, 8, 320, 24, 0) == 1
 
 
