@@ -849,6 +849,7 @@ extern "C" int sntc_syn_plan_create(int k, int stride, int cin, int ch, int has_
 
 extern "C" int sntc_syn_plan_update(sntc_syn_plan* p, const float* w1, const float* b1, const float* beta, const float* gamma, void* stream) {
   if (!p || !w1) return fail(SNTC_ERR_BAD_SHAPE, "sntc_syn_plan_update: null argument");
+  if ((p->act_kind == 1 || p->act_kind == 2) && (!beta || !gamma)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_syn_plan_update: GDN parameters missing");
   return syn_pack(p, w1, b1, beta, gamma, (hipStream_t)stream);
 }
 
