@@ -227,6 +227,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ops.side_streams(3, dev)          # the library's stream pool FIRST: the first three streams of a process own a hardware queue each
     world_info = D.describe_world(dev)                # one all_gather_object: backend, world, every rank's device
     if rccl_note:
         world_info["note"] = rccl_note
@@ -279,7 +280,7 @@ def main():
         return [model.decode(z_hat, sym, hw, check=False) for z_hat, sym, hw, _x in codes]
 
     nstreams = len(codes) if args.streams == 0 else args.streams
-    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
+    side = ops.side_streams(nstreams, dev) if nstreams > 1 else []      # the library's pool: its first three streams own a hardware queue each
 
     smap = [int(v) for v in args.stream_map.split(",")] if args.stream_map else None
 

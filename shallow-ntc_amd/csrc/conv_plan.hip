@@ -720,6 +720,10 @@ static Sched plan_schedule(const sntc_conv_plan* p, const Geo& g, int n, int h, 
       auto it = p->tuned.find({n, h, w});
       if (it != p->tuned.end()) { c = it->second; have = true; }
     }
+    // a measured stream-K choice says nothing about the static schedules: with stream-K switched off process-wide
+    // (sntc_conv_set_stream_k(0): a timed-out hand-off, or launches that run beside long-lived kernels) the cost model picks
+    // among the static candidates instead of running the stream-K tile one workgroup per tile
+    if (have && c.sk != 0 && !g_stream_k_enabled.load(std::memory_order_relaxed)) have = false;
     if (have) {
       const Sched s = schedule(p, g, n, false, &c);
       if (s.valid) return s;

@@ -173,6 +173,7 @@ def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+PIPELINE_BLOBS = True           # decompress_many: blobs pipelined largest first (False: round 4's two-phase schedule; same pixels)
 USE_START_TABLES = True         # decoder: its own tables in LDS, DeviceTables.dec / .lut (False: binary search of cdf; same values)
 
 ELEMS_PER_SEGMENT = 1 << 18     # one rANS stream (= one wave of coding parallelism, 256 bytes of flushed lane states) per
@@ -358,11 +359,13 @@ class Codec:
     def decompress_many(self, blobs):
         """Several bitstreams (e.g. one per batch shape of a set) -> their pixel batches, in order.  An entropy-decoding launch
         is a handful of lone waves whose time is a latency (one wave per stream, ~0.4 us per step of 64 symbols whatever the
-        batch), so the launches of ALL blobs run side by side on streams of their own: first every blob's hyper-latents, then --
-        after the hyper-syntheses, back on the caller's stream -- every blob's latents.  Only entropy decoding overlaps entropy
-        decoding: a decoding wave holds ~100 KB of tables in its CU's LDS and the stream-K convolutions need every one of their
-        workgroups resident, so a convolution launch that meets decoding waves simply waits for them (measured: groups of one
-        blob's images pipelined against each other's convolutions, 9.5 -> 10.9 / 12.7 / 17.6 ms with 2 / 3 / 4 groups)."""
+        batch), so the launches of ALL blobs' hyper-latents run side by side on streams of their own; then the blobs are
+        pipelined, largest first: blob k's latents decode on its stream while the caller's stream runs blob k + 1's
+        hyper-synthesis and, later, blob k - 1's synthesis.  A decoding wave holds ~100 KB of tables in its CU's LDS and a
+        stream-K convolution needs every one of its workers resident (round 4 measured what happens when they meet: groups of one
+        blob's images pipelined against each other's stream-K convolutions, 9.5 -> 10.9 / 12.7 / 17.6 ms with 2 / 3 / 4 groups),
+        so only the FIRST hyper-synthesis -- which meets no decoding wave -- keeps stream-K; the convolutions that may run beside
+        decoding waves take the static schedules (``ops.static_schedules``; same bits)."""
         m = self.m
         if not blobs:
             return []
@@ -410,22 +413,51 @@ class Codec:
                                                 (hd["n"], hd["hz"], hd["wz"], hd["cz"]), self.z_tables, hd["sz"], hd["lz"], bad=bad[2 * k:2 * k + 1],
                                                 offsets=offd[k][0]))
                 for k, hd in enumerate(heads)])
-            hypers, tids = [], []
-            for zi, hd in zip(zis, heads):
-                hyper = m._hyper_synthesis(int_to_float(zi))
+            # From here on the blobs are PIPELINED, largest first: a blob's latents decode on its side stream while the caller's
+            # stream runs the next blob's hyper-synthesis, and its synthesis runs while the later blobs' latents decode.  The first
+            # blob's hyper-synthesis meets no decoding wave and keeps its stream-K launches; every convolution after it may run
+            # beside decoding waves and takes the static schedules (ops.static_schedules: same bits).
+            piped = PIPELINE_BLOBS and len(heads) > 1 and side[0] is not main
+            order = sorted(range(len(heads)), key=lambda k: -(heads[k]["n"] * heads[k]["h"] * heads[k]["w"])) if piped else list(range(len(heads)))
+            hypers, syms, tidl = [None] * len(heads), [None] * len(heads), [None] * len(heads)
+
+            def launch_latents(k):
+                hd, st = heads[k], side[k]
+                if st is not main:
+                    st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    syms[k] = rans_decode(pay[k][1], hd["yl"], tidl[k], (hd["n"], hd["h"], hd["w"], hd["c"]), self.y_tables, hd["sy"], hd["ly"],
+                                          bad=bad[2 * k + 1:2 * k + 2], offsets=offd[k][1])
+                if st is not main:
+                    tidl[k].record_stream(st)
+
+            for i, k in enumerate(order):
+                hd = heads[k]
+                with ops.static_schedules(piped and i > 0):
+                    hyper = m._hyper_synthesis(int_to_float(zis[k]))
                 if tuple(hyper.shape) != (hd["n"], hd["h"], hd["w"], 2 * hd["c"]):
                     raise capi.SntcError(capi.ERR_BAD_SHAPE, f"hyper-synthesis output {tuple(hyper.shape)} does not match the latents "
                                          f"{(hd['n'], hd['h'], hd['w'], hd['c'])}")
-                hypers.append(hyper)
-                tids.append(scale_table_ids(hyper))
-            syms = side_by_side([
-                (lambda k=k, hd=hd: rans_decode(pay[k][1], hd["yl"], tids[k], (hd["n"], hd["h"], hd["w"], hd["c"]), self.y_tables, hd["sy"], hd["ly"],
-                                                bad=bad[2 * k + 1:2 * k + 2], offsets=offd[k][1]))
-                for k, hd in enumerate(heads)])
-            out = []
-            for sym, hyper, hd in zip(syms, hypers, heads):
-                y_hat = ops.dequant_split3(sym, hyper) if m._synthesis.takes_s3(hd["h"], hd["w"]) else ops.dequant_scale_normal(sym, hyper)
-                out.append(m._pixels(y_hat, (hd["H"], hd["W"])))
+                hypers[k] = hyper
+                tidl[k] = scale_table_ids(hyper)
+                if piped:
+                    launch_latents(k)
+            if not piped:                    # A/B (PIPELINE_BLOBS = False), round 4's schedule: every hyper-synthesis, then every blob's
+                for k in order:              # latents side by side, then the syntheses
+                    launch_latents(k)
+            out = [None] * len(heads)
+            if not piped:                    # A/B (PIPELINE_BLOBS = False): every blob's latents first, then the syntheses
+                for k in order:
+                    if side[k] is not main:
+                        main.wait_stream(side[k])
+            for i, k in enumerate(order):
+                hd, st = heads[k], side[k]
+                if st is not main:
+                    main.wait_stream(st)
+                    syms[k].record_stream(main)
+                with ops.static_schedules(piped and i + 1 < len(order)):
+                    y_hat = ops.dequant_split3(syms[k], hypers[k]) if m._synthesis.takes_s3(hd["h"], hd["w"]) else ops.dequant_scale_normal(syms[k], hypers[k])
+                    out[k] = m._pixels(y_hat, (hd["H"], hd["W"]))
             nbad = int(bad.sum().item())                           # synchronises the stream
             if nbad:
                 total = sum(hd["n"] * (hd["sz"] + hd["sy"]) for hd in heads)
@@ -434,9 +466,4 @@ class Codec:
             return out
 
     def _side_streams(self, count):
-        st = getattr(self, "_sides", None)
-        if st is None:
-            st = self._sides = []
-        while len(st) < count:
-            st.append(torch.cuda.Stream(device=self.m.device))
-        return st[:count]
+        return ops.side_streams(count, self.m.device)

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
 
 class DecodeGraph:
     """graph(z_hat, symbols) -> uint8 pixels [n, H, W, 3] (a static buffer, overwritten by the next call)."""
@@ -17,7 +19,7 @@ class DecodeGraph:
         self.z_hat = z_hat.clone()
         self.symbols = symbols.clone()
         with torch.cuda.device(model.device):
-            side = torch.cuda.Stream()
+            side = ops.side_streams(1, model.device)[0]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # warm-up off the capture: function attributes, allocator pools
                 for _ in range(warmup):
@@ -47,7 +49,7 @@ class DecodeSetGraph:
         self.model = model
         self.codes = [(z.clone(), s.clone(), tuple(hw)) for z, s, hw, *_ in codes]
         with torch.cuda.device(model.device):
-            self.streams = [torch.cuda.Stream() for _ in self.codes]
+            self.streams = ops.side_streams(len(self.codes), model.device)
             for _ in range(warmup):
                 self._launch()
             torch.cuda.synchronize()

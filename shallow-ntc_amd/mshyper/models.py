@@ -437,8 +437,7 @@ class Model:
             group = 1                                                 # per-transform times are per pass
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
-            if getattr(self, "_eval_streams", None) is None or len(self._eval_streams) < lookahead:
-                self._eval_streams = [torch.cuda.Stream(device=self.device) for _ in range(lookahead)]
+            self._eval_streams = ops.side_streams(lookahead, self.device)      # the library's one pool: a stream per hardware queue
             window = []                  # entries in input order: [x, metrics or None, launched]
             inflight = []                # (stream, pending, entries)
             it = iter(images)
@@ -553,8 +552,7 @@ class Model:
             return [self.decode(z, s, hw, reference=r, check=check) for z, s, hw, r in codes]
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
-            if getattr(self, "_set_streams", None) is None or len(self._set_streams) < len(codes):
-                self._set_streams = [torch.cuda.Stream(device=self.device) for _ in codes]
+            self._set_streams = ops.side_streams(len(codes), self.device)
             y_hats = []
             for st, (z_hat, sym, _hw, _r) in zip(self._set_streams, codes):
                 st.wait_stream(cur)

@@ -38,19 +38,47 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE_POOL = {}
+SIDE_POOL_MIN = 3
+
+
+def side_streams(n, device=None):
+    """The first ``n`` of the library's side streams on ``device`` (default: the current one): ONE pool per device, shared by
+    everything that keeps launches in flight side by side -- the two-stream decode / encode of a set, ``Model.decode_set``, the
+    look-ahead of ``Model.evaluate``, the blobs of ``decompress_many``, the attention block's branch (``companion_stream``).  A
+    process has FOUR hardware queues per device by default (``GPU_MAX_HW_QUEUES``); the default stream holds one, the first three
+    streams a process creates get one each, and every further stream SHARES a queue with an earlier one -- its kernels then wait
+    for that stream's, and an event recorded behind them waits as well (``tools/microbench/hw_queues.py`` prints the map; with
+    every component creating streams of its own, the pipelined ``decompress_many`` ran 6.35 ms in ``bench.py``'s process and
+    5.37 ms in a process with three streams).  The pool's first three streams are created together, on first use; asking for more
+    than three works and shares queues (raising ``GPU_MAX_HW_QUEUES`` instead costs the two-stream decode 5 %)."""
+    if device is None:
+        device = torch.cuda.current_device()
+    idx = device.index if isinstance(device, torch.device) else int(device)
+    if idx is None:
+        idx = torch.cuda.current_device()
+    pool = _SIDE_POOL.setdefault(idx, [])
+    while len(pool) < max(int(n), SIDE_POOL_MIN):
+        pool.append(torch.cuda.Stream(device=idx))
+    return pool[:int(n)]
+
+
 _COMPANIONS = {}
 
 
 def companion_stream():
-    """A second stream paired with the CURRENT one (one per current stream and device, created on first use): independent
-    sub-graphs of a small launch run on it next to the caller's stream.  None while a HIP graph is being captured or a
-    schedule is being measured (ops.autotune times launches with the device to itself)."""
+    """A second stream paired with the CURRENT one (one per current stream and device, created on first use -- AFTER the pool
+    above, so that it never takes one of the pool's hardware queues: it shares one, which costs nothing where it is used, a lone
+    image's attention branches with the pool idle): independent sub-graphs of a small launch run on it next to the caller's
+    stream.  None while a HIP graph is being captured or a schedule is being measured (ops.autotune times launches with the
+    device to itself)."""
     if AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return None
     cur = torch.cuda.current_stream()
     key = (cur.device.index, cur.cuda_stream)
     st = _COMPANIONS.get(key)
     if st is None:
+        side_streams(SIDE_POOL_MIN, cur.device)
         st = _COMPANIONS[key] = torch.cuda.Stream(device=cur.device)
     return st
 
@@ -639,9 +667,35 @@ def import_tuning(entries):
         p.set_choice(n, h, w, v, sk)
 
 
+_STREAM_K = True
+
+
 def set_stream_k(enabled):
     """Process-wide default of the persistent stream-K schedule (bit-identical results either way)."""
+    global _STREAM_K
     capi.call("sntc_conv_set_stream_k", int(bool(enabled)))
+    _STREAM_K = bool(enabled)
+
+
+class static_schedules:
+    """``with ops.static_schedules(): ...`` -- the convolutions launched inside take the one-workgroup-per-tile / split-K schedules
+    instead of persistent stream-K workers (same bits): for launches that run BESIDE kernels which hold CUs for long -- the lone
+    waves of an entropy decode with their tables in LDS -- where stream-K's workers would not all be resident.  The switch is the
+    process-wide one (a host-side decision per launch); it is restored on exit."""
+
+    def __init__(self, active=True):
+        self.active = bool(active)
+
+    def __enter__(self):
+        self._was = _STREAM_K
+        if self.active and self._was:
+            set_stream_k(False)
+        return self
+
+    def __exit__(self, *exc):
+        if self.active and self._was:
+            set_stream_k(True)
+        return False
 
 
 def gdn_small(x, beta, gamma, inverse=False, alpha=1, epsilon=1.0):

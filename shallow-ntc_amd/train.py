@@ -592,7 +592,7 @@ class Trainer:
         side = None
         if self.overlap_wgrad:
             if getattr(self, "_wgrad_stream", None) is None:
-                self._wgrad_stream = torch.cuda.Stream(device=x.device)
+                self._wgrad_stream = ops.side_streams(1, x.device)[0]
             side = self._wgrad_stream
 
         def notify(name):

@@ -482,3 +482,30 @@ def test_counted_flops_are_the_reference_tables(kodak_model, dev):
     from shallow_ntc_amd.sga import TwoLayerBackward
     bw = TwoLayerBackward(m._synthesis)
     assert bw.up_adj.cin == 32 and bw.up_adj.flops(1, 256, 384) == 2 * 32 * 48 * 169 * 24 * 320      # 24 real channels, padded to 32
+
+
+def test_static_schedules_switch_off_stream_k_and_restore_it(dev):
+    """``with ops.static_schedules():`` -- the launches inside leave the persistent stream-K workers alone (what
+    ``decompress_many`` asks of the convolutions that run beside entropy-decoding waves); same bits, the switch comes back."""
+    from shallow_ntc_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    p = ops.ConvPlan("convT", torch.randn((3, 3, 256, 480), device=dev, generator=g) * 0.02, None, 1)
+    x = torch.randn((18, 32, 48, 480), device=dev, generator=g)
+    shape = tuple(x.shape[:3])
+    info = p.launch_info(*shape)
+    want = p(x).clone()
+    assert ops._STREAM_K
+    with ops.static_schedules():
+        assert not ops._STREAM_K
+        inside = p.launch_info(*shape)
+        got = p(x).clone()
+        with ops.static_schedules():                     # nested: the inner block leaves the switch as it found it
+            assert not ops._STREAM_K
+        assert not ops._STREAM_K
+    assert ops._STREAM_K and p.launch_info(*shape) == info
+    assert inside != info, "the launch was expected to be a stream-K one outside the block"
+    assert torch.equal(got, want)
+    with ops.static_schedules(False):                    # inactive: nothing changes
+        assert ops._STREAM_K and p.launch_info(*shape) == info
+    ops.check_conv_status()

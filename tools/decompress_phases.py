@@ -24,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--no-lut", action="store_true")
 ap.add_argument("--one-by-one", action="store_true", help="one decompress() per blob instead of decompress_many()")
+ap.add_argument("--small-first", action="store_true", help="hand decompress_many the small blob first (bench.py's order)")
+ap.add_argument("--two-phase", action="store_true", help="A/B: round 4's schedule (all hyper-syntheses, then all latents side by side, then the syntheses)")
 args = ap.parse_args()
 if args.no_lut:
     ec.USE_START_TABLES = False
@@ -37,6 +39,10 @@ model.set_weights(w)
 batches = [torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(n, h, ww, seed=s))).to(dev)
            for n, h, ww, s in ((18, 512, 768, 1), (6, 768, 512, 2))]
 blobs = [model.compress(x) for x in batches]
+if args.small_first:
+    blobs = blobs[::-1]
+if args.two_phase:
+    ec.PIPELINE_BLOBS = False
 print("blob bytes", [len(b) for b in blobs], "bpp %.4f" % (8.0 * sum(len(b) for b in blobs) / (24 * 512 * 768)))
 
 marks = []
