@@ -509,3 +509,22 @@ def test_static_schedules_switch_off_stream_k_and_restore_it(dev):
     with ops.static_schedules(False):                    # inactive: nothing changes
         assert ops._STREAM_K and p.launch_info(*shape) == info
     ops.check_conv_status()
+
+
+def test_the_library_draws_its_side_streams_from_one_pool(dev):
+    """ops.side_streams: one pool per device -- the same stream objects for every caller (a process has four hardware queues;
+    streams beyond the first three share one), growing on demand; the attention block's companion is not one of them."""
+    from shallow_ntc_amd import ops
+    a = ops.side_streams(2, dev)
+    b = ops.side_streams(3, dev)
+    assert len(a) == 2 and len(b) == 3 and a[0] is b[0] and a[1] is b[1]
+    assert len({s.cuda_stream for s in b}) == 3 and all(s.cuda_stream != torch.cuda.current_stream().cuda_stream for s in b)
+    five = ops.side_streams(5, dev)
+    assert five[:3] == b and len({s.cuda_stream for s in five}) == 5
+    assert ops.side_streams(0, dev) == []
+    comp = ops.companion_stream()
+    assert comp is not None and comp.cuda_stream not in {s.cuda_stream for s in five}
+    assert ops.companion_stream() is comp                       # one per current stream
+    with torch.cuda.stream(b[0]):
+        other = ops.companion_stream()
+    assert other is not comp and other.cuda_stream not in {s.cuda_stream for s in five}
