@@ -453,16 +453,22 @@ def main():
     if not args.no_autotune and not args.graph and not args.no_decode_tune:
         t0 = time.perf_counter()
         want_px = [o.clone() for o in decode_step()]
-        tlog = []
+        tlog, tune_error = [], None
         tfile = Path(args.tuning_file) if args.tuning_file else None
         if rank == 0 and tfile is not None and tfile.exists():      # choices measured by an earlier run of this command (profiling runs)
             saved = json.loads(tfile.read_text())
             ops.import_tuning([tuple(e) for e in saved["entries"]])
             decode_tuning = dict(saved["decode_tuning"], source=str(tfile))
         elif rank == 0:
-            before, after = ops.tune_step(decode_step, reps=9, burst=4, passes=2, log=tlog)
-            decode_tuning = dict(step_ms_before=round(before, 4), step_ms_after=round(after, 4),
-                                 chosen=[dict(layer=r["layer"], shape=r["shape"], start=r["start"], chosen=r["chosen"]) for r in tlog if r["chosen"]])
+            try:
+                before, after = ops.tune_step(decode_step, reps=9, burst=4, passes=2, log=tlog)
+            except Exception as e:                   # noqa: BLE001 -- e.g. the step's stream-K hand-offs do not hold on a shared device: the
+                before = after = None                # library is on its static schedules from here on (same bits) and the line says so
+                tlog = [dict(rolled_back=True)]
+                tune_error = f"{type(e).__name__}: {e}"
+            decode_tuning = dict(step_ms_before=None if before is None else round(before, 4), step_ms_after=None if after is None else round(after, 4),
+                                 chosen=[dict(layer=r["layer"], shape=r["shape"], start=r["start"], chosen=r["chosen"]) for r in tlog if r.get("chosen")],
+                                 rolled_back=any(r.get("rolled_back") for r in tlog), **({"error": tune_error} if tune_error else {}))
             if tfile is not None:
                 tfile.write_text(json.dumps(dict(entries=ops.export_tuning(), decode_tuning=decode_tuning)))
         if world > 1:

@@ -520,14 +520,21 @@ class ConvPlan:
         return y
 
 
+def take_conv_status():
+    """The device's sticky stream-K status word, exchanged with 0 (sntc_conv_status; synchronises the current stream): non-zero
+    = a launch since the last call gave up waiting for a hand-off and its results are invalid.  ``check_conv_status`` is the
+    raising form; ``tune_step`` uses this one to drop a candidate schedule that does not hold beside the step's other streams."""
+    flags = C.c_int(0)
+    capi.call("sntc_conv_status", C.byref(flags), _stream())
+    return int(flags.value)
+
+
 def check_conv_status():
     """Call where the host synchronises anyway: raises if a stream-K launch since the last check gave up waiting for a
     neighbour's hand-off (an oversubscribed device; include/sntc.h "Stream-K health").  The schedule is switched to the
     static one for the rest of the process, so the caller can simply run the step again."""
-    flags = C.c_int(0)
-    capi.call("sntc_conv_status", C.byref(flags), _stream())
-    if flags.value:
-        capi.call("sntc_conv_set_stream_k", 0)
+    if take_conv_status():
+        set_stream_k(False)
         raise capi.SntcError(capi.ERR_HIP, "a stream-K hand-off timed out (the device is shared with other streams / processes): "
                                            "the results since the last check are invalid; stream-K is now off, run the step again")
 
@@ -593,7 +600,13 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
     launches.sort(key=lambda e: -e[0].flops(e[1], e[2], e[3]))
     for _ in range(3):
         step_fn()
+    check_conv_status()                      # what ran before this call is the caller's: raise here, not on a candidate
     base = best = clock()
+    if take_conv_status():
+        set_stream_k(False)
+        raise capi.SntcError(capi.ERR_HIP, "tune_step: a stream-K hand-off of the step timed out with the schedules it came with; "
+                                           "stream-K is now off, run the step again")
+    rollback = []                            # every launch back to what it came with (first walk's view)
     for walk in range(max(1, int(passes))):
         changed = False
         for plan, n, h, w in launches[:max_launches]:
@@ -602,7 +615,7 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
             start = plan.launch_info(n, h, w)
             had = plan._tuned.get((n, h, w))
 
-            def restore():
+            def restore(plan=plan, n=n, h=h, w=w, had=had):
                 if had is not None:
                     plan.set_choice(n, h, w, *had)
                 else:
@@ -611,7 +624,12 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
                     for (nn, hh, ww), (vv, ss) in list(plan._tuned.items()):
                         capi.call("sntc_conv_plan_set_choice", plan._h, nn, hh, ww, vv, ss)      # ... but the ones already chosen
 
+            if walk == 0:
+                rollback.append(restore)
+
             ref = clock()                        # what the launch runs now, measured next to its candidates (the clock drifts)
+            if take_conv_status():
+                ref = float("inf")               # ... and it does not hold here: any candidate that does wins
             chosen, t_chosen = None, ref
             for v, sk in plan.candidates(n, h, w):
                 plan.set_choice(n, h, w, v, sk)
@@ -620,8 +638,10 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
                 t = clock()
                 if t < t_chosen * (1.0 - min_gain):
                     t = max(t, clock())                          # a winner has to win twice
-                    if t < t_chosen * (1.0 - min_gain):
-                        chosen, t_chosen = (v, sk), t
+                if take_conv_status():
+                    continue                                     # a hand-off timed out beside the step's other streams: not a candidate here
+                if t < t_chosen * (1.0 - min_gain):
+                    chosen, t_chosen = (v, sk), t
             if chosen is not None:
                 plan.set_choice(n, h, w, *chosen)
                 changed = True
@@ -633,6 +653,19 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
                                 chosen=None if chosen is None else list(chosen), ref_ms=round(ref, 4), step_ms=round(t_chosen, 4), walk=walk))
         if not changed:
             break
+    for _ in range(3):                       # what was settled on has to hold together
+        step_fn()
+    if take_conv_status():
+        for undo in rollback:
+            undo()
+        for _ in range(3):
+            step_fn()
+        if take_conv_status():
+            set_stream_k(False)
+            raise capi.SntcError(capi.ERR_HIP, "tune_step: stream-K hand-offs of the step time out; stream-K is now off, run the step again")
+        if log is not None:
+            log.append(dict(rolled_back=True))
+        return base, base
     return base, best                # best: the last launch's sample of what the step now runs
 
 

@@ -442,7 +442,31 @@ def test_tuned_schedule_is_a_speed_choice_only(dev):
     had = {id(p): dict(p._tuned) for p in (pa, pb)}
     log2 = []
     t2, t3 = ops.tune_step(step, reps=3, burst=3, passes=2, min_gain=0.5, log=log2)      # nothing gains 50 %: every choice stays
-    assert t2 > 0 and t3 > 0 and all(r["chosen"] is None for r in log2) and {id(p): dict(p._tuned) for p in (pa, pb)} == had
+    assert t2 > 0 and t3 > 0 and all(r.get("chosen") is None for r in log2) and {id(p): dict(p._tuned) for p in (pa, pb)} == had
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(outs["a"], want[0]) and torch.equal(outs["b"], want[1])
+    # a step whose stream-K hand-offs time out (the status word, injected): no candidate is taken from such samples, the
+    # launches keep what they came with, and the call ends like check_conv_status -- stream-K off, an error
+    from shallow_ntc_amd import _capi as capi_mod
+    calls = {"n": 0, "from": 0}
+
+    def flagged_step():
+        step()
+        calls["n"] += 1
+        if calls["n"] > calls["from"]:
+            capi_mod.call("sntc_conv_status_inject", 1, ops._stream())
+
+    for clean_calls, message in ((4, "timed out with the schedules it came with"),     # flagged from the first sample on
+                                 (8, "hand-offs of the step time out")):              # ... from the candidates on: none is taken
+        calls.update(n=0)
+        calls["from"] = clean_calls
+        with pytest.raises(capi_mod.SntcError, match=message):
+            ops.tune_step(flagged_step, reps=2, log=[])
+        assert not ops._STREAM_K and {id(p): dict(p._tuned) for p in (pa, pb)} == had
+        ops.set_stream_k(True)
+        ops.take_conv_status()
+    assert ops._STREAM_K and ops.take_conv_status() == 0
     step()
     torch.cuda.synchronize()
     assert torch.equal(outs["a"], want[0]) and torch.equal(outs["b"], want[1])
