@@ -616,7 +616,7 @@ def main():
         torch.cuda.synchronize()
         codec_setup_s = time.perf_counter() - t0
         blobs = []
-        comp_fn = lambda: blobs.__setitem__(slice(None), [bs_model.compress(x) for _ids, x, _hw in batches])
+        comp_fn = lambda: blobs.__setitem__(slice(None), bs_model.compress_many([x for _ids, x, _hw in batches]))
         tune(comp_fn)
         st_c, st_d = {}, {}
         timed(comp_fn, 5, 2, st_c)

@@ -194,9 +194,9 @@ def _lanes(elems_per_stream, lanes=None):
     return 64 if elems_per_stream >= 16384 else 32 if elems_per_stream >= 6144 else 16 if elems_per_stream >= 2048 else 8
 
 
-def rans_encode(values, table_ids, tables: DeviceTables, segments=None, lanes=None):
-    """values int32 [n, ...], table_ids uint16 (int16 storage) same shape -> (payload int16-storage words on the
-    device, len_words int64[n * segments])."""
+def rans_encode_launch(values, table_ids, tables: DeviceTables, segments=None, lanes=None):
+    """The device half of ``rans_encode``: every stream coded into its own ``cap``-word scratch row, no host synchronisation.
+    -> (scratch int16 [streams, cap], lens int32 [streams]) for ``rans_encode_finish``."""
     n = values.shape[0]
     E = values.numel() // n
     segments = _segments(E, segments)
@@ -208,12 +208,25 @@ def rans_encode(values, table_ids, tables: DeviceTables, segments=None, lanes=No
     lens = torch.empty((ns,), dtype=torch.int32, device=dev)
     capi.call("sntc_rans_encode", _p(values), _p(table_ids), n, E, segments, lanes, _p(tables.cdf), _p(tables.meta), tables.ntables,
               tables.total, cap, _p(scratch), _p(lens), ops._stream())
-    lens_h = lens.cpu().numpy().astype(np.int64)
+    return scratch, lens
+
+
+def rans_encode_finish(scratch, lens, lens_h):
+    """The streams of ``rans_encode_launch`` packed back to back: ``lens_h`` = ``lens`` on the host (int64).  -> payload (device)."""
+    dev = scratch.device
     offsets = np.concatenate([[0], np.cumsum(lens_h)]).astype(np.int64)
     payload = torch.empty((int(offsets[-1]),), dtype=torch.int16, device=dev)
     offs_d = torch.from_numpy(offsets).to(dev)
-    capi.call("sntc_rans_compact", _p(scratch), cap, _p(lens), _p(offs_d), ns, _p(payload), ops._stream())
-    return payload, lens_h
+    capi.call("sntc_rans_compact", _p(scratch), scratch.shape[1], _p(lens), _p(offs_d), scratch.shape[0], _p(payload), ops._stream())
+    return payload
+
+
+def rans_encode(values, table_ids, tables: DeviceTables, segments=None, lanes=None):
+    """values int32 [n, ...], table_ids uint16 (int16 storage) same shape -> (payload int16-storage words on the
+    device, len_words int64[n * segments])."""
+    scratch, lens = rans_encode_launch(values, table_ids, tables, segments, lanes)
+    lens_h = lens.cpu().numpy().astype(np.int64)
+    return rans_encode_finish(scratch, lens, lens_h), lens_h
 
 
 def rans_decode(payload, lens_h, table_ids, shape, tables: DeviceTables, segments=None, lanes=None, bad=None, offsets=None):
@@ -314,6 +327,58 @@ class Codec:
         head = MAGIC + struct.pack(self.HEAD, VERSION | (ARITH[m._precision] << 8), n, H, W, y.shape[-1], z.shape[-1], z.shape[1], z.shape[2], y.shape[1], y.shape[2],
                                    sz, sy, lz, ly)
         return head + zl.astype("<u4").tobytes() + yl.astype("<u4").tobytes() + zb + yb
+
+    def compress_many(self, xs):
+        """``compress`` for several batches (e.g. one per image size of a set) -> their bitstreams, in order, byte for byte what one
+        ``compress`` per batch returns.  The batches' transforms and entropy-coding launches run side by side on the library's
+        side streams; the stream lengths of ALL batches come back in one copy, the packed payloads in another -- two host
+        synchronisations for the set instead of four per batch."""
+        m = self.m
+        xs = [m._as_device_images(x) for x in xs]
+        if not xs:
+            return []
+        with torch.cuda.device(m.device):
+            main = torch.cuda.current_stream()
+            side = ops.side_streams(len(xs), m.device) if len(xs) > 1 and not torch.cuda.is_current_stream_capturing() else [main] * len(xs)
+            jobs = []
+            for st, x in zip(side, xs):
+                if st is not main:
+                    st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    lat = m.infer_latent_rvs(x)
+                    z, y = lat.uq[0].loc, lat.uq[1].loc
+                    zi = round_to_int(z)
+                    hyper = m._hyper_synthesis(int_to_float(zi))
+                    _, _, sym = ops.entropy_scale_normal(y, hyper, want_symbols=True)
+                    sz, sy = _segments(zi[0].numel()), _segments(sym[0].numel())
+                    lz, ly = _lanes(-(-zi[0].numel() // sz)), _lanes(-(-sym[0].numel() // sy))
+                    zs, zlen = rans_encode_launch(zi, channel_table_ids(z.shape, m.device), self.z_tables, sz, lz)
+                    ys, ylen = rans_encode_launch(sym, scale_table_ids(hyper), self.y_tables, sy, ly)
+                jobs.append(dict(x=x, z=z, y=y, sz=sz, sy=sy, lz=lz, ly=ly, zs=zs, zlen=zlen, ys=ys, ylen=ylen, st=st))
+            for j in jobs:
+                if j["st"] is not main:
+                    main.wait_stream(j["st"])
+                    for t in (j["zs"], j["zlen"], j["ys"], j["ylen"]):
+                        t.record_stream(main)
+            lens_h = torch.cat([t for j in jobs for t in (j["zlen"], j["ylen"])]).cpu().numpy().astype(np.int64)     # read-back 1 of 2
+            pays, o = [], 0
+            for j in jobs:
+                nz, ny = j["zlen"].numel(), j["ylen"].numel()
+                j["zl"], j["yl"] = lens_h[o:o + nz], lens_h[o + nz:o + nz + ny]
+                o += nz + ny
+                pays += [rans_encode_finish(j["zs"], j["zlen"], j["zl"]), rans_encode_finish(j["ys"], j["ylen"], j["yl"])]
+            words = torch.cat(pays).cpu().numpy()                                                                    # read-back 2 of 2
+            ops.check_conv_status()       # the copies synchronised the stream: a flagged stream-K launch raises here, not a wrong file
+        out, o = [], 0
+        for j in jobs:
+            n, H, W, _ = j["x"].shape
+            z, y = j["z"], j["y"]
+            zw, yw = int(j["zl"].sum()), int(j["yl"].sum())
+            head = MAGIC + struct.pack(self.HEAD, VERSION | (ARITH[m._precision] << 8), n, H, W, y.shape[-1], z.shape[-1], z.shape[1], z.shape[2],
+                                       y.shape[1], y.shape[2], j["sz"], j["sy"], j["lz"], j["ly"])
+            out.append(head + j["zl"].astype("<u4").tobytes() + j["yl"].astype("<u4").tobytes() + words[o:o + zw + yw].tobytes())
+            o += zw + yw
+        return out
 
     def _parse(self, blob: bytes):
         """Header and stream lengths of one blob, checked against THIS model: nothing later trusts the header."""

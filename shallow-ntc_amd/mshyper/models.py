@@ -607,6 +607,11 @@ class Model:
         """Images -> self-contained bitstream (rANS over the integer CDF tables of both entropy models)."""
         return self._get_codec().compress(x)
 
+    def compress_many(self, xs):
+        """Several batches (e.g. one per image size of a set) -> their bitstreams; the batches' launches run side by side and
+        the set costs two host synchronisations (entropy_coding.Codec.compress_many).  Same bytes as one ``compress`` per batch."""
+        return self._get_codec().compress_many(list(xs))
+
     def decompress(self, blob: bytes):
         """Bitstream -> uint8 pixels [n, H, W, 3]; bit-identical to ``decode(encode(x))``."""
         return self._get_codec().decompress(blob)

@@ -139,6 +139,8 @@ def test_codec_round_trip_and_rate(dev):
     blobp = model.compress(xp)
     many = model.decompress_many([blob, blobp, blob0])
     assert torch.equal(many[0], px) and torch.equal(many[1], model.decompress(blobp)) and torch.equal(many[2], px0)
+    # ... and several batches compressed at once (their launches side by side, two read-backs for the set): the same bytes
+    assert model.compress_many([x, xp]) == [blob, blobp] and model.compress_many([xp]) == [blobp] and model.compress_many([]) == []
     # a flipped payload word is refused whether it sits in the hyper-latents' streams or in the latents' (one counter per
     # entropy-decoding launch, summed once)
     import struct as _st
