@@ -258,6 +258,9 @@ int sntc_dequant_split3(const int32_t* symbols, const float* hyper, int64_t npix
 int sntc_conv_status(int* flags, void* stream);
 int sntc_conv_status_inject(int flags, void* stream);
 int sntc_conv_set_stream_k(int enabled);
+/* The switch's current value (1 = stream-K where the schedule picks it): callers that turn it off around launches which run beside
+ * long-lived kernels (Python: ops.static_schedules) put back what they found. */
+int sntc_conv_get_stream_k(void);
 /* Gather-GEMM tile variant (1..7: 128 x 32v, 8: 64 x 64, 9: 128 x 128 as 64 x 64 per wave, 10: 256 x 128) picked for this call shape,
  * and the number of workgroups it launches; for profiling / roofline bookkeeping. */
 int sntc_conv_launch_info(const sntc_conv_plan* plan, int n, int h, int w, int* variant, int* nblocks);

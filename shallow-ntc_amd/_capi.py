@@ -87,6 +87,7 @@ SIGNATURES = {
     "sntc_conv_status": (C.c_int, [C.POINTER(C.c_int), _P]),
     "sntc_conv_status_inject": (C.c_int, [C.c_int, _P]),
     "sntc_conv_set_stream_k": (C.c_int, [C.c_int]),
+    "sntc_conv_get_stream_k": (C.c_int, []),
     "sntc_conv_launch_info": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sntc_conv_launch_order": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "sntc_conv_tune_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),

@@ -1021,6 +1021,8 @@ extern "C" int sntc_conv_set_stream_k(int enabled) {
   return SNTC_OK;
 }
 
+extern "C" int sntc_conv_get_stream_k(void) { return g_stream_k_enabled.load(std::memory_order_relaxed); }
+
 // read-and-clear in ONE atomic: a flag raised by a launch on another stream between a copy and a later memset would be lost
 __global__ void status_exchange_kernel(int* word, int* out) { *out = atomicExch(word, 0); }
 __global__ void status_or_kernel(int* word, int flags) { atomicOr(word, flags); }

@@ -700,14 +700,14 @@ def import_tuning(entries):
         p.set_choice(n, h, w, v, sk)
 
 
-_STREAM_K = True
-
-
 def set_stream_k(enabled):
     """Process-wide default of the persistent stream-K schedule (bit-identical results either way)."""
-    global _STREAM_K
     capi.call("sntc_conv_set_stream_k", int(bool(enabled)))
-    _STREAM_K = bool(enabled)
+
+
+def stream_k_enabled():
+    """The library's own switch (sntc_conv_get_stream_k), whoever set it last."""
+    return bool(capi.load().sntc_conv_get_stream_k())
 
 
 class static_schedules:
@@ -720,7 +720,7 @@ class static_schedules:
         self.active = bool(active)
 
     def __enter__(self):
-        self._was = _STREAM_K
+        self._was = stream_k_enabled()
         if self.active and self._was:
             set_stream_k(False)
         return self

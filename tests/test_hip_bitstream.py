@@ -223,4 +223,28 @@ def test_a_flagged_stream_k_launch_raises_in_every_codec_path(dev):
         with pytest.raises(_capi.SntcError, match="stream-K"):
             ops.check_conv_status()
     finally:
-        _capi.call("sntc_conv_set_stream_k", 1)
+        ops.set_stream_k(True)
+
+
+def test_many_blobs_of_mixed_sizes_in_any_order(dev):
+    """decompress_many pipelines its blobs largest first on the library's pooled streams (more blobs than the pool's three streams:
+    the pool grows, queues are shared): whatever the order they are handed in, every blob's pixels are those of its own
+    ``decompress``; repeated calls included.  compress_many returns the same bytes as one ``compress`` per batch."""
+    from shallow_ntc_amd.common import data_lib
+    from shallow_ntc_amd.mshyper import configs
+    from shallow_ntc_amd.mshyper.models import Model
+    from shallow_ntc_amd import ops
+    was = ops.stream_k_enabled()
+    model = Model(device=dev, **configs.two_layer_syn(rd_lambda=0.01))
+    shapes = [(3, 256, 384), (1, 384, 256), (2, 128, 128), (1, 512, 768), (2, 200, 120)]
+    xs = [torch.from_numpy(data_lib.normalize_image(data_lib.synthetic_images(n, h, w, seed=11 + i))).to(dev) for i, (n, h, w) in enumerate(shapes)]
+    blobs = [model.compress(x) for x in xs]
+    assert model.compress_many(xs) == blobs
+    want = [model.decompress(b) for b in blobs]
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        order = rng.permutation(len(blobs))
+        got = model.decompress_many([blobs[i] for i in order])
+        for i, px in zip(order, got):
+            assert torch.equal(px, want[i]), f"blob {i} in order {list(order)}"
+    assert ops.stream_k_enabled() == was                   # the static-schedule blocks left the process-wide switch as they found it

@@ -463,10 +463,10 @@ def test_tuned_schedule_is_a_speed_choice_only(dev):
         calls["from"] = clean_calls
         with pytest.raises(capi_mod.SntcError, match=message):
             ops.tune_step(flagged_step, reps=2, log=[])
-        assert not ops._STREAM_K and {id(p): dict(p._tuned) for p in (pa, pb)} == had
+        assert not ops.stream_k_enabled() and {id(p): dict(p._tuned) for p in (pa, pb)} == had
         ops.set_stream_k(True)
         ops.take_conv_status()
-    assert ops._STREAM_K and ops.take_conv_status() == 0
+    assert ops.stream_k_enabled() and ops.take_conv_status() == 0
     step()
     torch.cuda.synchronize()
     assert torch.equal(outs["a"], want[0]) and torch.equal(outs["b"], want[1])
@@ -519,19 +519,19 @@ def test_static_schedules_switch_off_stream_k_and_restore_it(dev):
     shape = tuple(x.shape[:3])
     info = p.launch_info(*shape)
     want = p(x).clone()
-    assert ops._STREAM_K
+    assert ops.stream_k_enabled()
     with ops.static_schedules():
-        assert not ops._STREAM_K
+        assert not ops.stream_k_enabled()
         inside = p.launch_info(*shape)
         got = p(x).clone()
         with ops.static_schedules():                     # nested: the inner block leaves the switch as it found it
-            assert not ops._STREAM_K
-        assert not ops._STREAM_K
-    assert ops._STREAM_K and p.launch_info(*shape) == info
+            assert not ops.stream_k_enabled()
+        assert not ops.stream_k_enabled()
+    assert ops.stream_k_enabled() and p.launch_info(*shape) == info
     assert inside != info, "the launch was expected to be a stream-K one outside the block"
     assert torch.equal(got, want)
     with ops.static_schedules(False):                    # inactive: nothing changes
-        assert ops._STREAM_K and p.launch_info(*shape) == info
+        assert ops.stream_k_enabled() and p.launch_info(*shape) == info
     ops.check_conv_status()
 
 
