@@ -356,6 +356,8 @@ KODAK_SHAPES = [(768, 512) if i in (3, 8, 9, 16, 17, 18) else (512, 768) for i i
 SETS = {
     "2.3bpp": dict(config="two_layer_syn", point="high_rate", precision="fp32", shapes=KODAK_SHAPES),
     "0.25bpp": dict(config="two_layer_syn", point=0.25, precision="fp32", shapes=KODAK_SHAPES),
+    "0.12bpp": dict(config="two_layer_syn", point=0.12, precision="fp32", shapes=KODAK_SHAPES[::2]),      # the published range's two ends
+    "0.5bpp": dict(config="two_layer_syn", point=0.5, precision="fp32", shapes=KODAK_SHAPES[::2]),        # on every second image (12)
     "jpegl/0.25bpp": dict(config="jpegl", point=0.25, precision="fp32", shapes=KODAK_SHAPES),
     "bf16x3/0.25bpp": dict(config="two_layer_syn", point=0.25, precision="bf16x3", shapes=KODAK_SHAPES),
     "two_layer_syn2/5x1200x1200/0.25bpp": dict(config="two_layer_syn2", point=0.25, precision="fp32", shapes=[(1200, 1200)] * 5),
