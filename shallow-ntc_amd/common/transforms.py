@@ -338,6 +338,7 @@ class _TwoLayerBase(Transform):
         if self._res_type == "d2s" and self._s[0] != 8:
             raise ValueError("res_type='d2s' upsamples by 2 x 2 x 2: the first layer's stride must be 8")
         super().__init__(None)
+        self._syn = None                  # the fused first-layer plan, created by build()
         self._names = ("base_conv", "res", "out_conv") if has_res else ("conv1", None, "conv2")
 
     def param_shapes(self, input_channels=None):
@@ -444,6 +445,12 @@ class _TwoLayerBase(Transform):
             return self._up(x)
         return ops.concat_channels(self._up(x), self._res_d2s(x))
 
+    def _ensure_built(self, x, cin=None):
+        """(Re)build on x's device if the transform has never been built there or its weights were replaced since
+        (Transform.set_weights clears _built_on): a direct caller must never run a plan packed from older weights."""
+        if self._built_on != x.device:
+            self.build(cin if cin is not None else (x.shape[-1] if x.dim() == 4 else x.shape[3] * 16), x.device)
+
     def _use_syn(self, x, alone=True):
         ok = self._syn is not None and ops.FUSED_SYNTHESIS and x.dim() == 4 and self._syn.fits(x)
         return ok and (not alone or self._syn.items([x]) >= ops.FUSED_SYNTHESIS_MIN_ITEMS)
@@ -451,13 +458,16 @@ class _TwoLayerBase(Transform):
     def hidden_many(self, xs):
         """act(base_conv(y_hat)) + res(y_hat) for a LIST of batches of different image sizes in one launch (None where the
         fused kernel does not apply: the caller then takes ``forward_pixels`` per batch)."""
-        if not 1 <= len(xs) <= 4 or not all(self._use_syn(x, alone=False) for x in xs) \
-                or self._syn.items(xs) < ops.FUSED_SYNTHESIS_MIN_ITEMS:
+        if not 1 <= len(xs) <= 4:
+            return None
+        self._ensure_built(xs[0])
+        if not all(self._use_syn(x, alone=False) for x in xs) or self._syn.items(xs) < ops.FUSED_SYNTHESIS_MIN_ITEMS:
             return None
         return self._syn(list(xs))
 
     def pixels_from_hidden(self, hid, h, w, reference=None):
         """The output layer on the hidden tensor (+ crop + uint8 + SSE): the tail kernel without activation and residual."""
+        self._ensure_built(hid, self._cin)
         return ops.two_layer_tail_pixels(hid, self._ch, False, 0, None, None, self._w2, self._b2, h, w, reference, self._k[1], self._s[1])
 
     def _forward(self, x):
@@ -471,8 +481,7 @@ class _TwoLayerBase(Transform):
     def forward_pixels(self, x, h, w, reference=None):
         """Decoder form: the synthesis ends in uint8 pixels cropped to h x w (and the integer SSE against ``reference``);
         for the fused shapes in the same launch as the activation and the output layer -- no float image round trip."""
-        if self._built_on != x.device:
-            self.build(x.shape[-1] if x.dim() == 4 else x.shape[3] * 16, x.device)
+        self._ensure_built(x)
         if self._fused and self._use_syn(x):
             return self.pixels_from_hidden(self._syn(x), h, w, reference)
         if self._fused:

@@ -262,6 +262,8 @@ __global__ void __launch_bounds__(512, 2) syn_kernel(const SynArgs a) {
   // epilogue and is drained by the wait that opens the item -- no step of the K loop ever waits for it
   int fetched = 0;
   if (tid == 0) fetched = atomicAdd(syn_args().queue, 1) + (int)gridDim.x;
+  int islot = 0;        // sh_item is double-buffered by item parity: slot p is rewritten two items later, i.e. behind a barrier that
+                        // every wave reaches only after its read of slot p (a single slot was a formal LDS race: ADVICE r5)
 
   while (true) {
     // ---- this item's lane geometry
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(512, 2) syn_kernel(const SynArgs a) {
     const int T = nslab * ns;
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (tid == 0) sh_item[0] = fetched;        // the item after this one (read by everybody behind the K loop's barriers)
+    if (tid == 0) sh_item[islot] = fetched;    // the item after this one (read by everybody behind the K loop's barriers)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -498,7 +500,8 @@ __global__ void __launch_bounds__(512, 2) syn_kernel(const SynArgs a) {
     }
 
     // ---- the next item: its first patch slabs and ring units travel while this item's results leave
-    const int item_next = __builtin_amdgcn_readfirstlane(sh_item[0]);
+    const int item_next = __builtin_amdgcn_readfirstlane(sh_item[islot]);
+    islot ^= 1;
     const Item Icur = I;
     const bool more = item_next < syn_args().nitems;
     if (more) {

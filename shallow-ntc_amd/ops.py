@@ -534,7 +534,7 @@ def check_conv_status():
     neighbour's hand-off (an oversubscribed device; include/sntc.h "Stream-K health").  The schedule is switched to the
     static one for the rest of the process, so the caller can simply run the step again."""
     if take_conv_status():
-        set_stream_k(False)
+        _latch_stream_k_off()
         raise capi.SntcError(capi.ERR_HIP, "a stream-K hand-off timed out (the device is shared with other streams / processes): "
                                            "the results since the last check are invalid; stream-K is now off, run the step again")
 
@@ -601,9 +601,9 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
     for _ in range(3):
         step_fn()
     check_conv_status()                      # what ran before this call is the caller's: raise here, not on a candidate
-    base = best = clock()
+    base = clock()
     if take_conv_status():
-        set_stream_k(False)
+        _latch_stream_k_off()
         raise capi.SntcError(capi.ERR_HIP, "tune_step: a stream-K hand-off of the step timed out with the schedules it came with; "
                                            "stream-K is now off, run the step again")
     rollback = []                            # every launch back to what it came with (first walk's view)
@@ -647,7 +647,6 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
                 changed = True
             else:
                 restore()
-            best = t_chosen
             if log is not None:
                 log.append(dict(layer=f"{plan.kind} k{plan.k[0]} s{plan.stride} {plan.cin}->{plan.cout}", shape=[n, h, w], start=list(start),
                                 chosen=None if chosen is None else list(chosen), ref_ms=round(ref, 4), step_ms=round(t_chosen, 4), walk=walk))
@@ -661,12 +660,15 @@ def tune_step(step_fn, reps=12, min_gain=0.004, max_launches=16, log=None, burst
         for _ in range(3):
             step_fn()
         if take_conv_status():
-            set_stream_k(False)
+            _latch_stream_k_off()
             raise capi.SntcError(capi.ERR_HIP, "tune_step: stream-K hand-offs of the step time out; stream-K is now off, run the step again")
         if log is not None:
             log.append(dict(rolled_back=True))
         return base, base
-    return base, best                # best: the last launch's sample of what the step now runs
+    after = clock()                          # the settled step, measured again (not the last launch's last sample)
+    if take_conv_status() or not (after == after and after != float("inf")):
+        after = base
+    return base, after
 
 
 def export_tuning():
@@ -700,8 +702,25 @@ def import_tuning(entries):
         p.set_choice(n, h, w, v, sk)
 
 
-def set_stream_k(enabled):
-    """Process-wide default of the persistent stream-K schedule (bit-identical results either way)."""
+STREAM_K_TIMED_OUT = False      # latched by check_conv_status / tune_step when a hand-off timed out: stream-K stays off for the process
+
+
+def _latch_stream_k_off():
+    """A stream-K hand-off timed out: static schedules for the rest of the process ("run the step again"); nothing that merely
+    restores an earlier setting (static_schedules.__exit__) may re-arm it."""
+    global STREAM_K_TIMED_OUT
+    STREAM_K_TIMED_OUT = True
+    capi.call("sntc_conv_set_stream_k", 0)
+
+
+def set_stream_k(enabled, force=False):
+    """Process-wide default of the persistent stream-K schedule (bit-identical results either way).  After a hand-off has timed
+    out in this process the switch stays off unless ``force`` (a caller that knows the device is its own again) is given."""
+    global STREAM_K_TIMED_OUT
+    if enabled and STREAM_K_TIMED_OUT and not force:
+        return
+    if enabled and force:
+        STREAM_K_TIMED_OUT = False
     capi.call("sntc_conv_set_stream_k", int(bool(enabled)))
 
 
@@ -714,7 +733,8 @@ class static_schedules:
     """``with ops.static_schedules(): ...`` -- the convolutions launched inside take the one-workgroup-per-tile / split-K schedules
     instead of persistent stream-K workers (same bits): for launches that run BESIDE kernels which hold CUs for long -- the lone
     waves of an entropy decode with their tables in LDS -- where stream-K's workers would not all be resident.  The switch is the
-    process-wide one (a host-side decision per launch); it is restored on exit."""
+    process-wide one (a host-side decision per launch); it is restored on exit -- unless a hand-off timed out inside the block
+    (check_conv_status / tune_step latch stream-K off for the process: set_stream_k(True) is then a no-op)."""
 
     def __init__(self, active=True):
         self.active = bool(active)

@@ -464,7 +464,13 @@ def test_tuned_schedule_is_a_speed_choice_only(dev):
         with pytest.raises(capi_mod.SntcError, match=message):
             ops.tune_step(flagged_step, reps=2, log=[])
         assert not ops.stream_k_enabled() and {id(p): dict(p._tuned) for p in (pa, pb)} == had
+        # the time-out latched stream-K off for the process: restoring an earlier setting does not re-arm it ...
         ops.set_stream_k(True)
+        assert not ops.stream_k_enabled()
+        with ops.static_schedules():
+            pass
+        assert not ops.stream_k_enabled()
+        ops.set_stream_k(True, force=True)       # ... only a caller that knows the device is its own again does
         ops.take_conv_status()
     assert ops.stream_k_enabled() and ops.take_conv_status() == 0
     step()
@@ -528,6 +534,18 @@ def test_static_schedules_switch_off_stream_k_and_restore_it(dev):
             assert not ops.stream_k_enabled()
         assert not ops.stream_k_enabled()
     assert ops.stream_k_enabled() and p.launch_info(*shape) == info
+    # a hand-off that times out INSIDE the block: check_conv_status switches stream-K off for the process, and leaving the block
+    # must not switch it back on
+    from shallow_ntc_amd import _capi as capi_mod
+    try:
+        with ops.static_schedules():
+            capi_mod.call("sntc_conv_status_inject", 1, ops._stream())
+            with pytest.raises(capi_mod.SntcError, match="stream-K"):
+                ops.check_conv_status()
+        assert not ops.stream_k_enabled()
+    finally:
+        ops.set_stream_k(True, force=True)
+    assert ops.stream_k_enabled()
     assert inside != info, "the launch was expected to be a stream-K one outside the block"
     assert torch.equal(got, want)
     with ops.static_schedules(False):                    # inactive: nothing changes

@@ -547,3 +547,66 @@ def test_tuning_choices_travel_between_ranks_as_plain_data(dev):
     assert b._tuned == a._tuned and torch.equal(b(x), ref)
     with pytest.raises(capi.SntcError, match="same plans"):
         ops.import_tuning([(base + 1, "conv", 192, 96) + entries[0][4:]])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the hand-worked [DEP] known answers of tests/test_oracle_pins.py (SignalConv2D "same_zeros" origins, the sf / cdf pair
+# selection of the noisy priors) put to the HIP kernels directly -- numbers derived in that file by scalar arithmetic, not by the
+# oracle.  Integers below 2^24: the convolution results must be EXACT.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("axis", [0, 1])
+def test_signal_conv_origins_hand_kats_on_the_gpu(axis, dev):
+    from shallow_ntc_amd import ops
+    from tests.test_oracle_pins import KERAS_DOWN, KERAS_UP, SIG_DOWN, SIG_UP, SIG_W5, SIG_X6
+    c = 16                               # channel ch carries the pattern times (ch + 1) through a diagonal kernel
+
+    def line(vals):
+        a = np.asarray(vals, np.float32)[:, None] * np.arange(1, c + 1, dtype=np.float32)[None, :]
+        return a.reshape((1, -1, 1, c) if axis == 0 else (1, 1, -1, c))
+
+    def kernel(vals):
+        k = np.zeros((len(vals), c, c), np.float32)
+        for j, v in enumerate(vals):
+            k[j] = v * np.eye(c, dtype=np.float32)
+        return k.reshape((len(vals), 1, c, c) if axis == 0 else (1, len(vals), c, c))
+
+    def out_line(y):
+        y = y.cpu().numpy()[0]
+        ln, rest = (y[:, 0], y[:, 1:]) if axis == 0 else (y[0], y[1:])
+        assert not rest.any()
+        return ln
+
+    scale = np.arange(1, c + 1, dtype=np.float32)[None, :]
+    for kind, x, want in (("sigdown", SIG_X6, SIG_DOWN), ("conv", SIG_X6, KERAS_DOWN), ("sigup", SIG_X6[:3], SIG_UP),
+                          ("convT", SIG_X6[:3], KERAS_UP)):
+        plan = ops.ConvPlan(kind, dev_t(kernel(SIG_W5), dev), None, 2)
+        got = out_line(plan(dev_t(line(x), dev)))
+        np.testing.assert_array_equal(got, np.asarray(want, np.float32)[:, None] * scale, err_msg=kind)
+
+
+def test_prior_tail_selection_hand_kats_on_the_gpu(dev):
+    """The closed forms of tests/test_oracle_pins.py: logistic prior P(v) = sigmoid(9 (v + .5)) - sigmoid(9 (v - .5)) and the
+    normal far tails through the Mills series; fp32 kernels against float64 numbers: 2e-4 relative (the bpp bar is 1e-4 ABSOLUTE on
+    sums over ~5e5 symbols whose typical term is a few bits)."""
+    import math
+    from shallow_ntc_amd import ops
+    from tests.test_oracle_pins import _affine_prior, _log_sf_mills
+    c = 4
+    ms, bs, fs = _affine_prior(c, 0.0)
+    prior = ops.DeepFactorizedPrior([m.astype(np.float32) for m in ms], [b.astype(np.float32) for b in bs],
+                                    [f.astype(np.float32) for f in fs])
+    want0 = -math.log2(math.tanh(2.25))
+    want5 = (40.5 - math.log1p(-math.exp(-9.0)) + math.log1p(math.exp(-40.5))) / math.log(2)
+    for v, want in ((0.0, want0), (5.0, want5), (-5.0, want5), (0.4, want0), (4.6, want5)):
+        z_hat, bits = prior(dev_t(np.full((1, 1, 1, c), v), dev))
+        assert float(z_hat.flatten()[0]) == round(v)
+        assert abs(float(bits[0]) / c - want) <= 2e-4 * want, (v, float(bits[0]) / c, want)
+    s0 = 0.11
+    for v, lo, hi in ((20.0, 19.5 / s0, 20.5 / s0), (-3.0, 2.5 / s0, 3.5 / s0), (-20.0, 19.5 / s0, 20.5 / s0), (3.0, 2.5 / s0, 3.5 / s0)):
+        ls_lo, ls_hi = _log_sf_mills(lo), _log_sf_mills(hi)
+        want = -(ls_lo + math.log1p(-math.exp(ls_hi - ls_lo))) / math.log(2)
+        y = np.full((1, 1, 1, c), v, np.float32)
+        hyper = np.concatenate([np.zeros_like(y), np.full_like(y, -50.0)], -1)          # exp(raw) = 0 -> index 0 -> sigma 0.11
+        _, bits, sym = ops.entropy_scale_normal(dev_t(y, dev), dev_t(hyper, dev), want_symbols=True)
+        assert int(sym.flatten()[0]) == int(v)
+        assert abs(float(bits[0]) / c - want) <= 2e-4 * want, (v, float(bits[0]) / c, want)
