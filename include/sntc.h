@@ -177,6 +177,29 @@ int sntc_resblock_forward(const sntc_resblock_plan* plan, const float* x, int n,
 /* Cap the persistent workgroups of THIS plan's launches (0 = one per CU): tests assert that results do not depend on it. */
 int sntc_resblock_plan_set_workgroups(sntc_resblock_plan* plan, int max_workgroups);
 /* ------------------------------------------------------------------------------------------
+ * The RGB first layer of the analysis transforms (reference common/elic.py:147 through build_conv :253-270 -- Keras
+ * Conv2D(channels[0], 5, strides=2, padding="SAME") on the 3-channel image; common/transforms.py:183 CNNAnalysis' first layer) as
+ * ONE launch of a kernel of its own:  y[n, ceil(h/2), ceil(w/2), cout] = act(conv(x) + bias),  x [n, h, w, 3] NHWC fp32.
+ * A persistent workgroup owns 8 x 32 output pixels at a time (wave = tile row, lane = pixel, registers = all cout channels); the
+ * packed weights stay in LDS, the tile's 19-row input patch is double-buffered there (SAME padding = zeros in the patch: no
+ * padded copy of the image), and a pixel fragment is four consecutive floats of a patch row.  Every output is the same
+ * k-ordered fp32 fma chain as the row-packed gather-GEMM plan (sntc_conv_desc.reserved[2] == 1 on a zero-padded image):
+ * bit-identical to it, for any batch size and any number of workgroups.
+ *   w [k, k, 3, cout]: the Keras HWIO kernel (device pointer); bias [cout] or NULL; act: SNTC_ACT_NONE / RELU / LEAKY_RELU.
+ * sntc_rgbconv_supported: 1 where the kernel exists (cin = 3, stride 2, k <= 5, cout in {128, 192, 256}), else 0 -- callers
+ * then run the row-packed plan.  x and y < 2 GiB per call. */
+typedef struct sntc_rgbconv_plan sntc_rgbconv_plan;
+int sntc_rgbconv_supported(int k, int stride, int cin, int cout, int act);
+int sntc_rgbconv_plan_create(int k, int stride, int cin, int cout, const float* w, const float* bias, int act,
+                             void* stream, sntc_rgbconv_plan** plan);
+int sntc_rgbconv_plan_update(sntc_rgbconv_plan* plan, const float* w, const float* bias, void* stream);
+void sntc_rgbconv_plan_destroy(sntc_rgbconv_plan* plan);
+/* Algorithmic 2*MAC FLOPs of one call: 2 n ceil(h/2) ceil(w/2) k k 3 cout (sntc_conv_flops of the layer). */
+int64_t sntc_rgbconv_flops(const sntc_rgbconv_plan* plan, int n, int h, int w);
+int sntc_rgbconv_forward(const sntc_rgbconv_plan* plan, const float* x, int n, int h, int w, float* y, void* stream);
+/* Cap the persistent workgroups of THIS plan's launches (0 = one per CU): tests assert that results do not depend on it. */
+int sntc_rgbconv_plan_set_workgroups(sntc_rgbconv_plan* plan, int max_workgroups);
+/* ------------------------------------------------------------------------------------------
  * The first layer of the two-layer syntheses (reference common/transforms.py:298-317 TwoLayerSynthesis, :320-361
  * TwoLayerResSynthesis) in ONE launch:  hidden = act(base_conv(y_hat)) [+ res(y_hat)]  -- the tensor the reference hands to
  * its output convolution (:315, :359).  base_conv / res = Conv2DTranspose k x k / stride, SAME (:307-313, :331-338, :351-357);

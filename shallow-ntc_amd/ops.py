@@ -853,6 +853,74 @@ class RowPackedConv:
         return self.plan(pad_zero(x, pt, pl, pb, pr), res, aux)
 
 
+RGB_FIRST_LAYER = not os.environ.get("SNTC_NO_RGBCONV")     # the RGB first layer on its own kernel (csrc/rgb_conv.hip); False: the row-packed plan (same bits)
+
+
+class RgbConvPlan:
+    """The RGB first layer of the analysis transforms (reference common/elic.py:147, common/transforms.py:183: Keras Conv2D(k, 2,
+    SAME) on 3 channels) as one launch of its own kernel: sntc_rgbconv_plan (csrc/rgb_conv.hip) -- weights resident in LDS, the
+    input patch double-buffered, no padded copy of the image; bit-identical to ``RowPackedConv`` (the same fma chains)."""
+
+    @staticmethod
+    def supported(k, stride, cin, cout, act=None):
+        return act in ACTS and bool(capi.load().sntc_rgbconv_supported(int(k), int(stride), int(cin), int(cout), ACTS[act]))
+
+    def __init__(self, weight, bias, stride, act=None):
+        capi.require_gpu()
+        self.k, self.stride = int(weight.shape[0]), int(stride)
+        self.cin, self.cout = int(weight.shape[2]), int(weight.shape[3])
+        if weight.shape[0] != weight.shape[1]:
+            raise ValueError(f"first-layer kernel {tuple(weight.shape)} is not square")
+        w = weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        self._h = C.c_void_p()
+        capi.call("sntc_rgbconv_plan_create", self.k, self.stride, self.cin, self.cout, _ptr(w), _ptr(b), ACTS[act], _stream(), C.byref(self._h))
+        torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_rgbconv_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def update(self, weight, bias=None):
+        capi.call("sntc_rgbconv_plan_update", self._h, _ptr(weight), _ptr(bias), _stream())
+
+    def set_workgroups(self, n):
+        """Cap the persistent workgroups of this plan's launches (0: one per CU); tests: identical bits for any value."""
+        capi.call("sntc_rgbconv_plan_set_workgroups", self._h, int(n))
+
+    def out_hw(self, h, w):
+        return -(-h // self.stride), -(-w // self.stride)
+
+    def flops(self, n, h, w):
+        return int(capi.load().sntc_rgbconv_flops(self._h, n, h, w))
+
+    def __call__(self, x, res=None, aux=None):
+        if res is not None or aux is not None:
+            raise ValueError("the first-layer kernel has no epilogue operands")
+        _check_nhwc(x, self.cin)
+        n, h, w, _ = x.shape
+        ho, wo = self.out_hw(h, w)
+        if n > 1 and max(x.numel(), n * ho * wo * self.cout) * 4 >= MAX_INPUT_BYTES:
+            half = n // 2
+            return torch.cat([self(x[:half]), self(x[half:])])
+        y = torch.empty((n, ho, wo, self.cout), dtype=torch.float32, device=x.device)
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        capi.call("sntc_rgbconv_forward", self._h, _ptr(x), n, h, w, _ptr(y), _stream())
+        if prof is not None:
+            e1.record()
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=0, nblocks=0, vec=True, kind="rgbconv", k=self.k, s=self.stride,
+                             cin=self.cin, cout=self.cout, n=n, h=h, w=w))
+        return y
+
+
 def pad_reflect(x, hp, wp):
     _check_nhwc(x)
     n, h, w, c = x.shape

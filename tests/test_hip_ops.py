@@ -526,6 +526,71 @@ def test_row_packed_first_layer(k, s, cin, cout, n, h, w, act, dev):
         ops.ConvPlan("conv", dev_t(rng.standard_normal((5, 5, 4, 16)).astype(np.float32), dev), None, 2, rowpack=True)   # 5 * 4 > 16
 
 
+@pytest.mark.parametrize("k,cout,n,h,w,act", [(5, 192, 2, 64, 96, None), (5, 192, 1, 37, 41, "relu"), (5, 128, 3, 16, 18, "leaky_relu"),
+                                              (5, 256, 1, 33, 70, None), (3, 192, 1, 19, 23, None), (5, 192, 2, 130, 257, None),
+                                              (4, 128, 1, 9, 5, "relu"), (5, 192, 1, 1, 1, None)])
+def test_rgb_first_layer_kernel_is_bit_identical_to_the_row_packed_plan(k, cout, n, h, w, act, dev):
+    """csrc/rgb_conv.hip (reference common/elic.py:147, common/transforms.py:183): the RGB first layer on its own kernel --
+    weights resident in LDS, double-buffered input patch, SAME padding as zeros in the patch -- gives the SAME BITS as the
+    row-packed gather-GEMM plan it replaces (the same k-ordered fma chains), for even and odd sizes (asymmetric pads), tiles that
+    hang over the image, any number of persistent workgroups, an image alone or in a batch; and agrees with the float64 oracle's
+    Keras SAME convolution to the row-packed path's own accuracy."""
+    from shallow_ntc_amd import ops
+    assert ops.RgbConvPlan.supported(k, 2, 3, cout, act)
+    assert not ops.RgbConvPlan.supported(k, 1, 3, cout, act) and not ops.RgbConvPlan.supported(k, 2, 4, cout, act)
+    assert not ops.RgbConvPlan.supported(5, 2, 3, 64, act) and not ops.RgbConvPlan.supported(5, 2, 3, cout, "sigmoid")
+    rng = np.random.default_rng(k * 1000 + cout + h * 7 + w)
+    x = rng.standard_normal((n, h, w, 3)).astype(np.float32)
+    wk = (rng.standard_normal((k, k, 3, cout)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.ACTIVATIONS[act](O.conv2d(x, wk, b, 2))
+    rp = ops.RowPackedConv(dev_t(wk, dev), dev_t(b, dev), 2, act)
+    plan = ops.RgbConvPlan(dev_t(wk, dev), dev_t(b, dev), 2, act)
+    xd = dev_t(x, dev)
+    want = rp(xd)
+    got = plan(xd)
+    assert tuple(got.shape) == ref.shape and plan.out_hw(h, w) == ref.shape[1:3]
+    assert torch.equal(got, want)
+    assert rel_err(got.cpu().numpy(), ref) < 2e-6
+    assert plan.flops(n, h, w) == rp.flops(n, h, w) == 2 * n * ref.shape[1] * ref.shape[2] * k * k * 3 * cout
+    for wg in (1, 3, 7, 0):
+        plan.set_workgroups(wg)
+        assert torch.equal(plan(xd), want), wg
+    assert torch.equal(plan(xd[:1].contiguous()), want[:1])
+    # no bias; an in-place weight update
+    nb = ops.RgbConvPlan(dev_t(wk, dev), None, 2, act)
+    assert torch.equal(nb(xd), ops.RowPackedConv(dev_t(wk, dev), None, 2, act)(xd))
+    wk2 = (wk * 0.5 + 0.01).astype(np.float32)
+    plan.update(dev_t(wk2, dev), dev_t(b, dev))
+    assert torch.equal(plan(xd), ops.RowPackedConv(dev_t(wk2, dev), dev_t(b, dev), 2, act)(xd))
+    with pytest.raises(Exception):
+        plan(xd, res=want)
+
+
+def test_rgb_first_layer_kernel_inside_the_analysis_transform(dev):
+    """ElicAnalysis (reduced widths do not qualify: 192 channels here) gives the same latents with the first layer on its own
+    kernel and as the row-packed plan; empty batches pass through."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.common import transforms as TR
+    x = dev_t(np.random.default_rng(3).standard_normal((2, 64, 96, 3)).astype(np.float32) * 0.3, dev)
+    outs = []
+    for flag in (True, False):
+        old = ops.RGB_FIRST_LAYER
+        ops.RGB_FIRST_LAYER = flag
+        try:
+            t = TR.ElicAnalysis(channels=(192, 32, 32, 64))
+            first = None
+            y = t(x)
+            first = t._graph.layers[0].plan
+            assert isinstance(first, ops.RgbConvPlan if flag else ops.RowPackedConv)
+            outs.append(y)
+        finally:
+            ops.RGB_FIRST_LAYER = old
+    assert torch.equal(outs[0], outs[1])
+    plan = ops.RgbConvPlan(dev_t(np.zeros((5, 5, 3, 192), np.float32), dev), None, 2)
+    assert tuple(plan(torch.empty((0, 8, 8, 3), device=dev)).shape) == (0, 4, 4, 192)
+
+
 @pytest.mark.gpu
 def test_tuning_choices_travel_between_ranks_as_plain_data(dev):
     """ops.export_tuning() / import_tuning(): what rank 0 measured, applied by another rank's plans in creation order -- the
