@@ -177,9 +177,14 @@ def main():
     ap.add_argument("--no-autotune", action="store_true",
                     help="A/B: let the cost model pick every convolution's tile and schedule instead of measuring the candidates "
                          "once per layer shape before the timed regions (sntc_conv_plan_tune; same bits either way)")
-    ap.add_argument("--tuning-file", type=str, default="",
-                    help="the decode step's measured schedules as a file: written after measuring if absent, applied WITHOUT measuring if "
-                         "present (profiling runs: the same launches as the run that wrote it, no tuning launches in the trace)")
+    ap.add_argument("--tuning-file", type=str, default=str(ROOT / "profiles" / "tuning_gfx950.json"),
+                    help="the measured launch schedules of an earlier run of this command (every region's per-layer choices and the "
+                         "decode step's): applied WITHOUT measuring where present and matching (arch, workload, flags); what it does "
+                         "not cover is measured as before.  Same bits either way.  '' = measure everything")
+    ap.add_argument("--retune", action="store_true", help="ignore --tuning-file and measure every schedule again")
+    ap.add_argument("--write-tuning", type=str, default="",
+                    help="write this run's schedules (measured or applied) to this path at the end (copy it to profiles/tuning_gfx950.json "
+                         "to persist them; default: gpurun_out/tuning_gfx950.json when anything was measured)")
     ap.add_argument("--no-preheat", action="store_true",
                     help="skip the second measurement of the headline region behind 40 more warm-up steps (`sustained` in the line; "
                          "`value` itself never has them)")
@@ -412,6 +417,20 @@ def main():
         return dict(gflop_per_step=round(flops / 1e9, 2), tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4))
 
     tune_seconds = [0.0]
+    # Schedules persisted by an earlier run of the same command on the same architecture (21 s of every run
+    # went into re-measuring them): keyed by a fingerprint of what decides which plans exist and which shapes they see.
+    tune_fp = dict(arch=torch.cuda.get_device_properties(dev).gcnArchName.split(":")[0], workload=args.workload, images=len(shapes),
+                   decode_only=bool(args.decode_only))
+    saved_tuning, saved_applied = None, [0]
+    tpath = Path(args.tuning_file) if args.tuning_file and not args.retune and not args.no_autotune else None
+    if tpath is not None and tpath.exists():
+        try:
+            cand = json.loads(tpath.read_text())
+            if cand.get("fingerprint") == tune_fp:
+                cand["entries"] = [tuple(e) for e in cand["entries"]]
+                saved_tuning = cand
+        except (OSError, ValueError, KeyError):
+            saved_tuning = None
 
     def tune(fn):
         """One untimed, serial, single-stream pass of a region's step in which every convolution plan measures its (tile,
@@ -423,8 +442,12 @@ def main():
         if args.no_autotune:
             return
         t0 = time.perf_counter()
+        if saved_tuning is not None:       # an earlier run's choices: the step once as it is (its plans exist after that), then the entries
+            fn()
+            torch.cuda.synchronize()
+            saved_applied[0] = max(saved_applied[0], ops.import_tuning(saved_tuning["entries"], strict=False))
         if rank == 0:
-            with ops.autotune():
+            with ops.autotune():           # measures only what the entries above did not cover
                 fn()
         else:
             fn()
@@ -457,11 +480,10 @@ def main():
         t0 = time.perf_counter()
         want_px = [o.clone() for o in decode_step()]
         tlog, tune_error = [], None
-        tfile = Path(args.tuning_file) if args.tuning_file else None
-        if rank == 0 and tfile is not None and tfile.exists():      # choices measured by an earlier run of this command (profiling runs)
-            saved = json.loads(tfile.read_text())
-            ops.import_tuning([tuple(e) for e in saved["entries"]])
-            decode_tuning = dict(saved["decode_tuning"], source=str(tfile))
+        if rank == 0 and saved_tuning is not None and saved_tuning.get("decode_tuning") is not None:
+            # the step's choices as an earlier run of this command measured them (no tuning launches in this run)
+            saved_applied[0] = max(saved_applied[0], ops.import_tuning(saved_tuning["entries"], strict=False))
+            decode_tuning = dict(saved_tuning["decode_tuning"], source=str(tpath))
         elif rank == 0:
             try:
                 before, after = ops.tune_step(decode_step, reps=9, burst=4, passes=2, log=tlog)
@@ -472,8 +494,6 @@ def main():
             decode_tuning = dict(step_ms_before=None if before is None else round(before, 4), step_ms_after=None if after is None else round(after, 4),
                                  chosen=[dict(layer=r["layer"], shape=r["shape"], start=r["start"], chosen=r["chosen"]) for r in tlog if r.get("chosen")],
                                  rolled_back=any(r.get("rolled_back") for r in tlog), **({"error": tune_error} if tune_error else {}))
-            if tfile is not None:
-                tfile.write_text(json.dumps(dict(entries=ops.export_tuning(), decode_tuning=decode_tuning)))
         if world > 1:
             choices = D.share_from_rank0(ops.export_tuning() if rank == 0 else None)
             if rank != 0:
@@ -810,6 +830,8 @@ def main():
                          f"eager, {min(nstreams, len(codes))} concurrent streams (one per batch)" if nstreams > 1 and len(codes) > 1 else "eager"),
                         codes="synthetic latents: z_hat ~ round(N(0,9)), symbols ~ round(Laplace(0,2))",
                         launch_schedule="cost model" if args.no_autotune else
+                        (f"{saved_applied[0]} schedules of an earlier run of this command applied from {tpath.name} (fingerprint arch / workload / "
+                         f"flags matched), the rest " if saved_tuning is not None else "") +
                         f"measured before the timed regions ({tune_seconds[0]:.1f} s untimed; every candidate computes the same chains, same "
                         "bits): once per layer shape with the device idle (sntc_conv_plan_tune) for the single-stream regions; the "
                         "two-stream Kodak decode of `value` by bursts of its own step (ops.tune_step, `decode_tuning`)"
@@ -818,6 +840,14 @@ def main():
             encode_decode_mpixels_per_s=None if e2e_value is None else round(e2e_value, 2), sustained=sustained,
             regions=regions, rd=rd, roofline=roofline, cpu_baseline=cpu_baseline, rccl=world_info,
         )
+        # this run's schedules as a file for later runs (the box's copy of profiles/ does not travel back: gpurun_out/ does)
+        wpath = args.write_tuning or ("" if saved_tuning is not None or args.no_autotune else str(ROOT / "gpurun_out" / "tuning_gfx950.json"))
+        if wpath:
+            try:
+                Path(wpath).parent.mkdir(parents=True, exist_ok=True)
+                Path(wpath).write_text(json.dumps(dict(fingerprint=tune_fp, entries=ops.export_tuning(), decode_tuning=decode_tuning)))
+            except OSError:
+                pass
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     D.shutdown()
 

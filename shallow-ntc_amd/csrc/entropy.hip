@@ -201,6 +201,110 @@ __global__ void __launch_bounds__(256) factorized_kernel(const float* __restrict
   block_sum_to(acc, bits + img);
 }
 
+// ---- round 6: the same likelihood for the priors the reference actually builds (widths 1 -> W -> ... -> W -> 1, W = 3:
+// tfc.NoisyDeepFactorized(num_filters=(3, 3[, 3])), mshyper/models.py:135) with the thread owning a CHANNEL: its record
+// (softplus(matrix), bias, tanh(factor): 33 / 48 floats) is read once into registers, then a run of pixels streams past, coalesced
+// across the block's channels.  tanh as 1 - 2 / (exp(2 h) + 1) (absolute error 1e-7, scaled by |tanh(factor)| < 1 into the logits),
+// and  ln[sigmoid(u) - sigmoid(w)] = ln sigmoid(u) + ln(1 - e^(w - u)) - softplus(w)  with the small arguments of the logarithms
+// through their series -- about 250 vector instructions per symbol where the generic kernel above spends ~1500 (tanhf, log1pf,
+// expf of the device library, the 64-bit index arithmetic, 33 scattered parameter loads per symbol); VERDICT r5: 57 us of pure
+// latency for 4.4 MB on every encode.  Same integers; the bits agree with the float64 oracle as before (test_entropy_factorized).
+__device__ __forceinline__ float tanh_fast(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(exp_f(2.0f * x) + 1.0f);
+}
+
+__device__ __forceinline__ float ln1p_pos(float t) {      // ln(1 + t), 0 <= t <= 1
+  const float ser = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 0.2f, -0.25f), 0.33333334f), -0.5f), 1.0f);
+  return t < 0.03125f ? ser : logf(1.0f + t);
+}
+
+template <int NL, int W>
+struct DFRec {
+  float m0[W], b0[W], f0[W];                  // 1 -> W
+  float mh[NL > 2 ? NL - 2 : 1][W * W], bh[NL > 2 ? NL - 2 : 1][W], fh[NL > 2 ? NL - 2 : 1][W];   // W -> W
+  float ml[W], bl;                            // W -> 1
+};
+
+template <int NL, int W>
+__device__ __forceinline__ float df_logits_fast(const DFRec<NL, W>& r, float x) {
+  float hcur[W];
+#pragma unroll
+  for (int o = 0; o < W; ++o) {
+    const float s = r.b0[o] + r.m0[o] * x;
+    hcur[o] = s + r.f0[o] * tanh_fast(s);
+  }
+#pragma unroll
+  for (int k = 0; k < NL - 2; ++k) {
+    float hn[W];
+#pragma unroll
+    for (int o = 0; o < W; ++o) {
+      float s = r.bh[k][o];
+#pragma unroll
+      for (int i = 0; i < W; ++i) s += r.mh[k][o * W + i] * hcur[i];
+      hn[o] = s + r.fh[k][o] * tanh_fast(s);
+    }
+#pragma unroll
+    for (int o = 0; o < W; ++o) hcur[o] = hn[o];
+  }
+  float s = r.bl;
+#pragma unroll
+  for (int i = 0; i < W; ++i) s += r.ml[i] * hcur[i];
+  return s;
+}
+
+// grid (channel blocks of 256, pixel chunks, n); a thread = one channel, `chunk` consecutive pixels
+template <int NL, int W>
+__global__ void __launch_bounds__(256) factorized_fast_kernel(const float* __restrict__ rec_all, DFDesc d, const float* __restrict__ z,
+                                                              int hw, int c, int chunk, float* __restrict__ z_hat,
+                                                              double* __restrict__ bits, int values_only) {
+  const int img = blockIdx.z;
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (ch < c) {
+    const float* rec = rec_all + (size_t)ch * d.stride;
+    DFRec<NL, W> r;
+#pragma unroll
+    for (int o = 0; o < W; ++o) {
+      r.m0[o] = rec[d.off_m[0] + o];
+      r.b0[o] = rec[d.off_b[0] + o];
+      r.f0[o] = rec[d.off_f[0] + o];
+      r.ml[o] = rec[d.off_m[NL - 1] + o];
+    }
+    r.bl = rec[d.off_b[NL - 1]];
+#pragma unroll
+    for (int k = 0; k < NL - 2; ++k) {
+#pragma unroll
+      for (int e = 0; e < W * W; ++e) r.mh[k][e] = rec[d.off_m[k + 1] + e];
+#pragma unroll
+      for (int o = 0; o < W; ++o) {
+        r.bh[k][o] = rec[d.off_b[k + 1] + o];
+        r.fh[k][o] = rec[d.off_f[k + 1] + o];
+      }
+    }
+    const int p0 = blockIdx.y * chunk, p1 = min(p0 + chunk, hw);
+    const size_t base = (size_t)img * hw * c + ch;
+    float b = 0.0f;
+    for (int p = p0; p < p1; ++p) {
+      const float zin = z[base + (size_t)p * c];
+      const float v = values_only ? zin : rintf(zin);
+      const float hi = df_logits_fast<NL, W>(r, v + 0.5f);
+      const float lo = df_logits_fast<NL, W>(r, v - 0.5f);
+      // right of the median the survival pair: P = sigmoid(u) - sigmoid(w), u > w
+      const bool right = hi > 0.0f;
+      const float u = right ? -lo : hi, w = right ? -hi : lo;
+      const float dd = u - w;                                            // > 0: the logits are increasing
+      const float e1 = dd * fmaf(dd, fmaf(dd, fmaf(dd, fmaf(dd, 0.0083333338f, -0.041666668f), 0.16666667f), -0.5f), 1.0f);   // 1 - e^-dd, small dd
+      const float om = dd < 0.125f ? e1 : 1.0f - exp_f(-dd);
+      // ln sigmoid(u) = min(u, 0) - L(u), softplus(w) = max(w, 0) + L(w), L(x) = ln(1 + e^-|x|): no large terms that cancel
+      const float lnp = (fminf(u, 0.0f) - fmaxf(w, 0.0f)) + logf(om) - ln1p_pos(exp_f(-fabsf(u))) - ln1p_pos(exp_f(-fabsf(w)));
+      b -= fmaf(lnp, 1.925963033500011e-8f, lnp * 1.44269502162933349609375f);
+      if (!values_only) z_hat[base + (size_t)p * c] = v;
+    }
+    acc = (double)b;
+  }
+  block_sum_to(acc, bits + img);
+}
+
 }  // namespace sntc
 
 using namespace sntc;
@@ -273,6 +377,24 @@ extern "C" int sntc_entropy_factorized(const sntc_prior* prior, const float* z, 
   hipStream_t s = (hipStream_t)stream;
   if (int zrc = zero_async(bits, sizeof(double) * n, s)) return zrc;
   const int64_t per = hw * prior->channels;
+  const DFDesc& d = prior->d;
+  bool uniform3 = d.nl >= 3 && d.nl <= 4 && hw < (1 << 30) && n <= 65535;
+  for (int k = 1; k < d.nl; ++k) uniform3 = uniform3 && d.w[k] == 3;
+  if (uniform3) {
+    // a thread = a channel; pixel chunks sized for >= ~4 workgroups per CU's worth of waves without starving a thread of work
+    const int cblocks = (prior->channels + 255) / 256;
+    int chunk = 8;
+    while ((int64_t)cblocks * ((hw + chunk - 1) / chunk) * n > 8192 && chunk < 512) chunk *= 2;
+    const dim3 grid(cblocks, (unsigned)((hw + chunk - 1) / chunk), n);
+    if (grid.y <= 65535) {
+      if (d.nl == 3)
+        hipLaunchKernelGGL((factorized_fast_kernel<3, 3>), grid, dim3(256), 0, s, prior->rec, d, z, (int)hw, prior->channels, chunk, z_hat, bits, values_only);
+      else
+        hipLaunchKernelGGL((factorized_fast_kernel<4, 3>), grid, dim3(256), 0, s, prior->rec, d, z, (int)hw, prior->channels, chunk, z_hat, bits, values_only);
+      SNTC_HIP(hipGetLastError());
+      return SNTC_OK;
+    }
+  }
   hipLaunchKernelGGL(factorized_kernel, dim3(grid_for(per), n), dim3(256), 0, s, prior->rec, prior->d, z, hw,
                      prior->channels, z_hat, bits, values_only);
   SNTC_HIP(hipGetLastError());

@@ -686,20 +686,33 @@ def export_tuning():
     return out
 
 
-def import_tuning(entries):
-    """Apply another rank's ``export_tuning()``; a plan whose (kind, cin, cout) does not match the entry's is a job whose ranks
-    built different models: refused loudly."""
+def import_tuning(entries, strict=True):
+    """Apply another rank's ``export_tuning()`` (or a file of an earlier run: bench.py --tuning-file); a plan whose (kind, cin,
+    cout) does not match the entry's is a job whose ranks built different models: refused loudly -- unless ``strict`` is False
+    (choices persisted by an earlier PROCESS: entries of plans that do not exist yet, or no longer match, are skipped; every
+    candidate computes the same bits, so a stale entry can only cost speed).  Returns the number of entries applied."""
+    applied = 0
     for idx, kind, cin, cout, n, h, w, v, sk in entries:
         if idx >= len(_PLAN_REGISTRY):
+            if not strict:
+                continue
             raise capi.SntcError(capi.ERR_BAD_SHAPE, f"import_tuning: plan {idx} does not exist here ({len(_PLAN_REGISTRY)} plans "
                                  "were built): the ranks did not build the same plans in the same order")
         p = _PLAN_REGISTRY[idx]()
         if p is None:
             continue        # collected here already (the cyclic collector runs at different times on different ranks): nothing to tune
         if (p.kind, p.cin, p.cout) != (kind, cin, cout):
+            if not strict:
+                continue
             raise capi.SntcError(capi.ERR_BAD_SHAPE, f"import_tuning: plan {idx} here is {(p.kind, p.cin, p.cout)}, the entry was "
                                  f"measured on {(kind, cin, cout)}: the ranks did not build the same plans in the same order")
-        p.set_choice(n, h, w, v, sk)
+        try:
+            p.set_choice(n, h, w, v, sk)
+            applied += 1
+        except capi.SntcError:
+            if strict:
+                raise
+    return applied
 
 
 STREAM_K_TIMED_OUT = False      # latched by check_conv_status / tune_step when a hand-off timed out: stream-K stays off for the process

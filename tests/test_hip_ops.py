@@ -351,6 +351,39 @@ def test_entropy_factorized(num_filters, dev):
     assert np.abs(bits2.cpu().numpy() - ref_bits).max() / np.abs(ref_bits).max() < 2e-5
 
 
+@pytest.mark.parametrize("num_filters,c,shape", [((3, 3), 320, (3, 8, 12)), ((3, 3, 3), 320, (2, 5, 7)), ((3, 3), 48, (1, 40, 33)),
+                                                 ((3, 3), 260, (2, 1, 1))])
+def test_entropy_factorized_channel_per_thread_kernel(num_filters, c, shape, dev):
+    """Round 6: priors of widths 1 -> 3 -> ... -> 3 -> 1 (what the reference builds, mshyper/models.py:135) take a kernel in which a
+    thread owns a channel (csrc/entropy.hip factorized_fast_kernel): channel counts across the 256-thread block boundary, pixel
+    counts that do not fill the last chunk, the explicit-sample mode, far tails and ties -- against the float64 oracle, and the
+    same integers as ever."""
+    from oracle import model_np
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(c + shape[1])
+    p = model_np.init_deep_factorized(c, rng, num_filters)
+    for k in p:
+        p[k] = (p[k] + 0.3 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    nl = len(num_filters) + 1
+    ms = [p[f"prior/matrix_{k}"] for k in range(nl)]
+    bs = [p[f"prior/bias_{k}"] for k in range(nl)]
+    fs = [p[f"prior/factor_{k}"] for k in range(nl - 1)]
+    z = (rng.standard_normal(shape + (c,)) * 3).astype(np.float32)
+    z.reshape(-1)[:6] = [40.0, -55.0, 2.5, -0.5, 1.5, 0.49999997]
+    ref_v, ref_bits = O.batched_deep_factorized(z, ms, bs, fs)
+    prior = ops.DeepFactorizedPrior(ms, bs, fs)
+    z_hat, bits = prior(dev_t(z, dev))
+    np.testing.assert_array_equal(z_hat.cpu().numpy(), np.rint(z))
+    assert np.abs(bits.cpu().numpy() - ref_bits).max() / np.abs(ref_bits).max() < 2e-6
+    _, bits2 = prior(z_hat, values_only=True)
+    assert np.abs(bits2.cpu().numpy() - ref_bits).max() / np.abs(ref_bits).max() < 2e-6
+    # non-integer samples (the explicit-sample mode of the training / SGA paths' callers)
+    zs = (z + rng.uniform(-0.5, 0.5, z.shape)).astype(np.float32)
+    want = -O.deep_factorized_logprob(zs.astype(np.float64), ms, bs, fs).sum(axis=(1, 2, 3)) / np.log(2)
+    _, bits3 = prior(dev_t(zs, dev), values_only=True)
+    assert np.abs(bits3.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6
+
+
 def test_errors_are_loud(dev):
     from shallow_ntc_amd import _capi as capi
     from shallow_ntc_amd import ops
@@ -629,11 +662,20 @@ def test_signal_conv_origins_hand_kats_on_the_gpu(axis, dev):
         a = np.asarray(vals, np.float32)[:, None] * np.arange(1, c + 1, dtype=np.float32)[None, :]
         return a.reshape((1, -1, 1, c) if axis == 0 else (1, 1, -1, c))
 
-    def kernel(vals):
+    def kernel(vals, other=None):
+        """The 1-D pattern along ``axis`` through a diagonal (channel-wise) kernel; ``other``: a 5-tap delta at that index on the
+        second axis (the transposed kinds need kernel >= stride on both axes)."""
         k = np.zeros((len(vals), c, c), np.float32)
         for j, v in enumerate(vals):
             k[j] = v * np.eye(c, dtype=np.float32)
-        return k.reshape((len(vals), 1, c, c) if axis == 0 else (1, len(vals), c, c))
+        if other is None:
+            return k.reshape((len(vals), 1, c, c) if axis == 0 else (1, len(vals), c, c))
+        k2 = np.zeros((len(vals), len(vals), c, c), np.float32)
+        if axis == 0:
+            k2[:, other] = k
+        else:
+            k2[other, :] = k
+        return k2
 
     def out_line(y):
         y = y.cpu().numpy()[0]
@@ -642,9 +684,11 @@ def test_signal_conv_origins_hand_kats_on_the_gpu(axis, dev):
         return ln
 
     scale = np.arange(1, c + 1, dtype=np.float32)[None, :]
-    for kind, x, want in (("sigdown", SIG_X6, SIG_DOWN), ("conv", SIG_X6, KERAS_DOWN), ("sigup", SIG_X6[:3], SIG_UP),
-                          ("convT", SIG_X6[:3], KERAS_UP)):
-        plan = ops.ConvPlan(kind, dev_t(kernel(SIG_W5), dev), None, 2)
+    # second axis of the transposed kinds (input width 1 -> output width 2): SignalConv2D lands x[0] w[j2] on column j2 - 2, the
+    # Keras layer on column j2 - 1: a delta at j2 = 2 / 1 puts the line on column 0 and nothing on column 1
+    for kind, x, want, other in (("sigdown", SIG_X6, SIG_DOWN, None), ("conv", SIG_X6, KERAS_DOWN, None), ("sigup", SIG_X6[:3], SIG_UP, 2),
+                                 ("convT", SIG_X6[:3], KERAS_UP, 1)):
+        plan = ops.ConvPlan(kind, dev_t(kernel(SIG_W5, other), dev), None, 2)
         got = out_line(plan(dev_t(line(x), dev)))
         np.testing.assert_array_equal(got, np.asarray(want, np.float32)[:, None] * scale, err_msg=kind)
 

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 SQ="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"
 # ---- decode (the headline region): one stream, so that a kernel's duration is its own; the launches are the ones bench.py's
 # two-stream step settles on (ops.tune_step) -- measured ONCE here, unprofiled, and applied from the file in the profiled runs
-python3 $R/bench.py --decode-only --no-cpu-baseline --steps 5 --warmup 2 --tuning-file $O/decode_tuning.json > $O/decode_tuning_run.json 2> /dev/null
+python3 $R/bench.py --decode-only --no-cpu-baseline --steps 5 --warmup 2 --retune --write-tuning $O/decode_tuning.json > $O/decode_tuning_run.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec_stats -- python3 $R/bench.py --decode-only --streams 1 --steps 20 --warmup 3 --tuning-file $O/decode_tuning.json > $O/decode_only_bench.json 2> $O/dec_stats.err
 rocprofv3 --pmc $SQ --output-format csv -d $O/dec_pmc_sq -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 --tuning-file $O/decode_tuning.json > /dev/null 2> $O/dec_pmc_sq.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/dec_pmc_fetch -- python3 $R/bench.py --decode-only --streams 1 --steps 5 --warmup 2 --tuning-file $O/decode_tuning.json > /dev/null 2> $O/dec_pmc_fetch.err
