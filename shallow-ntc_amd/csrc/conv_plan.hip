@@ -560,7 +560,10 @@ static int pick_ksplit(const sntc_conv_plan* p, const Geo& g) {
     steps_max = std::max(steps_max, steps);
     bpi += mt * ((p->g[gi].Ncol + 63) / 64);
   }
-  if (steps_max < 64 || bpi > 32) return 1;
+#ifndef SNTC_KSPLIT_BPI_MAX
+#define SNTC_KSPLIT_BPI_MAX 32
+#endif
+  if (steps_max < 64 || bpi > SNTC_KSPLIT_BPI_MAX) return 1;
   const int want = (int)((128 + bpi - 1) / bpi);
   return std::max(1, std::min({8, want, std::max(1, steps_min / 8)}));
 }

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(512, 2) rgb_conv_kernel(const RGBArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) Fw[j] = *reinterpret_cast<const f32x4*>(wrow + j * 32 * 16);
     };
-    if constexpr (KH > 0) {
+    if constexpr (KH > 0 && NT <= 6) {
       f32x4 FwA[NT], FwB[NT], PA, PB;
       read_frag(FwA, PA, 0);
       static_for<0, 2 * KH>([&](auto S) {
@@ -209,6 +209,16 @@ __global__ void __launch_bounds__(512, 2) rgb_conv_kernel(const RGBArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
       });
       __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (KH > 0) {
+      // 256 output channels: 128 accumulator registers leave no room for a second set of fragments (26 spilled registers with it)
+      static_for<0, 2 * KH>([&](auto S) {
+        f32x4 Fw[NT], P;
+        read_frag(Fw, P, decltype(S)::value);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = RGB_MFMA(P[e], Fw[j][e], acc[j]);
+      });
     } else {
 #pragma unroll 1
       for (int st = 0; st < 2 * a.k; ++st) {

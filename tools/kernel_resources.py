@@ -32,6 +32,9 @@ WATCH = {
     "rb_fused.hip": {"rb_kernel<192>": "rb_kernelILi192EE"},
     "syn_fused.hip": {"syn_kernel<24, true>": "syn_kernelILi24ELb1EE", "syn_kernel<12, false>": "syn_kernelILi12ELb0EE",
                       "syn_kernel<24, false>": "syn_kernelILi24ELb0EE"},
+    "rgb_conv.hip": {"rgb_conv_kernel<6, 5, false> (ELIC first layer)": "rgb_conv_kernelILi6ELi5ELb0EE",
+                     "rgb_conv_kernel<8, 5, true>": "rgb_conv_kernelILi8ELi5ELb1EE"},
+    "entropy.hip": {"scale_normal_kernel<false>": "scale_normal_kernelILb0EE", "factorized_fast_kernel<3, 3>": "factorized_fast_kernelILi3ELi3EE"},
 }
 FIELDS = {"VGPRs": r"\bVGPRs: (\d+)", "AGPRs": r"AGPRs: (\d+)", "SGPRs": r"TotalSGPRs: (\d+)", "scratch_bytes": r"ScratchSize \[bytes/lane\]: (\d+)",
           "waves_per_simd": r"Occupancy \[waves/SIMD\]: (\d+)", "vgpr_spills": r"VGPRs Spill: (\d+)"}
