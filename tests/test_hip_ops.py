@@ -384,6 +384,47 @@ def test_entropy_factorized_channel_per_thread_kernel(num_filters, c, shape, dev
     assert np.abs(bits3.cpu().numpy() - want).max() / np.abs(want).max() < 2e-6
 
 
+@pytest.mark.parametrize("n,h,w,c", [(1, 1, 1, 4), (2, 3, 5, 12), (3, 7, 9, 320), (1, 33, 17, 8), (2, 64, 48, 320), (5, 16, 16, 20),
+                                     (1, 130, 257, 64)])
+def test_entropy_scale_normal_shapes(n, h, w, c, dev):
+    """The rewritten scan walks (pixel, channel quad) incrementally by the launch's stride: every element visited exactly once for
+    channel counts that do not divide the stride, vectors that do not fill the last step, several images -- symbols exact, bits
+    against float64, per image."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(n * 1000 + h * 10 + c)
+    y, hyper = _synthetic_latents(rng, n, h, w, c)
+    mu, raw = hyper[..., :c], hyper[..., c:]
+    _, ref_bits, _ = O.scale_indexed_normal(y, mu, np.exp(raw.astype(np.float64)))
+    y_hat, bits, sym = ops.entropy_scale_normal(dev_t(y, dev), dev_t(hyper, dev), want_symbols=True)
+    ref_sym = np.rint(y - mu).astype(np.int32)
+    np.testing.assert_array_equal(sym.cpu().numpy(), ref_sym)
+    np.testing.assert_array_equal(y_hat.cpu().numpy(), ref_sym.astype(np.float32) + mu)
+    got = bits.cpu().numpy()
+    assert got.shape == (n,) and np.abs(got - ref_bits).max() <= 2e-5 * np.abs(ref_bits).max() + 1e-3
+    y2, bits2, none = ops.entropy_scale_normal(dev_t(y, dev), dev_t(hyper, dev))
+    assert none is None and torch.equal(y2, y_hat) and torch.allclose(bits2, bits, rtol=1e-12, atol=0)   # double atomics: the order of the block sums is free
+    # explicit non-integer samples (the reference formulation kept for this mode)
+    ys = (y + rng.uniform(-0.4, 0.4, y.shape)).astype(np.float32)
+    sig = O.scale_fn(np.clip(np.exp(raw.astype(np.float64)), 0, 63))
+    want = -(O.noisy_normal_logprob(ys.astype(np.float64) - mu, sig)).sum(axis=(1, 2, 3)) / np.log(2)
+    _, bits3, _ = ops.entropy_scale_normal(dev_t(ys, dev), dev_t(hyper, dev), values_only=True)
+    assert np.abs(bits3.cpu().numpy() - want).max() <= 3e-5 * np.abs(want).max() + 1e-3
+
+
+def test_rgb_first_layer_kernel_fuzz(dev):
+    """Random sizes (1 ... 200 pixels a side, 1 ... 4 images): the first-layer kernel == the row-packed plan, bit for bit."""
+    from shallow_ntc_amd import ops
+    rng = np.random.default_rng(2026)
+    wk = (rng.standard_normal((5, 5, 3, 192)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(192).astype(np.float32)
+    rp = ops.RowPackedConv(dev_t(wk, dev), dev_t(b, dev), 2, "leaky_relu")
+    plan = ops.RgbConvPlan(dev_t(wk, dev), dev_t(b, dev), 2, "leaky_relu")
+    for _ in range(24):
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        x = dev_t(rng.standard_normal((n, h, w, 3)).astype(np.float32), dev)
+        assert torch.equal(plan(x), rp(x)), (n, h, w)
+
+
 def test_errors_are_loud(dev):
     from shallow_ntc_amd import _capi as capi
     from shallow_ntc_amd import ops

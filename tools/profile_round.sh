@@ -1,9 +1,9 @@
-# rocprofv3 evidence for profiles/ (round 5): kernel stats + PMC passes of the decode-only bench AND of the encode-side layer
+# rocprofv3 evidence for profiles/ (round 6): kernel stats + PMC passes of the decode-only bench AND of the encode-side layer
 # table, the layer tables (Kodak batch and W1), the whole-ResidualBlock kernel alone, the stream kernels, the default bench line.
 # Program directly after `--`.  bash tools/profile_round.sh [round tag, default r04]
 # NOTE: gpurun MERGES what this writes into the local gpurun_out/prof_<tag> -- delete that directory locally before a re-run, or
 # stale *_kernel_stats.csv / *_counter_collection.csv of the previous run are averaged into tools/summarize_pmc.py's output.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 SQ="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"
@@ -28,6 +28,12 @@ python3 tools/profile_layers.py --reps 5 > $O/layer_table.txt 2>&1
 python3 tools/profile_layers.py --reps 5 --autotune > $O/layer_table_tuned.txt 2>&1
 python3 tools/profile_layers.py --reps 5 --batch 64 --hw 256 256 --autotune > $O/layer_table_w1.txt 2>&1
 python3 tools/rb_block.py > $O/resblock_vs_layers.txt 2>&1
+python3 tools/rgb_conv_block.py > $O/rgb_conv_vs_rowpacked.txt 2>&1
+python3 tools/encoder_segments.py > $O/encoder_segments.txt 2>&1
+SNTC_NO_BRANCH_STREAMS=1 python3 tools/encoder_segments.py --batches 18x512x768 > $O/encoder_segments_no_branch_streams.txt 2>&1
+python3 tools/ab_encode.py > $O/ab_encode_rgb.txt 2>&1
+python3 tools/ab_encode.py --one-stream >> $O/ab_encode_rgb.txt 2>&1
+python3 tools/microbench/write_bw.py > $O/write_bw.txt 2>&1
 python3 tools/syn_block.py > $O/synthesis_vs_layers.txt 2>&1
 python3 tools/syn_block.py --ch 24 --res 0 5 76 76 >> $O/synthesis_vs_layers.txt 2>&1
 python3 bench.py --decode-only --steps 50 --warmup 10 --set-decode > $O/decode_only_set_decode.json 2> /dev/null
