@@ -190,6 +190,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # A GPU that other processes or streams share cannot promise stream-K's workers co-residency (include/sntc.h, "Stream-K health"):
+    # SNTC_STATIC_SCHEDULES=1 makes every launch of this process take the one-workgroup-per-tile / split-K schedules from the
+    # start (same bits), instead of finding out through a timed-out hand-off and check_conv_status().
+    if os.environ.get("SNTC_STATIC_SCHEDULES", "") not in ("", "0"):
+        lib.sntc_conv_set_stream_k(0)
     return lib
 
 

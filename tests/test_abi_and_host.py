@@ -288,3 +288,19 @@ def test_hot_kernel_register_allocation_is_the_committed_one():
     import subprocess
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "kernel_resources.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_static_schedules_environment_switch():
+    """SNTC_STATIC_SCHEDULES=1: the process starts with stream-K off (a GPU shared with other processes cannot promise the
+    co-residency its hand-offs need; include/sntc.h "Stream-K health") -- read once, when the library is loaded."""
+    import os
+    import subprocess
+    import sys
+    code = ("import __graft_entry__ as g; g.load_package(); from shallow_ntc_amd import _capi; "
+            "print(int(_capi.load().sntc_conv_get_stream_k()))")
+    root = str(Path(__file__).resolve().parent.parent)
+    for env_val, want in (("1", "0"), ("", "1"), ("0", "1")):
+        env = dict(os.environ, SNTC_STATIC_SCHEDULES=env_val, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert out.stdout.strip().splitlines()[-1] == want, (env_val, out.stdout)
