@@ -1,5 +1,10 @@
 # A/B of the deterministic split-K threshold (conv_plan.hip::pick_ksplit, SNTC_KSPLIT_BPI_MAX) as LIBRARIES on one box:
 #   lib/libsntc_hip.so (32: round 1's rule), lib/libsntc_k16.so, lib/libsntc_k8.so -- W1 decode (64 x 256 x 256) and one 256 x 256 image
+# The variant libraries are not kept in the tree; build them here (CPU container) before the gpurun call:
+#   cd shallow-ntc_amd/csrc && for v in 16 8; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DSNTC_KSPLIT_BPI_MAX=$v \
+#     -c conv_plan.hip -o /tmp/conv_plan_$v.o && hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libsntc_k$v.so \
+#     $(ls build/*.o | grep -v conv_plan.o) /tmp/conv_plan_$v.o; done
+# Result of round 6: profiles/r06_ab_ksplit.txt (the threshold stays at 32).
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
 for i in 1 2; do
 for lib in hip k16 k8; do
