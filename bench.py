@@ -400,6 +400,8 @@ def main():
             per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
             stats.update(steps=steps, warmup=warmup, mean_ms=round(1e3 * wall / steps, 4), median_ms=round(float(np.median(per)), 4),
                          min_ms=round(float(per.min()), 4), timer="HIP events on the launch stream per step; mean = wall clock / steps")
+            if headline:
+                stats["per_step_ms"] = [round(float(v), 3) for v in per]      # the clock ramp, if any, is visible here
         return wall
 
     # >= 10 warm-up and >= 50 timed iterations per region (the 40 - 55 ms encode-side regions: >= 20)
@@ -825,6 +827,7 @@ def main():
                         timed_region="decode: (z_hat, symbols) in HBM -> uint8 pixels",
                         untimed_before=f"the {args.warmup} warm-up steps only; the timed steps' own HIP-event statistics: median "
                                        f"{hst.get('median_ms')} ms, min {hst.get('min_ms')} ms",
+                        timed_steps_ms=hst.get("per_step_ms"),
                         launch="hipGraph replay (one graph per batch shape)" if args.graph else
                         ("eager, Model.decode_set: hyper-syntheses of the batch shapes on concurrent streams, one synthesis launch for all" if set_decode else
                          f"eager, {min(nstreams, len(codes))} concurrent streams (one per batch)" if nstreams > 1 and len(codes) > 1 else "eager"),
