@@ -186,11 +186,15 @@ int sntc_resblock_plan_set_workgroups(sntc_resblock_plan* plan, int max_workgrou
  * k-ordered fp32 fma chain as the row-packed gather-GEMM plan (sntc_conv_desc.reserved[2] == 1 on a zero-padded image):
  * bit-identical to it, for any batch size and any number of workgroups.
  *   w [k, k, 3, cout]: the Keras HWIO kernel (device pointer); bias [cout] or NULL; act: SNTC_ACT_NONE / RELU / LEAKY_RELU.
- * sntc_rgbconv_supported: 1 where the kernel exists (cin = 3, stride 2, k <= 5, cout in {128, 192, 256}), else 0 -- callers
- * then run the row-packed plan.  x and y < 2 GiB per call. */
+ * kind SNTC_SIGNAL_DOWN: the same kernel for tfc.SignalConv2D(corr=True, strides_down=2, padding="same_zeros") on the image -- the
+ * first layer of MBT2018Analysis (reference common/transforms.py:152-155; BASELINE configs[1]) -- whose only difference is the
+ * padding origin (the kernel is centred: k / 2 in front on both axes); it replaces the generic dword-gather plan
+ * there (same products, the row-packed order of summation; tolerance-tested against the oracle, batch-invariant).
+ * sntc_rgbconv_supported: 1 where the kernel exists (kind SNTC_CONV2D or SNTC_SIGNAL_DOWN, cin = 3, stride 2, k <= 5, cout in
+ * {128, 192, 256}), else 0 -- callers then run the row-packed / generic plan.  x and y < 2 GiB per call. */
 typedef struct sntc_rgbconv_plan sntc_rgbconv_plan;
-int sntc_rgbconv_supported(int k, int stride, int cin, int cout, int act);
-int sntc_rgbconv_plan_create(int k, int stride, int cin, int cout, const float* w, const float* bias, int act,
+int sntc_rgbconv_supported(int kind, int k, int stride, int cin, int cout, int act);
+int sntc_rgbconv_plan_create(int kind, int k, int stride, int cin, int cout, const float* w, const float* bias, int act,
                              void* stream, sntc_rgbconv_plan** plan);
 int sntc_rgbconv_plan_update(sntc_rgbconv_plan* plan, const float* w, const float* bias, void* stream);
 void sntc_rgbconv_plan_destroy(sntc_rgbconv_plan* plan);

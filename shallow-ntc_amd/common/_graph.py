@@ -93,9 +93,10 @@ class Conv:
     def build(self, w, cin):
         args = (self.kind, w[f"{self.name}/kernel"], w.get(f"{self.name}/bias") if self.bias else None, self.s, self.act,
                 capi.PRO_NONE, self.epilogue)
-        if (self.kind == "conv" and self.epilogue == capi.EPI_STORE and ops.RGB_FIRST_LAYER
-                and ops.RgbConvPlan.supported(self.k, self.s, cin, self.cout, self.act)):
-            self.plan = ops.RgbConvPlan(args[1], args[2], self.s, self.act)        # the RGB first layer on its own kernel (same bits as the next)
+        if (self.kind in ("conv", "sigdown") and self.epilogue == capi.EPI_STORE and ops.RGB_FIRST_LAYER
+                and ops.RgbConvPlan.supported(self.k, self.s, cin, self.cout, self.act, self.kind)):
+            # the RGB first layer on its own kernel: Keras Conv2D (same bits as the row-packed plan below) or tfc.SignalConv2D
+            self.plan = ops.RgbConvPlan(args[1], args[2], self.s, self.act, self.kind)
         elif (self.kind == "conv" and cin <= 4 and self.k > 1 and self.k * cin <= 16 and self.epilogue == capi.EPI_STORE
                 and ops.ROW_PACKED_FIRST_LAYER):
             self.plan = ops.RowPackedConv(args[1], args[2], self.s, self.act)      # ... or as a row-packed gather-GEMM plan

@@ -324,7 +324,7 @@ int rgb_init(int* num_cus) {
 }  // namespace sntc
 
 struct sntc_rgbconv_plan {
-  int k = 0, cout = 0, act = 0;
+  int k = 0, cout = 0, act = 0, kind = SNTC_CONV2D;
   float* wpack = nullptr;
   float* bias = nullptr;
   int max_workgroups = 0;
@@ -340,8 +340,8 @@ static int rgb_pack(sntc_rgbconv_plan* p, const float* w, const float* bias, hip
   return SNTC_OK;
 }
 
-extern "C" int sntc_rgbconv_supported(int k, int stride, int cin, int cout, int act) {
-  return (cin == kCin && stride == kStride && k >= 1 && k <= kMaxK && k * cin <= 16 && (cout == 128 || cout == 192 || cout == 256) &&
+extern "C" int sntc_rgbconv_supported(int kind, int k, int stride, int cin, int cout, int act) {
+  return ((kind == SNTC_CONV2D || kind == SNTC_SIGNAL_DOWN) && cin == kCin && stride == kStride && k >= 1 && k <= kMaxK && k * cin <= 16 && (cout == 128 || cout == 192 || cout == 256) &&
           (act == SNTC_ACT_NONE || act == SNTC_ACT_RELU || act == SNTC_ACT_LEAKY_RELU)) ? 1 : 0;
 }
 
@@ -351,16 +351,16 @@ static void rgb_free(sntc_rgbconv_plan* p) {
   delete p;
 }
 
-extern "C" int sntc_rgbconv_plan_create(int k, int stride, int cin, int cout, const float* w, const float* bias, int act,
+extern "C" int sntc_rgbconv_plan_create(int kind, int k, int stride, int cin, int cout, const float* w, const float* bias, int act,
                                         void* stream, sntc_rgbconv_plan** plan) {
   if (!plan || !w) return fail(SNTC_ERR_BAD_SHAPE, "sntc_rgbconv_plan_create: null argument");
-  if (!sntc_rgbconv_supported(k, stride, cin, cout, act))
-    return fail(SNTC_ERR_UNSUPPORTED, "sntc_rgbconv_plan_create: the first-layer kernel exists for k <= 5, stride 2, 3 -> 128 / 192 / 256 channels, "
+  if (!sntc_rgbconv_supported(kind, k, stride, cin, cout, act))
+    return fail(SNTC_ERR_UNSUPPORTED, "sntc_rgbconv_plan_create: the first-layer kernel exists for Conv2D / SignalConv2D(corr, strides_down), k <= 5, stride 2, 3 -> 128 / 192 / 256 channels, "
                                       "no activation / relu / leaky relu");
   int cus = 0;
   if (int rc = rgb_init(&cus)) return rc;
   auto* p = new sntc_rgbconv_plan();
-  p->k = k; p->cout = cout; p->act = act;
+  p->k = k; p->cout = cout; p->act = act; p->kind = kind;
   if (hipMalloc(&p->wpack, sizeof(float) * k * cout * 16) != hipSuccess || hipMalloc(&p->bias, sizeof(float) * cout) != hipSuccess) {
     rgb_free(p);
     return fail(SNTC_ERR_HIP, "sntc_rgbconv_plan_create: out of device memory");
@@ -409,9 +409,14 @@ extern "C" int sntc_rgbconv_forward(const sntc_rgbconv_plan* p, const float* x, 
   a.xbytes = (unsigned)xbytes; a.ybytes = (unsigned)ybytes;
   a.N = n; a.H = h; a.W = w; a.Ho = ho; a.Wo = wo;
   a.k = p->k;
-  // Keras SAME: pad_total = max((out - 1) s + k - in, 0), the smaller half in front
-  a.pt = std::max((ho - 1) * kStride + p->k - h, 0) / 2;
-  a.pl = std::max((wo - 1) * kStride + p->k - w, 0) / 2;
+  if (p->kind == SNTC_SIGNAL_DOWN) {
+    // tfc.SignalConv2D(corr=True, strides_down, "same_zeros"): the kernel is CENTRED, y[i] = sum_j w[j] x[s i + j - k / 2]
+    a.pt = a.pl = p->k / 2;
+  } else {
+    // Keras SAME: pad_total = max((out - 1) s + k - in, 0), the smaller half in front
+    a.pt = std::max((ho - 1) * kStride + p->k - h, 0) / 2;
+    a.pl = std::max((wo - 1) * kStride + p->k - w, 0) / 2;
+  }
   a.tiles_x = (wo + kTW - 1) / kTW;
   const int64_t nu = (int64_t)n * a.tiles_x * ho;
   if (nu >= (1LL << 31)) return fail(SNTC_ERR_BAD_SHAPE, "sntc_rgbconv_forward: too many units");

@@ -875,11 +875,15 @@ class RgbConvPlan:
     input patch double-buffered, no padded copy of the image; bit-identical to ``RowPackedConv`` (the same fma chains)."""
 
     @staticmethod
-    def supported(k, stride, cin, cout, act=None):
-        return act in ACTS and bool(capi.load().sntc_rgbconv_supported(int(k), int(stride), int(cin), int(cout), ACTS[act]))
+    def supported(k, stride, cin, cout, act=None, kind="conv"):
+        return act in ACTS and kind in ("conv", "sigdown") and bool(
+            capi.load().sntc_rgbconv_supported(KINDS[kind], int(k), int(stride), int(cin), int(cout), ACTS[act]))
 
-    def __init__(self, weight, bias, stride, act=None):
+    def __init__(self, weight, bias, stride, act=None, kind="conv"):
+        """``kind`` "sigdown": tfc.SignalConv2D(corr=True, strides_down) -- MBT2018Analysis' first layer (reference
+        common/transforms.py:152-155): the same kernel with the centred padding origin."""
         capi.require_gpu()
+        self.kind = kind
         self.k, self.stride = int(weight.shape[0]), int(stride)
         self.cin, self.cout = int(weight.shape[2]), int(weight.shape[3])
         if weight.shape[0] != weight.shape[1]:
@@ -887,7 +891,7 @@ class RgbConvPlan:
         w = weight.contiguous()
         b = None if bias is None else bias.contiguous()
         self._h = C.c_void_p()
-        capi.call("sntc_rgbconv_plan_create", self.k, self.stride, self.cin, self.cout, _ptr(w), _ptr(b), ACTS[act], _stream(), C.byref(self._h))
+        capi.call("sntc_rgbconv_plan_create", KINDS[kind], self.k, self.stride, self.cin, self.cout, _ptr(w), _ptr(b), ACTS[act], _stream(), C.byref(self._h))
         torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
 
     def __del__(self):

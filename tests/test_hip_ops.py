@@ -411,6 +411,48 @@ def test_entropy_scale_normal_shapes(n, h, w, c, dev):
     assert np.abs(bits3.cpu().numpy() - want).max() <= 3e-5 * np.abs(want).max() + 1e-3
 
 
+@pytest.mark.parametrize("axis", [0, 1])
+def test_rgb_first_layer_kernel_signal_conv(axis, dev):
+    """The first-layer kernel as tfc.SignalConv2D(corr=True, strides_down=2, "same_zeros") -- MBT2018Analysis' first layer (reference
+    common/transforms.py:152-155, BASELINE configs[1]): the centred padding origin, against the hand-worked integers of
+    tests/test_oracle_pins.py (exact), the float64 oracle and the generic plan (tolerance: another order of summation), an image
+    alone == the image in a batch, and the transform picks it."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.common import transforms as TR
+    from tests.test_oracle_pins import KERAS_DOWN, SIG_DOWN, SIG_W5, SIG_X6
+    cout = 192
+    scale = np.arange(1, cout + 1, dtype=np.float32)
+    for kind, jc, want in (("sigdown", 2, SIG_DOWN), ("conv", 1, KERAS_DOWN)):
+        # the pattern along `axis` in channel 0 of line 2 of the other axis; the kernel's delta at jc on that axis lands it on output line 1
+        x = np.zeros((1, 6, 6, 3), np.float32)
+        w = np.zeros((5, 5, 3, cout), np.float32)
+        for a_, v in enumerate(SIG_X6):
+            x[(0, a_, 2, 0) if axis == 0 else (0, 2, a_, 0)] = v
+        for j, v in enumerate(SIG_W5):
+            w[(j, jc, 0) if axis == 0 else (jc, j, 0)] = v * scale
+        y = ops.RgbConvPlan(dev_t(w, dev), None, 2, None, kind)(dev_t(x, dev)).cpu().numpy()[0]          # [3, 3, cout]
+        line = y[:, 1] if axis == 0 else y[1, :]
+        np.testing.assert_array_equal(line, np.asarray(want, np.float32)[:, None] * scale[None, :], err_msg=kind)
+        rest = np.delete(y, 1, axis=1 if axis == 0 else 0)
+        assert not rest.any(), kind
+    rng = np.random.default_rng(77 + axis)
+    for n, h, w_, co, act in ((2, 64, 96, 192, None), (1, 37, 41, 128, "relu"), (3, 16, 18, 256, None)):
+        x = rng.standard_normal((n, h, w_, 3)).astype(np.float32)
+        wk = (rng.standard_normal((5, 5, 3, co)) * 0.2).astype(np.float32)
+        b = rng.standard_normal(co).astype(np.float32)
+        ref = O.ACTIVATIONS[act](O.signal_conv_down(x, wk, b, 2))
+        plan = ops.RgbConvPlan(dev_t(wk, dev), dev_t(b, dev), 2, act, "sigdown")
+        gen = ops.ConvPlan("sigdown", dev_t(wk, dev), dev_t(b, dev), 2, act)
+        got = plan(dev_t(x, dev))
+        assert tuple(got.shape) == ref.shape
+        e_new, e_gen = rel_err(got.cpu().numpy(), ref), rel_err(gen(dev_t(x, dev)).cpu().numpy(), ref)
+        assert e_new < 2e-6 and e_new < 4 * e_gen + 2e-7, (e_new, e_gen)
+        assert torch.equal(plan(dev_t(x[:1], dev)), got[:1])
+    t = TR.MBT2018Analysis(192, output_channels=320)
+    t(dev_t(rng.standard_normal((1, 64, 64, 3)).astype(np.float32) * 0.3, dev))
+    assert isinstance(t._graph.layers[0].plan, ops.RgbConvPlan) and t._graph.layers[0].plan.kind == "sigdown"
+
+
 def test_rgb_first_layer_kernel_fuzz(dev):
     """Random sizes (1 ... 200 pixels a side, 1 ... 4 images): the first-layer kernel == the row-packed plan, bit for bit."""
     from shallow_ntc_amd import ops
