@@ -69,6 +69,12 @@ SIGNATURES = {
     "sntc_resblock_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
     "sntc_resblock_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_resblock_plan_set_workgroups": (C.c_int, [_P, C.c_int]),
+    "sntc_upsmall_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sntc_upsmall_plan_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(_P)]),
+    "sntc_upsmall_plan_update": (C.c_int, [_P, _P, _P, _P]),
+    "sntc_upsmall_plan_destroy": (None, [_P]),
+    "sntc_upsmall_flops": (C.c_int64, [_P, C.c_int, C.c_int, C.c_int]),
+    "sntc_upsmall_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sntc_rgbconv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sntc_rgbconv_plan_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.POINTER(_P)]),
     "sntc_rgbconv_plan_update": (C.c_int, [_P, _P, _P, _P]),

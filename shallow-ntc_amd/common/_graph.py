@@ -97,6 +97,9 @@ class Conv:
                 and ops.RgbConvPlan.supported(self.k, self.s, cin, self.cout, self.act, self.kind)):
             # the RGB first layer on its own kernel: Keras Conv2D (same bits as the row-packed plan below) or tfc.SignalConv2D
             self.plan = ops.RgbConvPlan(args[1], args[2], self.s, self.act, self.kind)
+        elif (self.act is None and self.epilogue == capi.EPI_STORE and ops.SMALL_OUTPUT_LAYER
+                and ops.UpSmallPlan.supported(self.kind, self.k, self.s, cin, self.cout)):
+            self.plan = ops.UpSmallPlan(self.kind, args[1], args[2], self.s)       # the syntheses' last layer (5x5/2 -> 3 channels) on the vector ALU
         elif (self.kind == "conv" and cin <= 4 and self.k > 1 and self.k * cin <= 16 and self.epilogue == capi.EPI_STORE
                 and ops.ROW_PACKED_FIRST_LAYER):
             self.plan = ops.RowPackedConv(args[1], args[2], self.s, self.act)      # ... or as a row-packed gather-GEMM plan

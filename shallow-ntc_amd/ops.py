@@ -938,6 +938,65 @@ class RgbConvPlan:
         return y
 
 
+SMALL_OUTPUT_LAYER = not os.environ.get("SNTC_NO_UPSMALL")   # the 5x5/2 transposed convolution to 3 channels on its own kernel (csrc/up_small.hip); False: the gather GEMM
+
+
+class UpSmallPlan:
+    """The last layer of the multi-layer syntheses (reference common/transforms.py:172-175 MBT2018Synthesis, :195-206
+    CNNSynthesis): a 5 x 5 / 2 transposed convolution to the 3 image channels as one launch of a vector-ALU kernel --
+    sntc_upsmall_plan (csrc/up_small.hip); ``kind`` "convT" (Keras kernel [5, 5, 3, cin]) or "sigup" (tfc kernel [5, 5, cin, 3])."""
+
+    @staticmethod
+    def supported(kind, k, stride, cin, cout):
+        return kind in ("convT", "sigup") and bool(capi.load().sntc_upsmall_supported(KINDS[kind], int(k), int(stride), int(cin), int(cout)))
+
+    def __init__(self, kind, weight, bias, stride):
+        capi.require_gpu()
+        self.kind, self.stride = kind, int(stride)
+        self.k = int(weight.shape[0])
+        self.cout, self.cin = (int(weight.shape[2]), int(weight.shape[3])) if kind == "convT" else (int(weight.shape[3]), int(weight.shape[2]))
+        w = weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        self._h = C.c_void_p()
+        capi.call("sntc_upsmall_plan_create", KINDS[kind], self.k, self.stride, self.cin, self.cout, _ptr(w), _ptr(b), _stream(), C.byref(self._h))
+        torch.cuda.current_stream().synchronize()   # packing reads the arrays; they may be freed after this
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                capi.load().sntc_upsmall_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def update(self, weight, bias=None):
+        capi.call("sntc_upsmall_plan_update", self._h, _ptr(weight), _ptr(bias), _stream())
+
+    def out_hw(self, h, w):
+        return h * self.stride, w * self.stride
+
+    def flops(self, n, h, w):
+        return int(capi.load().sntc_upsmall_flops(self._h, n, h, w))
+
+    def __call__(self, x, res=None, aux=None):
+        if res is not None or aux is not None:
+            raise ValueError("the small-output transposed convolution has no epilogue operands")
+        _check_nhwc(x, self.cin)
+        n, h, w, _ = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, self.cout), dtype=torch.float32, device=x.device)
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        capi.call("sntc_upsmall_forward", self._h, _ptr(x), n, h, w, _ptr(y), _stream())
+        if prof is not None:
+            e1.record()
+            prof.append(dict(e0=e0, e1=e1, flops=self.flops(n, h, w), variant=0, nblocks=0, vec=True, kind="upsmall", k=self.k, s=self.stride,
+                             cin=self.cin, cout=self.cout, n=n, h=h, w=w))
+        return y
+
+
 def pad_reflect(x, hp, wp):
     _check_nhwc(x)
     n, h, w, c = x.shape

@@ -453,6 +453,59 @@ def test_rgb_first_layer_kernel_signal_conv(axis, dev):
     assert isinstance(t._graph.layers[0].plan, ops.RgbConvPlan) and t._graph.layers[0].plan.kind == "sigdown"
 
 
+@pytest.mark.parametrize("kind", ["convT", "sigup"])
+def test_small_output_transposed_conv_kernel(kind, dev):
+    """csrc/up_small.hip: the syntheses' last layer (5 x 5 / 2 transposed convolution to the 3 image channels; reference
+    common/transforms.py:172-175 MBT2018Synthesis -- tfc.SignalConv2D(strides_up=2) --, :195-206 CNNSynthesis -- Keras
+    Conv2DTranspose) on the vector ALU: against the float64 oracle and the gather-GEMM plan it replaces (another order of
+    summation: tolerance), odd sizes, tiles that hang over the image, channel counts from one slab to 320, with and without bias;
+    the hand-worked origin integers of tests/test_oracle_pins.py exactly; an image alone == the image in a batch; the transform
+    picks it."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.common import transforms as TR
+    from tests.test_oracle_pins import KERAS_UP, SIG_UP, SIG_W5, SIG_X6
+    fn = O.conv2d_transpose if kind == "convT" else O.signal_conv_up
+    assert ops.UpSmallPlan.supported(kind, 5, 2, 192, 3) and not ops.UpSmallPlan.supported(kind, 5, 2, 192, 12)
+    assert not ops.UpSmallPlan.supported(kind, 3, 1, 192, 3) and not ops.UpSmallPlan.supported("conv", 5, 2, 192, 3)
+    assert not ops.UpSmallPlan.supported(kind, 5, 2, 24, 3)
+    rng = np.random.default_rng(5 + len(kind))
+    for n, h, w, cin, bias in ((2, 16, 20, 192, True), (1, 5, 7, 32, True), (1, 33, 17, 64, False), (3, 8, 8, 320, True), (1, 1, 1, 16, True),
+                               (2, 40, 31, 192, True)):
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        wshape = (5, 5, 3, cin) if kind == "convT" else (5, 5, cin, 3)
+        wk = (rng.standard_normal(wshape) / np.sqrt(25 * cin / 4)).astype(np.float32)
+        b = rng.standard_normal(3).astype(np.float32) if bias else None
+        ref = fn(x, wk, b, 2)
+        plan = ops.UpSmallPlan(kind, dev_t(wk, dev), None if b is None else dev_t(b, dev), 2)
+        gen = ops.ConvPlan(kind, dev_t(wk, dev), None if b is None else dev_t(b, dev), 2)
+        got = plan(dev_t(x, dev))
+        assert tuple(got.shape) == ref.shape == (n, 2 * h, 2 * w, 3)
+        e_new, e_gen = rel_err(got.cpu().numpy(), ref), rel_err(gen(dev_t(x, dev)).cpu().numpy(), ref)
+        assert e_new < 2e-6 and e_new < 4 * e_gen + 2e-7, (n, h, w, cin, e_new, e_gen)
+        assert torch.equal(plan(dev_t(x[:1], dev)), got[:1])
+        assert plan.flops(n, h, w) == gen.flops(n, h, w)
+    # the padding origin, exactly: the 1-D integer pattern along each axis in channel 0, a delta at the other axis' index jc
+    want = np.asarray(KERAS_UP if kind == "convT" else SIG_UP, np.float32)
+    jc = 1 if kind == "convT" else 2
+    for axis in (0, 1):
+        x = np.zeros((1, 3, 3, 16), np.float32)
+        w = np.zeros((5, 5, 3, 16) if kind == "convT" else (5, 5, 16, 3), np.float32)
+        for a_, v in enumerate(SIG_X6[:3]):
+            x[(0, a_, 0, 0) if axis == 0 else (0, 0, a_, 0)] = v
+        for j, v in enumerate(SIG_W5):
+            idx = (j, jc) if axis == 0 else (jc, j)
+            for o in range(3):
+                w[idx + ((o, 0) if kind == "convT" else (0, o))] = v * (o + 1)
+        y = ops.UpSmallPlan(kind, dev_t(w, dev), None, 2)(dev_t(x, dev)).cpu().numpy()[0]          # [6, 6, 3]
+        line = y[:, 0] if axis == 0 else y[0, :]
+        np.testing.assert_array_equal(line, want[:, None] * np.array([1, 2, 3], np.float32)[None, :])
+        rest = y[:, 1:] if axis == 0 else y[1:, :]
+        assert not rest.any()
+    t = TR.MBT2018Synthesis(192, output_channels=3) if kind == "sigup" else TR.CNNSynthesis(192, output_channels=3)
+    t(dev_t(rng.standard_normal((1, 4, 4, 320)).astype(np.float32) * 0.3, dev))
+    assert isinstance(t._graph.layers[-1].plan, ops.UpSmallPlan)
+
+
 def test_rgb_first_layer_kernel_fuzz(dev):
     """Random sizes (1 ... 200 pixels a side, 1 ... 4 images): the first-layer kernel == the row-packed plan, bit for bit."""
     from shallow_ntc_amd import ops
