@@ -8,18 +8,19 @@
 // a quarter of that config's decode.  It is an HBM read stream (768 B in per 48 B out) with 6.25 x cin x 3 MACs per output pixel,
 // which the vector ALU does faster than a 90 %-empty matrix tile -- the structure of two_layer_tail_kernel's output stage (pixel.hip),
 // with the input channels walked in 16-channel slabs so that any cin % 16 == 0 fits:
-//   * a block owns 16 x 16 macro pixels q (one thread each); thread (qy, qx) emits the 2 x 2 output quad o = 2 q + phi - pt
-//     (phi in {0, 1}^2; pt = 1: Keras SAME, pt = 2: SignalConv2D's centred kernel -- SURVEY.md A.2 / A.3); phase 0 of an axis uses
-//     kernel indices {0, 2, 4} from source rows q, q - 1, q - 2, phase 1 uses {1, 3} from q, q - 1 (gather form of the scatter
-//     out[2 i + k - pt] += x[i] w[k]);
-//   * per slab the 18 x 18 x 16 input tile sits in LDS (zeros outside the image); a thread reads its 3 x 3 neighbourhood four
-//     channels at a time (36 ds_read_b128 per slab) and runs the 25 taps x 3 outputs on it; the next slab's tile travels global ->
-//     registers under the arithmetic;
+//   * a block owns 16 x 16 macro pixels q and their 2 x 2 output quads o = 2 q + phi - pt (phi in {0, 1}^2; pt = 1: Keras SAME,
+//     pt = 2: SignalConv2D's centred kernel -- SURVEY.md A.2 / A.3), one thread per OUTPUT pixel, one phase phi per wave; phase 0
+//     of an axis uses kernel indices {0, 2, 4} from source rows q, q - 1, q - 2, phase 1 uses {1, 3} from q, q - 1 (gather form of
+//     the scatter out[2 i + k - pt] += x[i] w[k]);
+//   * per slab the 18 x 18 x 16 input tile sits in LDS (zeros outside the image); a thread reads its phase's 9 / 6 / 6 / 4 source
+//     pixels four channels at a time and runs taps x 3 outputs on them; the next slab's tile travels global -> registers under the
+//     arithmetic;
 //   * the packed weights [slab][channel quad][tap][out][4] arrive by scalar loads (uniform addresses): SGPR operands, no LDS, no vector loads.
 // Arithmetic: fp32 fma chains per 16-channel slab (channel quads, taps row-major inside), the slabs' sums added in order -- NOT the
 // gather GEMM's order; the layer is
 // decoder-only and its chains do not depend on the batch (an image alone == the image in a batch); tested against the float64 oracle.
 #include <algorithm>
+#include <type_traits>
 #include "sntc_internal.h"
 #include "device_math.h"
 
@@ -30,7 +31,7 @@ constexpr int kTQ = 16, kTH = kTQ + 2;        // macro pixels per block side, in
 constexpr int kCS = 16;                       // channels per slab
 constexpr int kPX = 20;                       // LDS words per tile pixel: 16 + 4, an odd number of 16-B slots (conflict-free row reads)
 constexpr int kROW = 384;                     // LDS words per tile row (>= 18 * 20, a multiple of 64)
-constexpr int kTileLoads = (kTH * kTH * (kCS / 4) + 255) / 256;      // 16-B loads per thread and slab
+constexpr int kTileLoads = (kTH * kTH * (kCS / 4) + 1023) / 1024;    // 16-B loads per thread and slab (1024 threads)
 
 struct UpArgs {
   const float* x;          // [n, h, w, cin]
@@ -40,21 +41,28 @@ struct UpArgs {
   int h, w, cin, pt;
 };
 
+// One output PHASE per wave: a block is 16 x 16 macro pixels x 4 phases = 1024 threads, wave w computes phase (w / 8, (w / 4) & 1) of
+// macro rows 4 (w & 3) .. + 3.  A wave then needs only its phase's taps (9 / 6 / 6 / 4 of the 25), i.e. a quarter of the scalar weight
+// loads per wave at four times the waves.  (Measured, 8 x 128 x 128 x 192: one thread = one macro pixel = all four phases, 256
+// threads: 0.151 ms -- it waited for 1200 scalar loads per slab and wave with 2.5 waves per SIMD to hide them behind; this form:
+// 0.116 ms; two phases per wave paired to 13 / 12 taps, 512 threads, four blocks per CU: 0.127 ms.  The scalar path stays the limit.)
 template <int CO>
-__global__ void __launch_bounds__(256) up_small_kernel(const UpArgs a) {
+__global__ void __launch_bounds__(1024) up_small_kernel(const UpArgs a) {
   __shared__ __attribute__((aligned(16))) float sh[kTH * kROW];
   const int img = blockIdx.z;
   const int qy0 = blockIdx.y * kTQ, qx0 = blockIdx.x * kTQ;
   const int tid = threadIdx.x;
-  const int ty = tid >> 4, tx = tid & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int phase = wave >> 2;                       // uniform per wave: (py, px) = (phase >> 1, phase & 1)
+  const int ty = 4 * (wave & 3) + ((tid & 63) >> 4), tx = tid & 15;
   const int nslab = a.cin / kCS;
 
-  // this thread's share of a slab's tile: 16-B chunk `c4` of tile pixel `p` (zeros outside the image)
+  // this thread's share of a slab's tile: 16-B chunk `c4` of tile pixel `p` (zeros outside the image); 1296 chunks, 1024 threads
   int lds_off[kTileLoads];
   int64_t src_off[kTileLoads];                // float offset of (pixel, chunk) in x for slab 0, or -1
 #pragma unroll
   for (int i = 0; i < kTileLoads; ++i) {
-    const int idx = tid + 256 * i;
+    const int idx = tid + 1024 * i;
     const int p = idx >> 2, c4 = idx & 3;
     const int ly = p / kTH, lx = p - ly * kTH;
     const int iy = qy0 - 2 + ly, ix = qx0 - 2 + lx;
@@ -75,13 +83,44 @@ __global__ void __launch_bounds__(256) up_small_kernel(const UpArgs a) {
       if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(sh + lds_off[i]) = R[i];
   };
 
-  float acc[2][2][CO];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float acc[CO];
 #pragma unroll
-  for (int py = 0; py < 2; ++py)
+  for (int o = 0; o < CO; ++o) acc[o] = a.bias[o];
+
+  // one slab of this wave's phase (PY, PX): taps ky = PY + 2 jy, kx = PX + 2 jx from tile pixel (ty + 2 - jy, tx + 2 - jx).
+  // Two-level summation: the slab's products in two interleaved chains per output (even / odd channel of a pair, v_pk_fma_f32: the
+  // pixel's channel pair is a VGPR pair as it comes from LDS, the weight pair an SGPR pair as it comes from the scalar load), the
+  // slabs' sums added in slab order (a single chain over 2000 products at cin = 320 carried 4.7 x the MFMA path's rounding error)
+  auto slab = [&](auto PYc, auto PXc, const float* wslab) {
+    constexpr int PY = decltype(PYc)::value, PX = decltype(PXc)::value;
+    f32x2 part[CO];
 #pragma unroll
-    for (int px = 0; px < 2; ++px)
+    for (int o = 0; o < CO; ++o) part[o] = f32x2{0.0f, 0.0f};
+#pragma unroll 1
+    for (int c4 = 0; c4 < kCS / 4; ++c4) {
+      const float* wq = wslab + c4 * (25 * CO * 4);    // [tap][out][4 channels of this quad]: 12 consecutive floats per tap
 #pragma unroll
-      for (int o = 0; o < CO; ++o) acc[py][px][o] = a.bias[o];
+      for (int jy = 0; jy < 3 - PY; ++jy)
+#pragma unroll
+        for (int jx = 0; jx < 3 - PX; ++jx) {
+          const int ky = PY + 2 * jy, kx = PX + 2 * jx;
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(sh + (ty + 2 - jy) * kROW + (tx + 2 - jx) * kPX + 4 * c4);
+          const f32x2 h01 = f32x2{hv[0], hv[1]}, h23 = f32x2{hv[2], hv[3]};
+          const float* wp = wq + (ky * 5 + kx) * (CO * 4);
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            const f32x2 w01 = f32x2{wp[o * 4], wp[o * 4 + 1]}, w23 = f32x2{wp[o * 4 + 2], wp[o * 4 + 3]};
+            part[o] = __builtin_elementwise_fma(h01, w01, part[o]);
+            part[o] = __builtin_elementwise_fma(h23, w23, part[o]);
+          }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] += part[o][0] + part[o][1];
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
 
   load_slab(0);
   for (int cc = 0; cc < nslab; ++cc) {
@@ -89,67 +128,20 @@ __global__ void __launch_bounds__(256) up_small_kernel(const UpArgs a) {
     store_slab();
     __syncthreads();
     if (cc + 1 < nslab) load_slab(cc + 1);             // travels under this slab's arithmetic
-    const float* wslab = a.wpack + (size_t)cc * (25 * CO * kCS);      // uniform: the weights below are scalar loads
-    // two-level summation: a slab's <= 144 products per output in a chain of their own, the slabs' sums added in slab order -- a
-    // single chain over 6.25 x cin products (2000 at cin = 320) carried 4.7 x the rounding error of the MFMA path it replaces
-    // ... and inside a slab two interleaved chains per output (even / odd channel of a pair) on v_pk_fma_f32: the pixel's channel
-    // pair is a VGPR pair as it comes from LDS, the weight pair an SGPR pair as it comes from the scalar load -- half the vector
-    // instructions of the scalar form.  (Measured, 8 x 128 x 128 x 192: 0.151 ms either way -- the kernel waits for its 1200 scalar
-    // weight loads per slab and wave, not for the vector ALU; fencing the loads per kernel row (no spilled SGPRs instead of 43)
-    // exposed their latency: 0.179 ms.  The gather GEMM it replaces: 0.383 ms.)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 part[2][2][CO];
-#pragma unroll
-    for (int py = 0; py < 2; ++py)
-#pragma unroll
-      for (int px = 0; px < 2; ++px)
-#pragma unroll
-        for (int o = 0; o < CO; ++o) part[py][px][o] = f32x2{0.0f, 0.0f};
-#pragma unroll 1
-    for (int c4 = 0; c4 < kCS / 4; ++c4) {
-      f32x4 P[3][3];                                   // source rows qy - 2 .. qy, columns qx - 2 .. qx (tile rows ty .. ty + 2)
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) P[r][c] = *reinterpret_cast<const f32x4*>(sh + (ty + r) * kROW + (tx + c) * kPX + 4 * c4);
-      const float* wq = wslab + c4 * (25 * CO * 4);    // [tap][out][4 channels of this quad]: 12 consecutive floats per tap
-#pragma unroll
-      for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-          const int py = ky & 1, px = kx & 1, jy = ky >> 1, jx = kx >> 1;
-          const f32x4 hv = P[2 - jy][2 - jx];
-          const f32x2 h01 = f32x2{hv[0], hv[1]}, h23 = f32x2{hv[2], hv[3]};
-          const float* wp = wq + (ky * 5 + kx) * (CO * 4);
-#pragma unroll
-          for (int o = 0; o < CO; ++o) {
-            const f32x2 w01 = f32x2{wp[o * 4], wp[o * 4 + 1]}, w23 = f32x2{wp[o * 4 + 2], wp[o * 4 + 3]};
-            part[py][px][o] = __builtin_elementwise_fma(h01, w01, part[py][px][o]);
-            part[py][px][o] = __builtin_elementwise_fma(h23, w23, part[py][px][o]);
-          }
-        }
-    }
-#pragma unroll
-    for (int py = 0; py < 2; ++py)
-#pragma unroll
-      for (int px = 0; px < 2; ++px)
-#pragma unroll
-        for (int o = 0; o < CO; ++o) acc[py][px][o] += part[py][px][o][0] + part[py][px][o][1];
+    const float* wslab = a.wpack + (size_t)cc * (25 * CO * kCS);      // uniform: the weights are scalar loads
+    if (phase == 0) slab(I0{}, I0{}, wslab);
+    else if (phase == 1) slab(I0{}, I1{}, wslab);
+    else if (phase == 2) slab(I1{}, I0{}, wslab);
+    else slab(I1{}, I1{}, wslab);
   }
 
-  const int qy = qy0 + ty, qx = qx0 + tx;
-  const int ho = 2 * a.h, wo = 2 * a.w;
+  const int py = phase >> 1, px = phase & 1;
+  const int oy = 2 * (qy0 + ty) + py - a.pt, ox = 2 * (qx0 + tx) + px - a.pt;
+  if ((unsigned)oy < (unsigned)(2 * a.h) && (unsigned)ox < (unsigned)(2 * a.w)) {
+    float* dst = a.y + (((int64_t)img * (2 * a.h) + oy) * (2 * a.w) + ox) * CO;
 #pragma unroll
-  for (int py = 0; py < 2; ++py)
-#pragma unroll
-    for (int px = 0; px < 2; ++px) {
-      const int oy = 2 * qy + py - a.pt, ox = 2 * qx + px - a.pt;
-      if ((unsigned)oy < (unsigned)ho && (unsigned)ox < (unsigned)wo) {
-        float* dst = a.y + (((int64_t)img * ho + oy) * wo + ox) * CO;
-#pragma unroll
-        for (int o = 0; o < CO; ++o) dst[o] = acc[py][px][o];
-      }
-    }
+    for (int o = 0; o < CO; ++o) dst[o] = acc[o];
+  }
 }
 
 // wpack[slab][channel quad][tap][o][4] from the layer's kernel: Keras Conv2DTranspose [5, 5, Cout, Cin] (io == 0) or tfc.SignalConv2D
@@ -249,7 +241,7 @@ extern "C" int sntc_upsmall_forward(const sntc_upsmall_plan* p, const float* x, 
   a.h = h; a.w = w; a.cin = p->cin;
   a.pt = p->kind == SNTC_SIGNAL_UP ? 2 : 1;            // (k - 1) / 2 for the centred kernel; A.2: (k - s) / 2 for Keras SAME
   const dim3 grid((w + 1 + kTQ - 1) / kTQ, (h + 1 + kTQ - 1) / kTQ, n);
-  hipLaunchKernelGGL((up_small_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((up_small_kernel<3>), grid, dim3(1024), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "small-output transposed convolution launch");
   return SNTC_OK;
