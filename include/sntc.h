@@ -204,18 +204,19 @@ int sntc_rgbconv_forward(const sntc_rgbconv_plan* plan, const float* x, int n, i
 /* Cap the persistent workgroups of THIS plan's launches (0 = one per CU): tests assert that results do not depend on it. */
 int sntc_rgbconv_plan_set_workgroups(sntc_rgbconv_plan* plan, int max_workgroups);
 /* ------------------------------------------------------------------------------------------
- * The LAST layer of the multi-layer syntheses -- a stride-2 5 x 5 transposed convolution down to the 3 image channels (reference
+ * The LAST layer of the multi-layer syntheses -- a 5 x 5 / 2 or 9 x 9 / 4 transposed convolution down to the 3 image channels (reference
  * common/transforms.py:172-175, MBT2018Synthesis: tfc.SignalConv2D(3, (5, 5), corr=False, strides_up=2, padding="same_zeros");
  * :195-206, CNNSynthesis: conv_t_k5s2 = tf.keras.layers.Conv2DTranspose(3, 5, strides=2, padding="SAME"), :85-87) -- as ONE launch of a
  * vector-ALU kernel:
- *   y[n, 2h, 2w, 3] = conv_transpose(x[n, h, w, cin], w) + bias,   NHWC fp32, no activation (the reference has none there).
+ *   y[n, s h, s w, 3] = conv_transpose(x[n, h, w, cin], w) + bias,   NHWC fp32, no activation (the reference has none there);
+ * also :131-134, BLS2017Synthesis: tfc.SignalConv2D(3, (9, 9), corr=False, strides_up=4) (k = 9, stride 4).
  * With three output channels the layer's four output phases are four groups of 3 columns in 32-wide MFMA tiles on the gather
  * GEMM (9.9 TFLOP/s at 8 x 128 x 128 x 192: a quarter of the mbt2018 config's decode); here a block owns 16 x 16 macro pixels, the
  * input channels pass through LDS in 16-channel slabs, a thread runs the 25 taps x 3 outputs of its 2 x 2 output quad with the
  * weights as scalar operands.  fp32 fma chains in another order than sntc_conv_forward's (tolerance-tested against the oracle);
  * an image's results do not depend on the batch.
- *   kind SNTC_CONV2D_TRANSPOSE: w [5, 5, 3, cin] (Keras);  SNTC_SIGNAL_UP: w [5, 5, cin, 3] (tfc);  bias [3] or NULL.
- * sntc_upsmall_supported: 1 where the kernel exists (those kinds, k = 5, stride 2, cin % 16 == 0, cout = 3), else 0 -- callers then
+ *   kind SNTC_CONV2D_TRANSPOSE: w [k, k, 3, cin] (Keras);  SNTC_SIGNAL_UP: w [k, k, cin, 3] (tfc);  bias [3] or NULL.
+ * sntc_upsmall_supported: 1 where the kernel exists (those kinds, (k, stride) = (5, 2) or (9, 4), cin % 16 == 0, cout = 3), else 0 -- callers then
  * run sntc_conv_forward. */
 typedef struct sntc_upsmall_plan sntc_upsmall_plan;
 int sntc_upsmall_supported(int kind, int k, int stride, int cin, int cout);
@@ -223,7 +224,7 @@ int sntc_upsmall_plan_create(int kind, int k, int stride, int cin, int cout, con
                              sntc_upsmall_plan** plan);
 int sntc_upsmall_plan_update(sntc_upsmall_plan* plan, const float* w, const float* bias, void* stream);
 void sntc_upsmall_plan_destroy(sntc_upsmall_plan* plan);
-/* Algorithmic 2*MAC FLOPs of one call: 2 n h w 25 cin cout (sntc_conv_flops of the layer). */
+/* Algorithmic 2*MAC FLOPs of one call: 2 n h w k k cin cout (sntc_conv_flops of the layer). */
 int64_t sntc_upsmall_flops(const sntc_upsmall_plan* plan, int n, int h, int w);
 int sntc_upsmall_forward(const sntc_upsmall_plan* plan, const float* x, int n, int h, int w, float* y, void* stream);
 /* ------------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
-// up_small.hip -- the LAST layer of the multi-layer syntheses: a stride-2 5 x 5 transposed convolution down to the 3 image channels.
+// up_small.hip -- the LAST layer of the multi-layer syntheses: a 5 x 5 / 2 (or 9 x 9 / 4) transposed convolution down to the 3 image channels.
 //   reference common/transforms.py:172-175  MBT2018Synthesis: tfc.SignalConv2D(3, (5, 5), corr=False, strides_up=2, "same_zeros")
 //             common/transforms.py:195-206  CNNSynthesis:     conv_t_k5s2(output_channels) = Keras Conv2DTranspose(3, 5, strides=2, "SAME") (:85-87)
-//             (BASELINE configs[1], mshyper/configs/mbt2018.py, is the first of the two)
+//             common/transforms.py:131-134  BLS2017Synthesis: tfc.SignalConv2D(3, (9, 9), corr=False, strides_up=4, "same_zeros")
+//             (BASELINE configs[1], mshyper/configs/mbt2018.py, is the first of the three; configs[0], factorized/configs/bls2017.py, the last)
 //
 // With three output channels the layer is no GEMM worth the name: on the gather GEMM its four output phases are four groups of
 // N = 3 columns in 32-wide MFMA tiles (10 % of the MFMAs do work): 0.38 ms = 9.9 TFLOP/s for 8 x 128 x 128 x 192 -> 8 x 256 x 256 x 3,
@@ -41,19 +42,25 @@ struct UpArgs {
   int h, w, cin, pt;
 };
 
+constexpr int taps_of(int ks, int s, int phase) { return (ks - phase + s - 1) / s; }     // kernel indices phase, phase + s, ... < ks
+
 // One output PHASE per wave: a block is 16 x 16 macro pixels x 4 phases = 1024 threads, wave w computes phase (w / 8, (w / 4) & 1) of
 // macro rows 4 (w & 3) .. + 3.  A wave then needs only its phase's taps (9 / 6 / 6 / 4 of the 25), i.e. a quarter of the scalar weight
 // loads per wave at four times the waves.  (Measured, 8 x 128 x 128 x 192: one thread = one macro pixel = all four phases, 256
 // threads: 0.151 ms -- it waited for 1200 scalar loads per slab and wave with 2.5 waves per SIMD to hide them behind; this form:
 // 0.116 ms; two phases per wave paired to 13 / 12 taps, 512 threads, four blocks per CU: 0.127 ms.  The scalar path stays the limit.)
-template <int CO>
+// KS x KS / S: 5 x 5 / 2 (a wave = one of the 4 phases) or 9 x 9 / 4 (a wave = one phase ROW py, its four px phases per thread: 27 or
+// 18 of the 81 taps) -- either way 4 kinds of waves x 4 groups of macro rows.
+template <int KS, int S, int CO>
 __global__ void __launch_bounds__(1024) up_small_kernel(const UpArgs a) {
+  constexpr int NPX = S == 2 ? 1 : S;                // px phases per thread
+  static_assert((S == 2 && KS == 5) || (S == 4 && KS == 9), "two source pixels of halo, four kinds of waves");
   __shared__ __attribute__((aligned(16))) float sh[kTH * kROW];
   const int img = blockIdx.z;
   const int qy0 = blockIdx.y * kTQ, qx0 = blockIdx.x * kTQ;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int phase = wave >> 2;                       // uniform per wave: (py, px) = (phase >> 1, phase & 1)
+  const int kind = wave >> 2;                        // uniform per wave: S = 2: (py, px) = (kind >> 1, kind & 1); S = 4: py = kind
   const int ty = 4 * (wave & 3) + ((tid & 63) >> 4), tx = tid & 15;
   const int nslab = a.cin / kCS;
 
@@ -84,43 +91,57 @@ __global__ void __launch_bounds__(1024) up_small_kernel(const UpArgs a) {
   };
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  float acc[CO];
+  float acc[NPX][CO];
 #pragma unroll
-  for (int o = 0; o < CO; ++o) acc[o] = a.bias[o];
+  for (int i = 0; i < NPX; ++i)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[i][o] = a.bias[o];
 
-  // one slab of this wave's phase (PY, PX): taps ky = PY + 2 jy, kx = PX + 2 jx from tile pixel (ty + 2 - jy, tx + 2 - jx).
-  // Two-level summation: the slab's products in two interleaved chains per output (even / odd channel of a pair, v_pk_fma_f32: the
-  // pixel's channel pair is a VGPR pair as it comes from LDS, the weight pair an SGPR pair as it comes from the scalar load), the
-  // slabs' sums added in slab order (a single chain over 2000 products at cin = 320 carried 4.7 x the MFMA path's rounding error)
-  auto slab = [&](auto PYc, auto PXc, const float* wslab) {
-    constexpr int PY = decltype(PYc)::value, PX = decltype(PXc)::value;
-    f32x2 part[CO];
+  // one slab of this wave's phases (PY, PX0 .. PX0 + NPX - 1): taps ky = PY + S jy, kx = px + S jx from tile pixel
+  // (ty + 2 - jy, tx + 2 - jx).  Two-level summation: the slab's products in two interleaved chains per output (even / odd channel of
+  // a pair, v_pk_fma_f32: the pixel's channel pair is a VGPR pair as it comes from LDS, the weight pair an SGPR pair as it comes from
+  // the scalar load), the slabs' sums added in slab order (a single chain over 2000 products at cin = 320 carried 4.7 x the MFMA
+  // path's rounding error)
+  auto slab = [&](auto PYc, auto PX0c, const float* wslab) {
+    constexpr int PY = decltype(PYc)::value, PX0 = decltype(PX0c)::value;
+    f32x2 part[NPX][CO];
 #pragma unroll
-    for (int o = 0; o < CO; ++o) part[o] = f32x2{0.0f, 0.0f};
+    for (int i = 0; i < NPX; ++i)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) part[i][o] = f32x2{0.0f, 0.0f};
 #pragma unroll 1
     for (int c4 = 0; c4 < kCS / 4; ++c4) {
-      const float* wq = wslab + c4 * (25 * CO * 4);    // [tap][out][4 channels of this quad]: 12 consecutive floats per tap
+      const float* wq = wslab + c4 * (KS * KS * CO * 4);   // [tap][out][4 channels of this quad]: 12 consecutive floats per tap
 #pragma unroll
-      for (int jy = 0; jy < 3 - PY; ++jy)
+      for (int jy = 0; jy < taps_of(KS, S, PY); ++jy)
 #pragma unroll
-        for (int jx = 0; jx < 3 - PX; ++jx) {
-          const int ky = PY + 2 * jy, kx = PX + 2 * jx;
+        for (int jx = 0; jx < taps_of(KS, S, PX0); ++jx) {         // (the first px phase has the most taps)
           const f32x4 hv = *reinterpret_cast<const f32x4*>(sh + (ty + 2 - jy) * kROW + (tx + 2 - jx) * kPX + 4 * c4);
           const f32x2 h01 = f32x2{hv[0], hv[1]}, h23 = f32x2{hv[2], hv[3]};
-          const float* wp = wq + (ky * 5 + kx) * (CO * 4);
 #pragma unroll
-          for (int o = 0; o < CO; ++o) {
-            const f32x2 w01 = f32x2{wp[o * 4], wp[o * 4 + 1]}, w23 = f32x2{wp[o * 4 + 2], wp[o * 4 + 3]};
-            part[o] = __builtin_elementwise_fma(h01, w01, part[o]);
-            part[o] = __builtin_elementwise_fma(h23, w23, part[o]);
+          for (int i = 0; i < NPX; ++i) {
+            if (jx < taps_of(KS, S, PX0 + i)) {
+              const int ky = PY + S * jy, kx = PX0 + i + S * jx;
+              const float* wp = wq + (ky * KS + kx) * (CO * 4);
+#pragma unroll
+              for (int o = 0; o < CO; ++o) {
+                const f32x2 w01 = f32x2{wp[o * 4], wp[o * 4 + 1]}, w23 = f32x2{wp[o * 4 + 2], wp[o * 4 + 3]};
+                part[i][o] = __builtin_elementwise_fma(h01, w01, part[i][o]);
+                part[i][o] = __builtin_elementwise_fma(h23, w23, part[i][o]);
+              }
+            }
           }
         }
     }
 #pragma unroll
-    for (int o = 0; o < CO; ++o) acc[o] += part[o][0] + part[o][1];
+    for (int i = 0; i < NPX; ++i)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) acc[i][o] += part[i][o][0] + part[i][o][1];
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
 
   load_slab(0);
   for (int cc = 0; cc < nslab; ++cc) {
@@ -128,31 +149,42 @@ __global__ void __launch_bounds__(1024) up_small_kernel(const UpArgs a) {
     store_slab();
     __syncthreads();
     if (cc + 1 < nslab) load_slab(cc + 1);             // travels under this slab's arithmetic
-    const float* wslab = a.wpack + (size_t)cc * (25 * CO * kCS);      // uniform: the weights are scalar loads
-    if (phase == 0) slab(I0{}, I0{}, wslab);
-    else if (phase == 1) slab(I0{}, I1{}, wslab);
-    else if (phase == 2) slab(I1{}, I0{}, wslab);
-    else slab(I1{}, I1{}, wslab);
+    const float* wslab = a.wpack + (size_t)cc * (KS * KS * CO * kCS);      // uniform: the weights are scalar loads
+    if constexpr (S == 2) {
+      if (kind == 0) slab(I0{}, I0{}, wslab);
+      else if (kind == 1) slab(I0{}, I1{}, wslab);
+      else if (kind == 2) slab(I1{}, I0{}, wslab);
+      else slab(I1{}, I1{}, wslab);
+    } else {
+      if (kind == 0) slab(I0{}, I0{}, wslab);
+      else if (kind == 1) slab(I1{}, I0{}, wslab);
+      else if (kind == 2) slab(I2{}, I0{}, wslab);
+      else slab(I3{}, I0{}, wslab);
+    }
   }
 
-  const int py = phase >> 1, px = phase & 1;
-  const int oy = 2 * (qy0 + ty) + py - a.pt, ox = 2 * (qx0 + tx) + px - a.pt;
-  if ((unsigned)oy < (unsigned)(2 * a.h) && (unsigned)ox < (unsigned)(2 * a.w)) {
-    float* dst = a.y + (((int64_t)img * (2 * a.h) + oy) * (2 * a.w) + ox) * CO;
+  const int py = S == 2 ? kind >> 1 : kind, px0 = S == 2 ? kind & 1 : 0;
+  const int oy = S * (qy0 + ty) + py - a.pt;
 #pragma unroll
-    for (int o = 0; o < CO; ++o) dst[o] = acc[o];
+  for (int i = 0; i < NPX; ++i) {
+    const int ox = S * (qx0 + tx) + px0 + i - a.pt;
+    if ((unsigned)oy < (unsigned)(S * a.h) && (unsigned)ox < (unsigned)(S * a.w)) {
+      float* dst = a.y + (((int64_t)img * (S * a.h) + oy) * (S * a.w) + ox) * CO;
+#pragma unroll
+      for (int o = 0; o < CO; ++o) dst[o] = acc[i][o];
+    }
   }
 }
 
 // wpack[slab][channel quad][tap][o][4] from the layer's kernel: Keras Conv2DTranspose [5, 5, Cout, Cin] (io == 0) or tfc.SignalConv2D
 // [5, 5, Cin, Cout] (io == 1: true convolution, no flip in scatter form -- SURVEY.md A.3)
-__global__ void __launch_bounds__(256) up_small_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int co, int io) {
-  const int total = (cin / kCS) * 25 * co * kCS;
+__global__ void __launch_bounds__(256) up_small_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int co, int io, int ntap) {
+  const int total = (cin / kCS) * ntap * co * kCS;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int e = idx & 3;
     int r = idx >> 2;
     const int o = r % co; r /= co;
-    const int tap = r % 25; r /= 25;
+    const int tap = r % ntap; r /= ntap;
     const int c4 = r % (kCS / 4);
     const int slab = r / (kCS / 4);
     const int c = slab * kCS + 4 * c4 + e;
@@ -169,7 +201,7 @@ __global__ void up_small_bias_kernel(const float* b, float* out, int co) {
 }  // namespace sntc
 
 struct sntc_upsmall_plan {
-  int kind = SNTC_CONV2D_TRANSPOSE, cin = 0, cout = 0;
+  int kind = SNTC_CONV2D_TRANSPOSE, cin = 0, cout = 0, k = 5, stride = 2;
   float* wpack = nullptr;
   float* bias = nullptr;
 };
@@ -177,9 +209,9 @@ struct sntc_upsmall_plan {
 using namespace sntc;
 
 static int up_pack(sntc_upsmall_plan* p, const float* w, const float* bias, hipStream_t s) {
-  const int total = (p->cin / kCS) * 25 * p->cout * kCS;
+  const int total = (p->cin / kCS) * p->k * p->k * p->cout * kCS;
   hipLaunchKernelGGL(up_small_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, p->wpack, p->cin, p->cout,
-                     p->kind == SNTC_SIGNAL_UP ? 1 : 0);
+                     p->kind == SNTC_SIGNAL_UP ? 1 : 0, p->k * p->k);
   hipLaunchKernelGGL(up_small_bias_kernel, dim3(1), dim3(64), 0, s, bias, p->bias, p->cout);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "small-output transposed convolution: weight packing");
@@ -187,7 +219,7 @@ static int up_pack(sntc_upsmall_plan* p, const float* w, const float* bias, hipS
 }
 
 extern "C" int sntc_upsmall_supported(int kind, int k, int stride, int cin, int cout) {
-  return ((kind == SNTC_CONV2D_TRANSPOSE || kind == SNTC_SIGNAL_UP) && k == 5 && stride == 2 && cin >= kCS && cin % kCS == 0 && cout == 3) ? 1 : 0;
+  return ((kind == SNTC_CONV2D_TRANSPOSE || kind == SNTC_SIGNAL_UP) && ((k == 5 && stride == 2) || (k == 9 && stride == 4)) && cin >= kCS && cin % kCS == 0 && cout == 3) ? 1 : 0;
 }
 
 static void up_free(sntc_upsmall_plan* p) {
@@ -200,11 +232,11 @@ extern "C" int sntc_upsmall_plan_create(int kind, int k, int stride, int cin, in
                                         sntc_upsmall_plan** plan) {
   if (!plan || !w) return fail(SNTC_ERR_BAD_SHAPE, "sntc_upsmall_plan_create: null argument");
   if (!sntc_upsmall_supported(kind, k, stride, cin, cout))
-    return fail(SNTC_ERR_UNSUPPORTED, "sntc_upsmall_plan_create: the kernel exists for Conv2DTranspose / SignalConv2D(strides_up) 5 x 5 / 2, "
+    return fail(SNTC_ERR_UNSUPPORTED, "sntc_upsmall_plan_create: the kernel exists for Conv2DTranspose / SignalConv2D(strides_up) 5 x 5 / 2 and 9 x 9 / 4, "
                                       "cin % 16 == 0, 3 output channels");
   auto* p = new sntc_upsmall_plan();
-  p->kind = kind; p->cin = cin; p->cout = cout;
-  if (hipMalloc(&p->wpack, sizeof(float) * 25 * cin * cout) != hipSuccess || hipMalloc(&p->bias, sizeof(float) * 4) != hipSuccess) {
+  p->kind = kind; p->cin = cin; p->cout = cout; p->k = k; p->stride = stride;
+  if (hipMalloc(&p->wpack, sizeof(float) * k * k * cin * cout) != hipSuccess || hipMalloc(&p->bias, sizeof(float) * 4) != hipSuccess) {
     up_free(p);
     return fail(SNTC_ERR_HIP, "sntc_upsmall_plan_create: out of device memory");
   }
@@ -227,7 +259,7 @@ extern "C" void sntc_upsmall_plan_destroy(sntc_upsmall_plan* p) {
 
 extern "C" int64_t sntc_upsmall_flops(const sntc_upsmall_plan* p, int n, int h, int w) {
   if (!p || n < 0 || h < 0 || w < 0) return -1;
-  return 2 * (int64_t)n * h * w * 25 * p->cin * p->cout;
+  return 2 * (int64_t)n * h * w * p->k * p->k * p->cin * p->cout;
 }
 
 extern "C" int sntc_upsmall_forward(const sntc_upsmall_plan* p, const float* x, int n, int h, int w, float* y, void* stream) {
@@ -239,9 +271,10 @@ extern "C" int sntc_upsmall_forward(const sntc_upsmall_plan* p, const float* x, 
   UpArgs a{};
   a.x = x; a.y = y; a.wpack = p->wpack; a.bias = p->bias;
   a.h = h; a.w = w; a.cin = p->cin;
-  a.pt = p->kind == SNTC_SIGNAL_UP ? 2 : 1;            // (k - 1) / 2 for the centred kernel; A.2: (k - s) / 2 for Keras SAME
+  a.pt = p->kind == SNTC_SIGNAL_UP ? (p->k - 1) / 2 : (p->k - p->stride) / 2;     // the centred kernel; A.2: Keras SAME
   const dim3 grid((w + 1 + kTQ - 1) / kTQ, (h + 1 + kTQ - 1) / kTQ, n);
-  hipLaunchKernelGGL((up_small_kernel<3>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+  if (p->stride == 2) hipLaunchKernelGGL((up_small_kernel<5, 2, 3>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((up_small_kernel<9, 4, 3>), grid, dim3(1024), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "small-output transposed convolution launch");
   return SNTC_OK;

@@ -943,7 +943,7 @@ SMALL_OUTPUT_LAYER = not os.environ.get("SNTC_NO_UPSMALL")   # the 5x5/2 transpo
 
 class UpSmallPlan:
     """The last layer of the multi-layer syntheses (reference common/transforms.py:172-175 MBT2018Synthesis, :195-206
-    CNNSynthesis): a 5 x 5 / 2 transposed convolution to the 3 image channels as one launch of a vector-ALU kernel --
+    CNNSynthesis: 5 x 5 / 2; :131-134 BLS2017Synthesis: 9 x 9 / 4): a transposed convolution to the 3 image channels as one launch of a vector-ALU kernel --
     sntc_upsmall_plan (csrc/up_small.hip); ``kind`` "convT" (Keras kernel [5, 5, 3, cin]) or "sigup" (tfc kernel [5, 5, cin, 3])."""
 
     @staticmethod
@@ -984,7 +984,7 @@ class UpSmallPlan:
             raise ValueError("the small-output transposed convolution has no epilogue operands")
         _check_nhwc(x, self.cin)
         n, h, w, _ = x.shape
-        y = torch.empty((n, 2 * h, 2 * w, self.cout), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, self.stride * h, self.stride * w, self.cout), dtype=torch.float32, device=x.device)
         prof = PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -501,6 +501,25 @@ def test_small_output_transposed_conv_kernel(kind, dev):
         np.testing.assert_array_equal(line, want[:, None] * np.array([1, 2, 3], np.float32)[None, :])
         rest = y[:, 1:] if axis == 0 else y[1:, :]
         assert not rest.any()
+    # 9 x 9 / 4 (BLS2017Synthesis' last layer, reference common/transforms.py:131-134): four px phases per thread, a phase row per wave
+    assert ops.UpSmallPlan.supported(kind, 9, 4, 256, 3) and not ops.UpSmallPlan.supported(kind, 9, 2, 256, 3)
+    for n, h, w, cin in ((2, 16, 12, 256), (1, 5, 7, 32), (1, 19, 33, 64)):
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        wk = (rng.standard_normal((9, 9, 3, cin) if kind == "convT" else (9, 9, cin, 3)) / np.sqrt(81 * cin / 16)).astype(np.float32)
+        b = rng.standard_normal(3).astype(np.float32)
+        ref = fn(x, wk, b, 4)
+        plan = ops.UpSmallPlan(kind, dev_t(wk, dev), dev_t(b, dev), 4)
+        gen = ops.ConvPlan(kind, dev_t(wk, dev), dev_t(b, dev), 4)
+        got = plan(dev_t(x, dev))
+        assert tuple(got.shape) == ref.shape == (n, 4 * h, 4 * w, 3)
+        e_new, e_gen = rel_err(got.cpu().numpy(), ref), rel_err(gen(dev_t(x, dev)).cpu().numpy(), ref)
+        assert e_new < 2e-6 and e_new < 4 * e_gen + 2e-7, (n, h, w, cin, e_new, e_gen)
+        assert torch.equal(plan(dev_t(x[:1], dev)), got[:1])
+        assert plan.flops(n, h, w) == gen.flops(n, h, w)
+    if kind == "sigup":
+        tb = TR.BLS2017Synthesis(256)
+        tb(dev_t(rng.standard_normal((1, 4, 4, 256)).astype(np.float32) * 0.3, dev))
+        assert isinstance(tb._graph.layers[-1].plan, ops.UpSmallPlan) and tb._graph.layers[-1].plan.stride == 4
     t = TR.MBT2018Synthesis(192, output_channels=3) if kind == "sigup" else TR.CNNSynthesis(192, output_channels=3)
     t(dev_t(rng.standard_normal((1, 4, 4, 320)).astype(np.float32) * 0.3, dev))
     assert isinstance(t._graph.layers[-1].plan, ops.UpSmallPlan)

@@ -34,7 +34,7 @@ WATCH = {
                       "syn_kernel<24, false>": "syn_kernelILi24ELb0EE"},
     "rgb_conv.hip": {"rgb_conv_kernel<6, 5, false> (ELIC first layer)": "rgb_conv_kernelILi6ELi5ELb0EE",
                      "rgb_conv_kernel<8, 5, true>": "rgb_conv_kernelILi8ELi5ELb1EE"},
-    "up_small.hip": {"up_small_kernel<3>": "up_small_kernelILi3EE"},
+    "up_small.hip": {"up_small_kernel<5, 2, 3>": "up_small_kernelILi5ELi2ELi3EE", "up_small_kernel<9, 4, 3>": "up_small_kernelILi9ELi4ELi3EE"},
     "entropy.hip": {"scale_normal_kernel<false>": "scale_normal_kernelILb0EE", "factorized_fast_kernel<3, 3>": "factorized_fast_kernelILi3ELi3EE"},
 }
 FIELDS = {"VGPRs": r"\bVGPRs: (\d+)", "AGPRs": r"AGPRs: (\d+)", "SGPRs": r"TotalSGPRs: (\d+)", "scratch_bytes": r"ScratchSize \[bytes/lane\]: (\d+)",
