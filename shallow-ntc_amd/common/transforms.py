@@ -452,7 +452,8 @@ class _TwoLayerBase(Transform):
             self.build(cin if cin is not None else (x.shape[-1] if x.dim() == 4 else x.shape[3] * 16), x.device)
 
     def _use_syn(self, x, alone=True):
-        ok = self._syn is not None and ops.FUSED_SYNTHESIS and x.dim() == 4 and self._syn.fits(x)
+        ok = (self._syn is not None and ops.FUSED_SYNTHESIS and x.dim() == 4 and self._syn.fits(x)
+              and (2 if self._has_res else 1) * self._ch >= ops.FUSED_SYNTHESIS_MIN_COLUMNS)
         return ok and (not alone or self._syn.items([x]) >= ops.FUSED_SYNTHESIS_MIN_ITEMS)
 
     def hidden_many(self, xs):

@@ -222,6 +222,10 @@ class ResBlockPlan:
 
 
 FUSED_SYNTHESIS_MIN_ITEMS = 512   # ... where the launch offers about two items per CU (speed only: the same bits either way)
+FUSED_SYNTHESIS_MIN_COLUMNS = 24  # ... and the layer has at least 24 output columns per phase ((1 + has_res) x hidden channels): with 12
+                                  # (TwoLayerSynthesis(12, 3), the default of two_layer_syn2) a unit of 96 columns is eight phases whose shift
+                                  # sets pad each other -- 86 against 108 TFLOP/s for the gather GEMM, whose [base] output the tail kernel
+                                  # activates in its own stage 1 anyway: decode of 5 x 1200 x 1200 2.36 -> 2.27 ms without it (round 6)
 FUSED_SYNTHESIS = not os.environ.get("SNTC_NO_SYN_FUSE")   # two-layer syntheses: first layer + activation + residual in ONE launch (csrc/syn_fused.hip;
                                                            # bit-identical; False: phase-grouped gather GEMM + the tail kernel's stage 1)
 

@@ -244,3 +244,27 @@ def test_a_set_of_batches_replays_from_one_graph(dev):
     want2 = [model.decode(z, s, hw) for z, s, hw in flipped]
     for got, ref in zip(graph(flipped), want2):
         assert torch.equal(got, ref)
+
+
+def test_fused_synthesis_is_taken_from_24_columns_per_phase_on(dev):
+    """ops.FUSED_SYNTHESIS_MIN_COLUMNS: TwoLayerSynthesis(12, 3) (two_layer_syn2's default; 12 output columns per phase) decodes
+    through the gather GEMM + the tail kernel's own activation stage (faster there: DESIGN.md 8), TwoLayerResSynthesis(12, 3) and
+    TwoLayerSynthesis(24, 3) through the fused launch -- the same pixels either way (the fused kernel is bit-identical to the layers)."""
+    from shallow_ntc_amd import ops
+    from shallow_ntc_amd.common import transforms as TR
+    rng = np.random.default_rng(12)
+    y_hat = dev_t(rng.standard_normal((6, 48, 32, 320)).astype(np.float32), dev)           # 6 x 6 tiles x 8 units = 288 items
+    old_items, old_cols = ops.FUSED_SYNTHESIS_MIN_ITEMS, ops.FUSED_SYNTHESIS_MIN_COLUMNS
+    ops.FUSED_SYNTHESIS_MIN_ITEMS = 1
+    try:
+        for t, fused_by_default in ((TR.TwoLayerSynthesis(channels=(12, 3)), False), (TR.TwoLayerSynthesis(channels=(24, 3)), True),
+                                    (TR.TwoLayerResSynthesis(channels=(12, 3)), True)):
+            px, _ = t.forward_pixels(y_hat, 768, 512)
+            assert t._use_syn(y_hat) == fused_by_default
+            ops.FUSED_SYNTHESIS_MIN_COLUMNS = 12 if not fused_by_default else 1000       # the other path
+            assert t._use_syn(y_hat) != fused_by_default
+            px2, _ = t.forward_pixels(y_hat, 768, 512)
+            ops.FUSED_SYNTHESIS_MIN_COLUMNS = old_cols
+            assert torch.equal(px, px2)
+    finally:
+        ops.FUSED_SYNTHESIS_MIN_ITEMS, ops.FUSED_SYNTHESIS_MIN_COLUMNS = old_items, old_cols
